@@ -1,0 +1,137 @@
+"""ctypes binding of ``libghr_hip.so`` (C ABI in ``include/ghr.h``) and its in-tree build recipe.
+
+The shared library is the product: there is **no** CPU or eager-PyTorch fallback.  If the library is missing and
+cannot be built (no ``hipcc``) importing it raises, and every entry point refuses non-ROCm tensors.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libghr_hip.so")
+SOURCES = ["ghr_capi.hip"]
+HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h",
+           "ghr_geom_bwd.h"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
+               "-shared"]
+
+NUM_CHANNELS = 10
+GRAD_STRIDE = 16
+
+GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
+
+
+class GhrError(RuntimeError):
+    pass
+
+
+def _hipcc() -> Optional[str]:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+def _stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(_HERE, "..", "include", "ghr.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 into ``csrc/libghr_hip.so`` (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    if hipcc is None:
+        raise GhrError("libghr_hip.so is missing/stale and hipcc was not found; the HIP extension is required "
+                       "(there is no CPU fallback)")
+    tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise GhrError("hipcc failed:\n" + res.stdout + res.stderr)
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+class ViewArgs(ctypes.Structure):
+    """``ghr_view_args`` (include/ghr.h)."""
+    _fields_ = [
+        ("P", ctypes.c_int32), ("W", ctypes.c_int32), ("H", ctypes.c_int32), ("C", ctypes.c_int32),
+        ("background", ctypes.c_void_p), ("means3D", ctypes.c_void_p), ("colors", ctypes.c_void_p),
+        ("opacities", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("rotations", ctypes.c_void_p),
+        ("cov3D_precomp", ctypes.c_void_p), ("conic_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
+        ("projmatrix", ctypes.c_void_p), ("scale_modifier", ctypes.c_float), ("tan_fovx", ctypes.c_float),
+        ("tan_fovy", ctypes.c_float), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+    ]
+
+
+class WsView(ctypes.Structure):
+    """``ghr_ws_view`` (include/ghr.h) -- test introspection."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "cov3D", "final_T", "n_contrib",
+                                                "tile_start", "keys", "point_list")]
+
+
+# Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
+EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
+           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect"]
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (building first if needed) the HIP library.  torch must be imported first so that the HIP runtime the
+    library binds to (soname libamdhip64.so.7) is the one torch already loaded -- streams and pointers are shared."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (load torch's libamdhip64 first)
+    build_library()
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, u32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_float
+    L.ghr_last_error.restype = ctypes.c_char_p
+    L.ghr_abi_version.restype = ctypes.c_int
+    L.ghr_forward_sizes.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t),
+                                    ctypes.POINTER(ctypes.c_size_t)]
+    L.ghr_binning_size.argtypes = [u32, ctypes.POINTER(ctypes.c_size_t)]
+    L.ghr_forward_stage1.argtypes = [vp, ctypes.POINTER(ViewArgs), vp, vp, vp, vp]
+    L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp]
+    L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
+    L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("ghr_last_error",):
+            fn.restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != GHR_OK:
+        msg = lib().ghr_last_error().decode("utf-8", "replace")
+        if rc == GHR_E_NOCOLORS:
+            raise RuntimeError(msg)  # same text as the reference's std::runtime_error (rasterizer_impl.cu:246)
+        raise GhrError("libghr_hip: %s (code %d)" % (msg, rc))
+
+
+def forward_sizes(P: int, W: int, H: int, mode_b: bool):
+    g, i = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    check(lib().ghr_forward_sizes(P, W, H, int(mode_b), ctypes.byref(g), ctypes.byref(i)))
+    return int(g.value), int(i.value)
+
+
+def binning_size(R: int) -> int:
+    b = ctypes.c_size_t(0)
+    check(lib().ghr_binning_size(R, ctypes.byref(b)))
+    return int(b.value)

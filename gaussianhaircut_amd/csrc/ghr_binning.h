@@ -1,0 +1,140 @@
+// ghr_binning.h -- tile binning: offset scan, instance scatter, per-tile depth sort.
+//
+// Replaces the reference's K2-K6 (R:cuda_rasterizer/rasterizer_impl.cu:70-138,281-321): inclusive scan over P,
+// duplicateWithKeys, a global 64-bit (tile|depth) stable radix sort of R pairs (6+ passes x 24 B/instance) and
+// identifyTileRanges.  Because the sorted list is only ever consumed tile by tile, the same result is produced
+// here with one pass each:
+//   k_tile_scan : exclusive scan of the T per-tile counts -> tile_start[T+1]  (== `ranges`, rasterizer_impl.cu:116-138)
+//   k_scatter   : each Gaussian appends (depth_bits<<32 | idx) to the lists of the tiles in its rect (8 B/instance)
+//   k_tile_sort : one workgroup sorts one tile's list in LDS by (depth_bits, idx) and emits point_list (4 B/instance)
+// Equivalence: the reference's key is (tile<<32 | depth_bits), sorted stably, with instances emitted in ascending
+// Gaussian index (rasterizer_impl.cu:88-108), so within a tile its order is "depth bits ascending, ties by ascending
+// idx" -- exactly the total order of the 64-bit key used here.  point_list and ranges are therefore bit-identical
+// to the reference's, independent of the (non-deterministic) order in which k_scatter appends.
+#pragma once
+#include "ghr_device.h"
+
+namespace ghr {
+
+#define GHR_SCAN_BLOCK 1024
+#define GHR_SORT_CAP 4096  // keys sorted in LDS (32 KiB); longer lists use the in-place global path
+
+// Exclusive scan of tile_count[T] into tile_start[T+1]; resets tile_count to 0 so k_scatter can reuse it as the
+// per-tile append cursor; publishes R = tile_start[T].
+__global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
+                                                              uint32_t* R_out)
+{
+    __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
+    const int tid = threadIdx.x;
+    const int per = (T + GHR_SCAN_BLOCK - 1) / GHR_SCAN_BLOCK;
+    const int b = tid * per, e = min(T, b + per);
+    uint32_t sum = 0;
+    for (int i = b; i < e; i++) sum += tile_count[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over the 1024 partials
+    for (int off = 1; off < GHR_SCAN_BLOCK; off <<= 1) {
+        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
+    for (int i = b; i < e; i++) {
+        const uint32_t c = tile_count[i];
+        tile_start[i] = run;
+        tile_count[i] = 0u;
+        run += c;
+    }
+    if (tid == GHR_SCAN_BLOCK - 1) {
+        const uint32_t total = s_part[GHR_SCAN_BLOCK - 1];
+        tile_start[T] = total;
+        *R_out = total;
+    }
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const uint2* __restrict__ rects,
+                                                       const float* __restrict__ depths,
+                                                       const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
+                                                       uint64_t* keys)
+{
+    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const uint2 r = rects[idx];
+    const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
+    if (x1 <= x0 || y1 <= y0) return;
+    const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const int t = y * gx + x;
+            const uint32_t pos = atomicAdd(&tile_cursor[t], 1u);
+            keys[tile_start[t] + pos] = key;
+        }
+}
+
+// Bitonic network in its "flip" form: every compare-exchange moves the smaller key to the lower index, so virtual
+// +inf padding beyond n never moves and exchanges whose upper index is >= n are simply skipped (any n, no padding).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GHR_SYNC() __syncthreads()
+#else
+#define GHR_SYNC() ((void)0)  // tests/hostsim runs the network with one "thread": steps are already ordered
+#endif
+template <typename KeyPtr>
+GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
+{
+    uint32_t np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    const uint32_t half = np2 >> 1;
+    for (uint32_t size = 2; size <= np2; size <<= 1) {
+        const uint32_t hs = size >> 1;
+        for (uint32_t i = tid; i < half; i += nthreads) {  // flip: l <-> block_end - offset
+            const uint32_t blk = i / hs, off = i - blk * hs;
+            const uint32_t l = blk * size + off, u = blk * size + (size - 1 - off);
+            if (u < n) {
+                const uint64_t a = k[l], b = k[u];
+                if (b < a) { k[l] = b; k[u] = a; }
+            }
+        }
+        GHR_SYNC();
+        for (uint32_t j = hs >> 1; j >= 1; j >>= 1) {  // disperse: l <-> l + j
+            for (uint32_t i = tid; i < half; i += nthreads) {
+                const uint32_t l = 2 * j * (i / j) + (i % j), u = l + j;
+                if (u < n) {
+                    const uint64_t a = k[l], b = k[u];
+                    if (b < a) { k[l] = b; k[u] = a; }
+                }
+            }
+            GHR_SYNC();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
+                                                         uint64_t* keys, uint32_t* point_list)
+{
+    __shared__ uint64_t s_keys[GHR_SORT_CAP];
+    const uint32_t tile = xcd_tile(blockIdx.x, T);
+    const uint32_t s = tile_start[tile];
+    const uint32_t n = tile_start[tile + 1] - s;
+    if (n == 0) return;
+    const int tid = threadIdx.x;
+    uint64_t* g = keys + s;
+    if (n <= GHR_SORT_CAP) {
+        for (uint32_t i = tid; i < n; i += GHR_BLOCK) s_keys[i] = g[i];
+        __syncthreads();
+        if (n > 1) bitonic_any_n(s_keys, n, tid, GHR_BLOCK);
+        for (uint32_t i = tid; i < n; i += GHR_BLOCK) {
+            const uint64_t k = s_keys[i];
+            g[i] = k;
+            point_list[s + i] = (uint32_t)k;
+        }
+    } else {
+        // Rare: a single tile with more instances than fit in LDS.  Same network, in place in global memory
+        // (one workgroup => same CU/L1, __syncthreads orders the accesses).
+        __syncthreads();
+        bitonic_any_n(g, n, tid, GHR_BLOCK);
+        for (uint32_t i = tid; i < n; i += GHR_BLOCK) point_list[s + i] = (uint32_t)g[i];
+    }
+}
+
+}  // namespace ghr

@@ -1,0 +1,273 @@
+// ghr_capi.hip -- C ABI of libghr_hip.so (declared in include/ghr.h).  Host-side orchestration only:
+// workspace carving, argument checks, kernel launches on the caller's stream.  Replaces
+// R:rasterize_points.cu (torch glue) + R:cuda_rasterizer/rasterizer_impl.cu:155-441 (state carving, forward, backward).
+#include "../../include/ghr.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "ghr_binning.h"
+#include "ghr_device.h"
+#include "ghr_geom_bwd.h"
+#include "ghr_preprocess.h"
+#include "ghr_render_bwd.h"
+#include "ghr_render_fwd.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* detail = "")
+{
+    std::snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define GHR_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) return fail(GHR_E_HIP, #expr ": %s", hipGetErrorString(e_)); \
+    } while (0)
+
+constexpr size_t ALIGN = 256;
+inline size_t up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
+
+// Sub-allocation of the three caller-owned workspaces (cf. obtain()/fromChunk, rasterizer_impl.h:21-73).
+struct Geom {
+    ghr::f4* rec;
+    float* depths;
+    uint2* rects;
+    float* cov3D;
+};
+struct Img {
+    float* final_T;
+    uint32_t* n_contrib;
+    uint32_t* tile_count;  // per-tile instance count, then append cursor
+    uint32_t* tile_start;  // [T+1]
+    uint32_t* R_dev;
+};
+struct Bin {
+    uint64_t* keys;
+    uint32_t* point_list;
+};
+
+size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
+    ghr::f4* rec = (ghr::f4*)take(P * 64);
+    float* depths = (float*)take(P * 4);
+    uint2* rects = (uint2*)take(P * 8);
+    float* cov3D = mode_b ? (float*)take(P * 24) : nullptr;
+    if (g) *g = Geom{rec, depths, rects, cov3D};
+    return off + ALIGN;
+}
+size_t carve_img(char* base, size_t N, size_t T, Img* im)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
+    float* final_T = (float*)take(N * 4);
+    uint32_t* n_contrib = (uint32_t*)take(N * 4);
+    uint32_t* tile_count = (uint32_t*)take(T * 4);
+    uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
+    uint32_t* R_dev = (uint32_t*)take(4);
+    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev};
+    return off + ALIGN;
+}
+size_t carve_bin(char* base, size_t R, Bin* b)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
+    uint64_t* keys = (uint64_t*)take(R * 8);
+    uint32_t* pl = (uint32_t*)take(R * 4);
+    if (b) *b = Bin{keys, pl};
+    return off + ALIGN;
+}
+inline char* align_base(const void* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
+
+int check_view(const ghr_view_args* a)
+{
+    if (!a) return fail(GHR_E_INVALID, "ghr_view_args is NULL");
+    if (a->P < 0 || a->W <= 0 || a->H <= 0) return fail(GHR_E_INVALID, "bad P/W/H");
+    if (a->C != GHR_NUM_CHANNELS) return fail(GHR_E_INVALID, "C must equal GHR_NUM_CHANNELS (10)");
+    if (a->P == 0) return GHR_OK;
+    if (!a->colors) return fail(GHR_E_NOCOLORS, "For non-RGB, provide precomputed Gaussian colors!");
+    if (!a->means3D || !a->opacities || !a->background || !a->viewmatrix || !a->projmatrix)
+        return fail(GHR_E_INVALID, "means3D/opacities/background/viewmatrix/projmatrix must be non-NULL");
+    if (!a->conic_precomp && !a->cov3D_precomp && !(a->scales && a->rotations))
+        return fail(GHR_E_INVALID, "kernel-geometry mode needs cov3D_precomp or scales+rotations");
+    if ((a->W + GHR_TILE - 1) / GHR_TILE > 65535 || (a->H + GHR_TILE - 1) / GHR_TILE > 65535)
+        return fail(GHR_E_INVALID, "image too large for 16-bit tile coordinates");
+    return GHR_OK;
+}
+
+int finish(hipStream_t s, int debug)
+{
+    GHR_HIP(hipGetLastError());
+    if (debug) GHR_HIP(hipStreamSynchronize(s));
+    return GHR_OK;
+}
+
+inline int grid_x(int W) { return (W + GHR_TILE - 1) / GHR_TILE; }
+
+}  // namespace
+
+extern "C" {
+
+const char* ghr_last_error(void) { return g_err; }
+int ghr_abi_version(void) { return GHR_ABI_VERSION; }
+
+int ghr_forward_sizes(int32_t P, int32_t W, int32_t H, int32_t mode_b, size_t* geom_bytes, size_t* img_bytes)
+{
+    if (P < 0 || W <= 0 || H <= 0 || !geom_bytes || !img_bytes) return fail(GHR_E_INVALID, "ghr_forward_sizes: bad args");
+    const size_t T = (size_t)grid_x(W) * grid_x(H);
+    *geom_bytes = carve_geom(nullptr, (size_t)P, mode_b != 0, nullptr);
+    *img_bytes = carve_img(nullptr, (size_t)W * H, T, nullptr);
+    return GHR_OK;
+}
+
+int ghr_binning_size(uint32_t R, size_t* bin_bytes)
+{
+    if (!bin_bytes) return fail(GHR_E_INVALID, "ghr_binning_size: bad args");
+    *bin_bytes = carve_bin(nullptr, (size_t)R, nullptr);
+    return GHR_OK;
+}
+
+int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void* img_ws, int32_t* radii,
+                       uint32_t* R_host)
+{
+    if (int rc = check_view(a)) return rc;
+    if (!R_host) return fail(GHR_E_INVALID, "R_host is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if (a->P == 0) { *R_host = 0; return GHR_OK; }
+    if (!geom_ws || !img_ws || !radii) return fail(GHR_E_INVALID, "workspace/radii is NULL");
+    const bool mode_b = a->conic_precomp == nullptr;
+    const int gx = grid_x(a->W), gy = grid_x(a->H);
+    const int T = gx * gy;
+    Geom g; Img im;
+    carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
+    carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
+
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    ghr::PreArgs pa;
+    pa.P = a->P; pa.W = a->W; pa.H = a->H; pa.gx = gx; pa.gy = gy;
+    pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;
+    pa.scales = a->scales; pa.rotations = a->rotations;
+    pa.cov3D_precomp = a->cov3D_precomp; pa.conic_precomp = a->conic_precomp;
+    pa.view = a->viewmatrix; pa.proj = a->projmatrix;
+    pa.scale_modifier = a->scale_modifier; pa.tan_fovx = a->tan_fovx; pa.tan_fovy = a->tan_fovy;
+    pa.focal_y = a->H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:224-225
+    pa.focal_x = a->W / (2.0f * a->tan_fovx);
+    pa.rec = g.rec; pa.depths = g.depths; pa.rects = g.rects; pa.cov3D = g.cov3D; pa.radii = radii;
+    pa.tile_count = im.tile_count;
+    hipLaunchKernelGGL(ghr::k_preprocess, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, pa);
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev);
+    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return finish(s, a->debug);
+}
+
+int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
+                       float* out_color)
+{
+    if (int rc = check_view(a)) return rc;
+    if (!out_color) return fail(GHR_E_INVALID, "out_color is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    const int gx = grid_x(a->W), gy = grid_x(a->H);
+    const int T = gx * gy;
+    if (a->P == 0) {
+        // Nothing to splat: the reference skips the whole forward and returns the zero-filled image
+        // (rasterize_points.cu:70,87); keep that.
+        GHR_HIP(hipMemsetAsync(out_color, 0, sizeof(float) * (size_t)a->C * a->W * a->H, s));
+        return finish(s, a->debug);
+    }
+    if (!geom_ws || !img_ws || (R > 0 && !bin_ws)) return fail(GHR_E_INVALID, "workspace is NULL");
+    const bool mode_b = a->conic_precomp == nullptr;
+    Geom g; Img im; Bin b;
+    carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
+    carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    if (R > 0) {
+        hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a->P, gx,
+                           g.rects, g.depths, im.tile_start, im.tile_count, b.keys);
+        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
+                           b.point_list);
+    }
+    hipLaunchKernelGGL(ghr::k_render_fwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T, im.tile_start,
+                       b.point_list, g.rec, a->background, out_color, im.final_T, im.n_contrib);
+    return finish(s, a->debug);
+}
+
+int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
+                 const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations)
+{
+    if (int rc = check_view(a)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (a->P == 0) return GHR_OK;
+    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || !grad_scratch || !dL_dmeans2D ||
+        !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations)
+        return fail(GHR_E_INVALID, "ghr_backward: NULL buffer");
+    const bool mode_b = a->conic_precomp == nullptr;
+    const int gx = grid_x(a->W), gy = grid_x(a->H);
+    const int T = gx * gy;
+    Geom g; Img im; Bin b;
+    carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
+    carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+
+    GHR_HIP(hipMemsetAsync(grad_scratch, 0, sizeof(float) * GHR_GRAD_STRIDE * (size_t)a->P, s));
+    if (R > 0)
+        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T,
+                           im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib, dL_dpix,
+                           grad_scratch);
+    ghr::GeomBwdArgs ga;
+    ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
+    ga.cov3D = g.cov3D; ga.conic_precomp = a->conic_precomp; ga.view = a->viewmatrix; ga.proj = a->projmatrix;
+    ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
+    ga.focal_y = a->H / (2.0f * a->tan_fovy);
+    ga.focal_x = a->W / (2.0f * a->tan_fovx);
+    ga.gacc = grad_scratch;
+    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
+    ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
+    hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
+    return finish(s, a->debug);
+}
+
+int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;
+    if (P < 0) return fail(GHR_E_INVALID, "P < 0");
+    if (P == 0) return GHR_OK;
+    if (!means3D || !viewmatrix || !present) return fail(GHR_E_INVALID, "ghr_mark_visible: NULL buffer");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ghr::k_mark_visible, dim3((P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, P, means3D,
+                       viewmatrix, present);
+    return finish(s, 0);
+}
+
+int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, const void* geom_ws,
+                   const void* img_ws, const void* bin_ws, ghr_ws_view* out)
+{
+    if (!out || P < 0 || W <= 0 || H <= 0) return fail(GHR_E_INVALID, "ghr_ws_inspect: bad args");
+    const size_t T = (size_t)grid_x(W) * grid_x(H);
+    Geom g; Img im; Bin b;
+    carve_geom(align_base(geom_ws), (size_t)P, mode_b != 0, &g);
+    carve_img(align_base(img_ws), (size_t)W * H, T, &im);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    out->rec = (const float*)g.rec;
+    out->depths = g.depths;
+    out->rects = (const uint32_t*)g.rects;
+    out->cov3D = g.cov3D;
+    out->final_T = im.final_T;
+    out->n_contrib = im.n_contrib;
+    out->tile_start = im.tile_start;
+    out->keys = b.keys;
+    out->point_list = b.point_list;
+    return GHR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// ghr_device.h -- shared device helpers for the gfx950 rasterizer kernels.
+//
+// Arithmetic discipline: the translation unit is compiled with -ffp-contract=off, so `a*b+c` is two rounded fp32
+// operations unless written as __builtin_fmaf.  Everything that feeds a DISCRETE decision of the reference
+// (near cull, radius ceil, tile rect truncation, depth key bits, power>0, alpha<1/255, T<1e-4) is written in the
+// reference's source order without fusion, so those decisions are reproducible on a CPU; accumulations that only
+// feed continuous outputs use explicit FMAs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define GHR_TILE_X 16
+#define GHR_TILE_Y 16
+#define GHR_BLOCK 256
+#define GHR_C 10
+#define GHR_REC 16  // floats per packed per-Gaussian render record (one 64-B line)
+
+// Pure math helpers are host+device so that tests/hostsim can run the SAME per-Gaussian / per-pixel code on
+// the CPU and compare it with the oracle without a GPU (test scaffolding; the product never runs on the host).
+#define GHR_HD __host__ __device__ __forceinline__
+
+namespace ghr {
+
+typedef float f4 __attribute__((ext_vector_type(4)));  // native 16-B vector: b128 loads/stores, SSA-friendly
+
+// ---- reference helpers, R:cuda_rasterizer/auxiliary.h ------------------------------------------------------------
+
+// auxiliary.h:41-44 (double literals => evaluated in double, narrowed once)
+GHR_HD float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+// auxiliary.h:58-66
+GHR_HD void xform4x3(const float* m, float px, float py, float pz, float& ox,
+                                         float& oy, float& oz)
+{
+    ox = m[0] * px + m[4] * py + m[8] * pz + m[12];
+    oy = m[1] * px + m[5] * py + m[9] * pz + m[13];
+    oz = m[2] * px + m[6] * py + m[10] * pz + m[14];
+}
+
+GHR_HD int imin(int a, int b) { return a < b ? a : b; }
+GHR_HD int imax(int a, int b) { return a > b ? a : b; }
+
+// auxiliary.h:46-56 -- radius as int, float divide truncated toward zero, clamped to the grid.
+GHR_HD void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1)
+{
+    x0 = imin(gx, imax(0, (int)((px - radius) / GHR_TILE_X)));
+    y0 = imin(gy, imax(0, (int)((py - radius) / GHR_TILE_Y)));
+    x1 = imin(gx, imax(0, (int)((px + radius + GHR_TILE_X - 1) / GHR_TILE_X)));
+    y1 = imin(gy, imax(0, (int)((py + radius + GHR_TILE_Y - 1) / GHR_TILE_Y)));
+}
+
+// 3x3 in glm's column-major storage m[c][r]; product term order of glm's operator* (k = 0,1,2).
+struct m3 { float m[3][3]; };
+GHR_HD m3 mul(const m3& a, const m3& b)
+{
+    m3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) o.m[c][r] = a.m[0][r] * b.m[c][0] + a.m[1][r] * b.m[c][1] + a.m[2][r] * b.m[c][2];
+    return o;
+}
+GHR_HD m3 transpose(const m3& a)
+{
+    m3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) o.m[c][r] = a.m[r][c];
+    return o;
+}
+
+// ---- chip mapping ----------------------------------------------------------------------------------------------------
+
+// Workgroup b is dispatched to XCD b % 8 (observed, speed only).  Give every XCD one contiguous run of
+// row-major tiles so neighbouring tiles (which share Gaussians) hit the same private L2.  Bijective for any n.
+GHR_HD uint32_t xcd_tile(uint32_t b, uint32_t n)
+{
+    const uint32_t xcd = b & 7u, k = b >> 3, q = n >> 3, r = n & 7u;
+    const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + k;
+}
+
+// v_exp_f32 / v_rcp_f32 (1 ulp each); exp(x) = 2^(x*log2 e) carries a few ulp more from the rounded product.
+GHR_HD float fast_exp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+#else
+    return exp2f(x * 1.4426950408889634f);
+#endif
+}
+GHR_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+GHR_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+}  // namespace ghr

@@ -1,0 +1,185 @@
+// ghr_preprocess.h -- K1 (per-Gaussian preprocess) fused with the per-tile instance count; markVisible.
+// Follows R:cuda_rasterizer/forward.cu:155-282 (preprocessCUDA), :74-152 (computeCov2D / computeCov3D) and
+// R:cuda_rasterizer/auxiliary.h:139-164 (in_frustum).  One thread per Gaussian, HBM-bound:
+//   reads  xyz 12 + conic 12 (or scales/rot/cov3D) + opacity 4 + colors 40 B
+//   writes one 64-B packed record {x, y, a, b | c, opacity, f0, f1 | f2..f5 | f6..f9}, depth 4, rect 8, radii 4 B.
+#pragma once
+#include "ghr_device.h"
+
+namespace ghr {
+
+struct PreArgs {
+    int P, W, H, gx, gy;
+    const float* means3D;
+    const float* colors;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* conic_precomp;
+    const float* view;
+    const float* proj;
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
+    // outputs
+    f4* rec;
+    float* depths;
+    uint2* rects;
+    float* cov3D;  // mode B only
+    int* radii;
+    uint32_t* tile_count;
+};
+
+// forward.cu:118-152.  The quaternion is used as given (normalisation is commented out at :127).
+GHR_HD void cov3d_from_scale_rot(const float* s3, float mod, const float* q4, float* cov3D)
+{
+    m3 S = {};
+    S.m[0][0] = mod * s3[0];
+    S.m[1][1] = mod * s3[1];
+    S.m[2][2] = mod * s3[2];
+    const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+    m3 R;
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z); R.m[0][2] = 2.f * (x * z + r * y);
+    R.m[1][0] = 2.f * (x * y + r * z); R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+    R.m[2][0] = 2.f * (x * z - r * y); R.m[2][1] = 2.f * (y * z + r * x); R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+    const m3 M = mul(S, R);
+    const m3 Sigma = mul(transpose(M), M);
+    cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+// Shared by forward.cu:74-113 and backward.cu:166-194: clamped view-space mean, J, W, T = W*J, Vrk.
+struct Cov2DCtx {
+    float tx, ty, tz, txtz, tytz, limx, limy;
+    m3 J, Wm, T, Vrk;
+};
+GHR_HD void cov2d_setup(Cov2DCtx& c, float mx, float my, float mz, float fx, float fy,
+                                            float tan_fovx, float tan_fovy, const float* cov3D,
+                                            const float* view)
+{
+    xform4x3(view, mx, my, mz, c.tx, c.ty, c.tz);
+    c.limx = 1.3f * tan_fovx;
+    c.limy = 1.3f * tan_fovy;
+    c.txtz = c.tx / c.tz;
+    c.tytz = c.ty / c.tz;
+    c.tx = fminf(c.limx, fmaxf(-c.limx, c.txtz)) * c.tz;
+    c.ty = fminf(c.limy, fmaxf(-c.limy, c.tytz)) * c.tz;
+    c.J = {};
+    c.J.m[0][0] = fx / c.tz; c.J.m[0][2] = -(fx * c.tx) / (c.tz * c.tz);
+    c.J.m[1][1] = fy / c.tz; c.J.m[1][2] = -(fy * c.ty) / (c.tz * c.tz);
+    c.Wm.m[0][0] = view[0]; c.Wm.m[0][1] = view[4]; c.Wm.m[0][2] = view[8];
+    c.Wm.m[1][0] = view[1]; c.Wm.m[1][1] = view[5]; c.Wm.m[1][2] = view[9];
+    c.Wm.m[2][0] = view[2]; c.Wm.m[2][1] = view[6]; c.Wm.m[2][2] = view[10];
+    c.T = mul(c.Wm, c.J);
+    c.Vrk.m[0][0] = cov3D[0]; c.Vrk.m[0][1] = cov3D[1]; c.Vrk.m[0][2] = cov3D[2];
+    c.Vrk.m[1][0] = cov3D[1]; c.Vrk.m[1][1] = cov3D[3]; c.Vrk.m[1][2] = cov3D[4];
+    c.Vrk.m[2][0] = cov3D[2]; c.Vrk.m[2][1] = cov3D[4]; c.Vrk.m[2][2] = cov3D[5];
+}
+// cov = T^t * Vrk^t * T, +0.3 on the diagonal (forward.cu:106-112); returns (xx, xy, yy).
+GHR_HD void cov2d_eval(const Cov2DCtx& c, float& a, float& b, float& d)
+{
+    const m3 A = mul(transpose(c.T), transpose(c.Vrk));
+    const m3 Cm = mul(A, c.T);
+    a = Cm.m[0][0] + 0.3f;
+    b = Cm.m[0][1];
+    d = Cm.m[1][1] + 0.3f;
+}
+
+// Per-Gaussian body of K1.  Returns false when the Gaussian is culled (radii/rect already zeroed).
+GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1, int& y1)
+{
+    a.radii[idx] = 0;  // forward.cu:190-191
+    a.rects[idx] = uint2{0u, 0u};
+
+    const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
+    float vx, vy, vz;
+    xform4x3(a.view, mx, my, mz, vx, vy, vz);
+    if (vz <= 0.2f) return false;  // auxiliary.h:154 -- silent cull, never trap
+
+    // forward.cu:203-205
+    const float* pm = a.proj;
+    const float hx = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+    const float hy = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+    const float hw = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float projx = hx * p_w, projy = hy * p_w;
+
+    float cva, cvb, cvc, cx, cy, cz, det;
+    if (a.conic_precomp == nullptr) {  // mode B, forward.cu:214-239
+        float c3[6];
+        if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = a.cov3D_precomp[6 * idx + i];
+        } else {
+            const float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            const float q4[4] = {a.rotations[4 * idx], a.rotations[4 * idx + 1], a.rotations[4 * idx + 2],
+                                 a.rotations[4 * idx + 3]};
+            cov3d_from_scale_rot(s3, a.scale_modifier, q4, c3);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.cov3D[6 * idx + i] = c3[i];
+        Cov2DCtx c;
+        cov2d_setup(c, mx, my, mz, a.focal_x, a.focal_y, a.tan_fovx, a.tan_fovy, c3, a.view);
+        cov2d_eval(c, cva, cvb, cvc);
+        det = (cva * cvc - cvb * cvb);
+        if (det == 0.0f) return false;
+        const float det_inv = 1.f / det;
+        cx = cvc * det_inv;
+        cy = -cvb * det_inv;
+        cz = cva * det_inv;
+    } else {  // mode A, forward.cu:240-248
+        cx = a.conic_precomp[3 * idx];
+        cy = a.conic_precomp[3 * idx + 1];
+        cz = a.conic_precomp[3 * idx + 2];
+        const float det_inv = (cx * cz - cy * cy);
+        if (det_inv == 0.0f) return false;
+        det = 1.f / det_inv;
+        cva = cz * det;
+        cvb = -cy * det;
+        cvc = cx * det;
+    }
+    // forward.cu:254-262
+    const float mid = 0.5f * (cva + cvc);
+    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda1 = mid + sq, lambda2 = mid - sq;
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float pixx = ndc2pix(projx, a.W), pixy = ndc2pix(projy, a.H);
+    tile_rect(pixx, pixy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return false;
+
+    // forward.cu:275-281, packed: one 64-B line per Gaussian, read back as 4 x b128 by the render kernels.
+    const float* col = a.colors + (size_t)GHR_C * idx;
+    f4* r = a.rec + 4 * (size_t)idx;
+    r[0] = f4{pixx, pixy, cx, cy};
+    r[1] = f4{cz, a.opacities[idx], col[0], col[1]};
+    r[2] = f4{col[2], col[3], col[4], col[5]};
+    r[3] = f4{col[6], col[7], col[8], col[9]};
+    a.depths[idx] = vz;
+    a.radii[idx] = (int)my_radius;
+    a.rects[idx] = uint2{(uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16)};
+    return true;
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
+{
+    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    int x0, y0, x1, y1;
+    if (!preprocess_one(a, idx, x0, y0, x1, y1)) return;
+    // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
+    // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+}
+
+// rasterizer_impl.cu:54-66 (checkFrustum): only the near test is live (auxiliary.h:154).
+__global__ void __launch_bounds__(GHR_BLOCK) k_mark_visible(int P, const float* __restrict__ means3D,
+                                                            const float* __restrict__ view, uint8_t* present)
+{
+    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    float vx, vy, vz;
+    xform4x3(view, means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2], vx, vy, vz);
+    present[idx] = !(vz <= 0.2f);
+}
+
+}  // namespace ghr

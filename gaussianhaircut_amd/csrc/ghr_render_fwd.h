@@ -1,0 +1,119 @@
+// ghr_render_fwd.h -- K7: front-to-back alpha compositing of the 10 feature channels, one 16x16 tile per workgroup.
+// Follows R:cuda_rasterizer/forward.cu:287-400 (renderCUDA).
+//
+// CDNA4 mapping: 256 threads = 4 wavefronts; wave w owns pixel rows 4w..4w+3 of the tile (lane = 16*row + col), so
+// every lane of a wave reads the SAME staged record (LDS broadcast, conflict-free) and whole waves skip a splat that
+// misses their 4 rows.  A batch of 256 list entries is staged as packed 64-B records (position, conic, opacity AND
+// the 10 features -- the reference re-gathers features from global memory per contributing pixel, forward.cu:381)
+// into four SoA float4 planes (conflict-free ds_write_b128 / broadcast ds_read_b128).  The gather for batch b+1 is
+// issued into registers before batch b is composited, so HBM/L2 latency overlaps the VALU loop.
+#pragma once
+#include "ghr_device.h"
+
+namespace ghr {
+
+struct PixFwd {
+    float T;
+    float C[GHR_C];
+    uint32_t last;  // last_contributor
+};
+
+// One list entry applied to one pixel (forward.cu:351-388).  `pos1` is the 1-based position of the entry in the
+// tile's list (the reference's `contributor`).  Returns true when the pixel is finished (T would drop below 1e-4).
+GHR_HD bool fwd_step(PixFwd& s, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2, const f4& r3,
+                     uint32_t pos1)
+{
+    const float dx = r0.x - pxf, dy = r0.y - pyf;
+    // forward.cu:361, source order, unfused (decision input)
+    const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
+    if (power > 0.0f) return false;
+    const float alpha = fminf(0.99f, r1.y * fast_exp(power));
+    if (alpha < 1.0f / 255.0f) return false;
+    const float test_T = s.T * (1 - alpha);
+    if (test_T < 0.0001f) return true;
+    const float w = alpha * s.T;
+    s.C[0] = fma_(r1.z, w, s.C[0]);
+    s.C[1] = fma_(r1.w, w, s.C[1]);
+    s.C[2] = fma_(r2.x, w, s.C[2]);
+    s.C[3] = fma_(r2.y, w, s.C[3]);
+    s.C[4] = fma_(r2.z, w, s.C[4]);
+    s.C[5] = fma_(r2.w, w, s.C[5]);
+    s.C[6] = fma_(r3.x, w, s.C[6]);
+    s.C[7] = fma_(r3.y, w, s.C[7]);
+    s.C[8] = fma_(r3.z, w, s.C[8]);
+    s.C[9] = fma_(r3.w, w, s.C[9]);
+    s.T = test_T;
+    s.last = pos1;
+    return false;
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, uint32_t T_tiles,
+                                                          const uint32_t* __restrict__ tile_start,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const f4* __restrict__ rec, const float* __restrict__ bg,
+                                                          float* __restrict__ out_color, float* __restrict__ final_T,
+                                                          uint32_t* __restrict__ n_contrib)
+{
+    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK];
+
+    const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x;
+    const int px = tx * GHR_TILE_X + (tid & 15), py = ty * GHR_TILE_Y + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+
+    const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t n = end - beg;
+
+    PixFwd st;
+    st.T = 1.0f;
+    st.last = 0;
+#pragma unroll
+    for (int c = 0; c < GHR_C; c++) st.C[c] = 0.f;
+    bool done = !inside;
+
+    // software-pipelined gather: registers hold the next batch while the current one is composited
+    const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f4 g0 = zero4, g1 = zero4, g2 = zero4, g3 = zero4;
+#define GHR_GATHER(base_)                                     \
+    do {                                                      \
+        const uint32_t i_ = (base_) + tid;                    \
+        if (i_ < n) {                                         \
+            const uint32_t id_ = point_list[beg + i_];        \
+            const f4* r_ = rec + 4 * (size_t)id_;             \
+            g0 = r_[0]; g1 = r_[1]; g2 = r_[2]; g3 = r_[3];   \
+        }                                                     \
+    } while (0)
+    if (n > 0) GHR_GATHER(0u);
+
+    for (uint32_t base = 0; base < n; base += GHR_BLOCK) {
+        // forward.cu:335-337: stop when the whole tile is done.  The barrier also protects the LDS planes.
+        if (__syncthreads_count(done) == GHR_BLOCK) break;
+        s_r0[tid] = g0; s_r1[tid] = g1; s_r2[tid] = g2; s_r3[tid] = g3;
+        __syncthreads();
+        if (base + GHR_BLOCK < n) GHR_GATHER(base + GHR_BLOCK);
+
+        const uint32_t cnt = min((uint32_t)GHR_BLOCK, n - base);
+        if (__builtin_amdgcn_ballot_w64(!done) != 0) {  // wave-uniform: skip the batch once all 64 pixels are done
+            for (uint32_t j = 0; j < cnt; j++) {
+                if (!done) done = fwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
+                // once every lane of the wave is done nothing below can change
+                if ((j & 15u) == 15u && __builtin_amdgcn_ballot_w64(!done) == 0) break;
+            }
+        }
+    }
+
+#undef GHR_GATHER
+
+    if (inside) {  // forward.cu:393-399
+        const size_t pix = (size_t)W * py + px;
+        const size_t plane = (size_t)W * H;
+        final_T[pix] = st.T;
+        n_contrib[pix] = st.last;
+#pragma unroll
+        for (int c = 0; c < GHR_C; c++) out_color[c * plane + pix] = st.C[c] + st.T * bg[c];
+    }
+}
+
+}  // namespace ghr

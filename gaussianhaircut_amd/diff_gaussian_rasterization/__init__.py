@@ -1,0 +1,299 @@
+"""Drop-in for the reference's ``diff_gaussian_rasterization`` package, backed by ``libghr_hip.so`` (MI355X / gfx950).
+
+API surface kept verbatim (reference ``ext/diff_gaussian_rasterization_hair/diff_gaussian_rasterization/__init__.py``):
+
+* ``GaussianRasterizationSettings`` -- the 12-field NamedTuple (:170-182)
+* ``GaussianRasterizer(raster_settings)`` with ``forward(means3D, means2D, opacities, shs, colors_precomp, scales,
+  rotations, cov3D_precomp, conic_precomp) -> (color[C,H,W], radii[P] int32)`` and ``markVisible`` (:184-236)
+* ``rasterize_gaussians`` / ``_RasterizeGaussians`` with the same argument order, saved-tensor tuple and gradient
+  tuple (:21-168), including the ``[xx, 2*xy, yy]`` restack of the conic gradient (:149-153).
+
+Differences, all deliberate: ``means2D`` is only a gradient sink (the reference's null-check
+on it is inverted and its values are never read, forward.cu:199-210); kernels run on torch's *current* stream;
+a Gaussian failing the near test is culled silently instead of ``__trap()``-ing.  There is no CPU path: tensors
+must live on a ROCm device and the HIP library must be present.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+try:  # imported as gaussianhaircut_amd.diff_gaussian_rasterization
+    from .. import _lib
+except ImportError:  # imported as top-level `diff_gaussian_rasterization` (reference-style sys.path layout)
+    from gaussianhaircut_amd import _lib
+
+NUM_CHANNELS = _lib.NUM_CHANNELS
+
+# pinned host word per device that receives num_rendered from stage 1
+_pinned_R = {}
+
+
+def _pinned(device: torch.device) -> torch.Tensor:
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    t = _pinned_R.get(key)
+    if t is None:
+        t = torch.zeros(4, dtype=torch.int32).pin_memory()
+        _pinned_R[key] = t
+    return t
+
+
+def _ptr(t):
+    """Device pointer, or NULL for the reference's 'absent optional' empty tensor (__init__.py:210-222)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_f32(t, name):
+    if t is None or t.numel() == 0:
+        return t
+    if not t.is_cuda:
+        raise RuntimeError("gaussianhaircut_amd: tensor '%s' is on %s; the HIP rasterizer has no CPU path "
+                           "(tensors must be on a ROCm device)" % (name, t.device))
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+def _view_args(rs, P, means3D, colors, opacities, scales, rotations, cov3D, conic, bg, view, proj):
+    a = _lib.ViewArgs()
+    a.P, a.W, a.H, a.C = int(P), int(rs.image_width), int(rs.image_height), NUM_CHANNELS
+    a.background = _ptr(bg)
+    a.means3D = _ptr(means3D)
+    a.colors = _ptr(colors)
+    a.opacities = _ptr(opacities)
+    a.scales = _ptr(scales)
+    a.rotations = _ptr(rotations)
+    a.cov3D_precomp = _ptr(cov3D)
+    a.conic_precomp = _ptr(conic)
+    a.viewmatrix = _ptr(view)
+    a.projmatrix = _ptr(proj)
+    a.scale_modifier = float(rs.scale_modifier)
+    a.tan_fovx = float(rs.tanfovx)
+    a.tan_fovy = float(rs.tanfovy)
+    a.prefiltered = int(bool(rs.prefiltered))
+    a.debug = int(bool(rs.debug))
+    return a
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rasterize_gaussians(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        conics_precomp, raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, conics_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                conics_precomp, raster_settings):
+        rs = raster_settings
+        L = _lib.lib()
+        if means3D.dim() != 2 or means3D.size(1) != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
+        if not means3D.is_cuda:
+            raise RuntimeError("gaussianhaircut_amd: means3D is on %s; the HIP rasterizer has no CPU path" %
+                               means3D.device)
+        P = means3D.size(0)
+        H, W = int(rs.image_height), int(rs.image_width)
+        dev = means3D.device
+
+        means3D_c = _dev_f32(means3D, "means3D")
+        colors_c = _dev_f32(colors_precomp, "colors_precomp")
+        opac_c = _dev_f32(opacities, "opacities")
+        scales_c = _dev_f32(scales, "scales")
+        rot_c = _dev_f32(rotations, "rotations")
+        cov3D_c = _dev_f32(cov3Ds_precomp, "cov3D_precomp")
+        conic_c = _dev_f32(conics_precomp, "conic_precomp")
+        bg_c = _dev_f32(rs.bg, "bg")
+        view_c = _dev_f32(rs.viewmatrix, "viewmatrix")
+        proj_c = _dev_f32(rs.projmatrix, "projmatrix")
+        if colors_c is None or colors_c.numel() == 0:
+            # rasterizer_impl.cu:244-247 (NUM_CHANNELS != 3 forces precomputed colours; the in-kernel SH path is dead)
+            if P != 0:
+                raise RuntimeError("For non-RGB, provide precomputed Gaussian colors!")
+        elif colors_c.dim() != 2 or colors_c.size(0) != P or colors_c.size(1) != NUM_CHANNELS:
+            raise RuntimeError("colors_precomp must have dimensions (num_points, %d)" % NUM_CHANNELS)
+
+        mode_b = conic_c is None or conic_c.numel() == 0
+        with torch.cuda.device(dev):
+            color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            gbytes, ibytes = _lib.forward_sizes(P, W, H, mode_b)
+            geomBuffer = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
+            imgBuffer = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
+            args = _view_args(rs, P, means3D_c, colors_c, opac_c, scales_c, rot_c, cov3D_c, conic_c, bg_c, view_c,
+                              proj_c)
+            cpu_args = None
+            if rs.debug:  # __init__.py:88-95: snapshot the inputs before they can be corrupted
+                cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, means2D_precomp, colors_precomp, opacities, scales,
+                                                rotations, rs.scale_modifier, cov3Ds_precomp, conics_precomp,
+                                                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy,
+                                                rs.image_height, rs.image_width, sh, rs.sh_degree, rs.campos,
+                                                rs.prefiltered, rs.debug))
+            try:
+                pinned = _pinned(dev)
+                stream = torch.cuda.current_stream()
+                _lib.check(L.ghr_forward_stage1(_stream(), ctypes.byref(args), _ptr(geomBuffer), _ptr(imgBuffer),
+                                                _ptr(radii), ctypes.c_void_p(pinned.data_ptr())))
+                stream.synchronize()  # the reference blocks on the same 4 bytes (rasterizer_impl.cu:284-285)
+                num_rendered = int(pinned[0].item()) if P > 0 else 0
+                bbytes = _lib.binning_size(num_rendered)
+                binningBuffer = torch.empty((bbytes,), dtype=torch.uint8, device=dev)
+                _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), num_rendered, _ptr(geomBuffer),
+                                                _ptr(imgBuffer), _ptr(binningBuffer), _ptr(color)))
+            except Exception as ex:
+                if cpu_args is not None:
+                    torch.save(cpu_args, "snapshot_fw.dump")
+                    print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.mark_non_differentiable(radii)
+        # same tuple as the reference (__init__.py:102); tensors are the contiguous fp32 versions the kernels read
+        ctx.save_for_backward(colors_c if colors_c is not None else torch.empty(0), means3D_c,
+                              scales_c if scales_c is not None else torch.empty(0),
+                              rot_c if rot_c is not None else torch.empty(0),
+                              cov3D_c if cov3D_c is not None else torch.empty(0),
+                              conic_c if conic_c is not None else torch.empty(0), radii,
+                              sh if sh is not None else torch.empty(0), geomBuffer, binningBuffer, imgBuffer,
+                              opac_c, bg_c, view_c, proj_c)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        num_rendered = ctx.num_rendered
+        (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, conics_precomp, radii, sh, geomBuffer,
+         binningBuffer, imgBuffer, opacities, bg, view, proj) = ctx.saved_tensors
+        L = _lib.lib()
+        P = means3D.size(0)
+        dev = means3D.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            grad_means2D = torch.empty((P, 3), **f32)
+            grad_colors_precomp = torch.empty((P, NUM_CHANNELS), **f32)
+            grad_opacities = torch.empty((P, 1), **f32)
+            grad_means3D = torch.empty((P, 3), **f32)
+            grad_cov3Ds_precomp = torch.empty((P, 6), **f32)
+            grad_conic = torch.empty((P, 2, 2), **f32)
+            grad_scales = torch.empty((P, 3), **f32)
+            grad_rotations = torch.empty((P, 4), **f32)
+            scratch = torch.empty((P, _lib.GRAD_STRIDE), **f32)
+            dL = grad_out_color
+            if dL.dtype != torch.float32:
+                dL = dL.float()
+            dL = dL.contiguous()
+            args = _view_args(rs, P, means3D, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                              conics_precomp, bg, view, proj)
+            cpu_args = None
+            if rs.debug:
+                cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, radii, colors_precomp, scales, rotations,
+                                                rs.scale_modifier, cov3Ds_precomp, conics_precomp, rs.viewmatrix,
+                                                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, sh,
+                                                rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer,
+                                                imgBuffer, rs.debug))
+            try:
+                if P > 0:
+                    _lib.check(L.ghr_backward(_stream(), ctypes.byref(args), num_rendered, _ptr(radii),
+                                              _ptr(geomBuffer), _ptr(imgBuffer), _ptr(binningBuffer), _ptr(dL),
+                                              _ptr(scratch), _ptr(grad_means2D), _ptr(grad_conic),
+                                              _ptr(grad_opacities), _ptr(grad_colors_precomp), _ptr(grad_means3D),
+                                              _ptr(grad_cov3Ds_precomp), _ptr(grad_scales), _ptr(grad_rotations)))
+            except Exception as ex:
+                if cpu_args is not None:
+                    torch.save(cpu_args, "snapshot_bw.dump")
+                    print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+
+        # __init__.py:149-153: the kernel stores half of d/d(conic.y) (backward.cu:554); the wrapper doubles it
+        grad_conics_precomp = torch.stack([grad_conic[:, 0, 0], 2 * grad_conic[:, 0, 1], grad_conic[:, 1, 1]], dim=-1)
+
+        def opt(g, ref):
+            return g if ref.numel() != 0 else None
+
+        grads = (
+            grad_means3D,
+            grad_means2D,
+            None,  # sh: the SH path is dead in this fork (dL_dsh has M = 0 columns in the reference)
+            grad_colors_precomp,
+            grad_opacities,
+            opt(grad_scales, scales),
+            opt(grad_rotations, rotations),
+            opt(grad_cov3Ds_precomp, cov3Ds_precomp),
+            opt(grad_conics_precomp, conics_precomp),
+            None,
+        )
+        return grads
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of points passing the near-plane test (rasterizer_impl.cu:54-66)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            if not positions.is_cuda:
+                raise RuntimeError("gaussianhaircut_amd: markVisible needs a tensor on a ROCm device")
+            pos = _dev_f32(positions, "positions")
+            P = pos.size(0)
+            with torch.cuda.device(pos.device):
+                present = torch.zeros((P,), dtype=torch.bool, device=pos.device)
+                if P:
+                    _lib.check(_lib.lib().ghr_mark_visible(_stream(), P, _ptr(pos),
+                                                           _ptr(_dev_f32(rs.viewmatrix, "viewmatrix")),
+                                                           _ptr(_dev_f32(rs.projmatrix, "projmatrix")), _ptr(present)))
+        return present
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, conic_precomp=None):
+        raster_settings = self.raster_settings
+
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        empty = torch.Tensor([])
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        conic_precomp = empty if conic_precomp is None else conic_precomp
+
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, conic_precomp, raster_settings)

@@ -1,0 +1,113 @@
+"""``render()`` / ``render_hair()`` -- same signatures and return dict as the reference's
+``src/gaussian_renderer/__init__.py:23-113,116-214``; the rasterizer behind them is the gfx950 HIP library.
+
+Channel layout of the 10-feature splat (``:64-74``): ``[rgb(3) | hair label(1) | foreground(1) | dir2D(3) |
+orientation confidence(1) | view depth(1)]``; outputs are split ``[3, 2, 3, 1, 1]`` (``:100``) and the 2D strand
+direction is turned into an orientation angle in [0,1) (``:102-105``).
+
+``pc`` / ``pc_hair`` only need the reference's model interface (get_conic, get_mean_2d, get_direction_2d,
+get_depths, filter_points, get_xyz, get_opacity, get_features, get_label, get_orient_conf, cov, ...), so the
+reference's own model classes work here too.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+from ..diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from ..utils.sh_utils import eval_sh
+
+
+def _tan_half(fov) -> float:
+    return math.tan(float(fov) * 0.5)
+
+
+def _raster_settings(cam, bg_color, scaling_modifier, sh_degree, debug):
+    return GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy), bg=bg_color, scale_modifier=scaling_modifier,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=sh_degree,
+        campos=cam.camera_center, prefiltered=True, debug=debug)
+
+
+def _sh_to_rgb(deg, shs_view, xyz, campos):
+    d = xyz - campos[None, :]
+    d = d / d.norm(dim=1, keepdim=True)
+    return torch.clamp_min(eval_sh(deg, shs_view, d) + 0.5, 0.0)
+
+
+def _package(renders, screenspace_points, radii):
+    image, mask, cov2d, orient_conf, _ = renders.split([3, 2, 3, 1, 1], dim=0)
+    dir2d = F.normalize(cov2d[:2], dim=0)
+    mirror = torch.where(dir2d[[0]] < 0, -torch.ones_like(dir2d[[0]]), torch.ones_like(dir2d[[0]]))
+    orient_angle = torch.acos(dir2d[[1]].clamp(-1 + 1e-3, 1 - 1e-3) * mirror) / math.pi
+    return {"render": image, "mask": mask, "orient_angle": orient_angle, "orient_conf": orient_conf,
+            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+
+
+def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
+    """Render the scene (reference :23-113).  ``bg_color`` (10 floats) must be on the GPU."""
+    conic = pc.get_conic(viewpoint_camera, scaling_modifier)  # must precede direction / filter (cached state)
+    screenspace_points = pc.get_mean_2d(viewpoint_camera)
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, bg_color, scaling_modifier,
+                                                     pc.active_sh_degree, getattr(pipe, "debug", False)))
+    xyz = pc.get_xyz
+    n_coef = (pc.max_sh_degree + 1) ** 2
+    shs_view = pc.get_features.transpose(1, 2).reshape(-1, 3, n_coef)
+    rgb = _sh_to_rgb(pc.active_sh_degree, shs_view, xyz, viewpoint_camera.camera_center)
+    cov3D = pc.cov
+    dir2d = pc.get_direction_2d(viewpoint_camera)
+    label = pc.get_label
+    colors = torch.cat([rgb, label, torch.ones_like(label), dir2d, pc.get_orient_conf,
+                        pc.get_depths(viewpoint_camera)], dim=-1)
+
+    keep = pc.filter_points(viewpoint_camera)
+    radii = torch.zeros_like(xyz[:, 0]).int()
+    renders, _radii = rasterizer(means3D=xyz[keep], means2D=screenspace_points[keep], shs=None,
+                                 colors_precomp=colors[keep], opacities=pc.get_opacity[keep], scales=None,
+                                 rotations=None, cov3D_precomp=cov3D[keep], conic_precomp=conic[keep])
+    radii[keep] = _radii
+    return _package(renders, screenspace_points, radii)
+
+
+def render_hair(viewpoint_camera, pc, pc_hair, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
+    """Frozen head Gaussians (``*_precomp`` attributes of ``pc``) + trainable hair strands (reference :116-214)."""
+    head = pc.mask_precomp
+    conic = torch.cat([pc.get_conic(viewpoint_camera, scaling_modifier)[head],
+                       pc_hair.get_conic(viewpoint_camera, scaling_modifier)])
+    screenspace_points = torch.cat([pc.get_mean_2d(viewpoint_camera)[head].detach(),
+                                    pc_hair.get_mean_2d(viewpoint_camera)], dim=0)
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rasterizer = GaussianRasterizer(_raster_settings(viewpoint_camera, bg_color, scaling_modifier,
+                                                     pc_hair.active_sh_degree, getattr(pipe, "debug", False)))
+    xyz = torch.cat([pc.xyz_precomp, pc_hair.get_xyz])
+    opacity = torch.cat([pc.opacity_precomp, pc_hair.get_opacity])
+    keep = torch.cat([pc.filter_points(viewpoint_camera)[head], pc_hair.filter_points(viewpoint_camera)])
+    scales = torch.cat([pc.scaling_precomp, pc_hair.get_scaling])
+    rotations = torch.cat([pc.rotation_precomp, pc_hair.get_rotation])
+
+    n_coef = (pc.max_sh_degree + 1) ** 2
+    shs_view = torch.cat([pc.shs_view, pc_hair.get_features.transpose(1, 2).reshape(-1, 3, n_coef)])
+    rgb = _sh_to_rgb(pc_hair.active_sh_degree, shs_view, xyz, viewpoint_camera.camera_center)
+    zeros1 = torch.zeros_like(pc.xyz_precomp[:, :1])
+    label = torch.cat([zeros1, pc_hair.get_label])
+    dir2d = torch.cat([torch.zeros_like(pc.xyz_precomp), pc_hair.get_direction_2d(viewpoint_camera)])
+    orient_conf = torch.cat([zeros1, pc_hair.get_orient_conf])
+    depth = torch.cat([pc.get_depths(viewpoint_camera)[head], pc_hair.get_depths(viewpoint_camera)])
+    colors = torch.cat([rgb, label, torch.ones_like(label), dir2d, orient_conf, depth], dim=-1)
+
+    radii = torch.zeros_like(xyz[:, 0]).int()
+    renders, _radii = rasterizer(means3D=xyz[keep], means2D=screenspace_points[keep], shs=None,
+                                 colors_precomp=colors[keep], opacities=opacity[keep], scales=scales[keep],
+                                 rotations=rotations[keep], cov3D_precomp=None, conic_precomp=conic[keep])
+    radii[keep] = _radii
+    return _package(renders, screenspace_points, radii)

@@ -1,0 +1,86 @@
+"""Strand-parametrised hair Gaussians: host-side mirror of the projection helpers of the reference's
+``src/scene/gaussian_model_strands.py`` (:230-452).  Each strand is a polyline of ``n_seg`` direction vectors; every
+segment becomes one Gaussian (mid-point, longest axis = half the segment length along the segment, parallel-transport
+quaternion; ``initialize_gaussians_hair`` :435-452).  The learned strand *generators* of the reference depend on the
+un-vendored NeuralHaircut checkpoints and are out of scope; strands here are explicit tensors.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils.general_utils import build_scaling_rotation, parallel_transport
+from .gaussian_model import GaussianModel
+
+
+class GaussianModelStrands(GaussianModel):
+    conic_eps = 1e-7  # gaussian_model_strands.py:355
+
+    def __init__(self, sh_degree: int, scale: float = 1e-3):
+        super().__init__(sh_degree)
+        self.scale = scale
+
+    def create_from_strands(self, origins, dirs, features, orient_conf_log=None):
+        """origins: (S,1,3) roots, dirs: (S,n_seg,3) segment vectors, features: (S*n_seg, K, 3)."""
+        self.pts_origins = origins.detach().clone().float()
+        self._dirs = nn.Parameter(dirs.detach().clone().float().requires_grad_(True))
+        P = dirs.shape[0] * dirs.shape[1]
+        dev = dirs.device
+        self._features_dc = nn.Parameter(features[:, :1, :].detach().clone().float().contiguous().requires_grad_(True))
+        self._features_rest = nn.Parameter(features[:, 1:, :].detach().clone().float().contiguous().requires_grad_(True))
+        self._orient_conf = nn.Parameter((orient_conf_log if orient_conf_log is not None
+                                          else torch.zeros(P, 1, device=dev)).float().requires_grad_(True))
+        self.initialize_gaussians_hair()
+        return self
+
+    def initialize_gaussians_hair(self):
+        """gaussian_model_strands.py:435-452."""
+        pts = self.pts_origins + torch.cat([torch.zeros_like(self.pts_origins), torch.cumsum(self._dirs, dim=1)], dim=1)
+        self._pts = pts
+        self._dir = self._dirs.reshape(-1, 3)
+        self._xyz = ((pts[:, 1:] + pts[:, :-1]) * 0.5).reshape(-1, 3)
+        x_axis = torch.zeros_like(self._xyz)
+        x_axis[:, 0] = 1.0
+        self._rotation = parallel_transport(x_axis, self._dir).reshape(-1, 4)
+        scaling = torch.ones_like(self._xyz) * self.scale
+        self._scaling = torch.cat([self._dir.norm(dim=-1, keepdim=True) * 0.5, scaling[:, 1:]], dim=-1)
+
+    # activations differ from the free-Gaussian model: scaling / rotation are already in linear space
+    @property
+    def get_scaling(self):
+        return self._scaling
+
+    @property
+    def get_rotation(self):
+        return self.rotation_activation(self._rotation)
+
+    @property
+    def get_opacity(self):  # gaussian_model_strands.py:131-136: strands are opaque hair
+        return torch.ones_like(self.get_xyz[:, :1])
+
+    @property
+    def get_label(self):
+        return torch.ones_like(self.get_xyz[:, :1])
+
+    def get_covariance(self, scaling_modifier=1, return_full_covariance=False):
+        from ..utils.general_utils import strip_symmetric
+        self.scaling = self.get_scaling
+        M = build_scaling_rotation(self.scaling * scaling_modifier, self._rotation)
+        self.cov_full = M.transpose(1, 2) @ M
+        self.cov = strip_symmetric(self.cov_full)
+        return self.cov_full if return_full_covariance else self.cov
+
+    def get_direction_2d(self, viewpoint_camera):
+        """normalize(dir) @ T (gaussian_model_strands.py:396-433)."""
+        T = self._projection_jacobian(viewpoint_camera)
+        return (F.normalize(self._dir, dim=-1)[:, None, :] @ T)[:, 0]
+
+    def param_groups(self, training_args):
+        """gaussian_model_strands.py:578-589 (directions, SH, orientation confidence)."""
+        return [
+            {'params': [self._dirs], 'lr': training_args.position_lr_init * max(self.spatial_lr_scale, 1.0), "name": "dirs"},
+            {'params': [self._features_dc], 'lr': training_args.feature_lr, "name": "f_dc"},
+            {'params': [self._features_rest], 'lr': training_args.feature_lr / 20.0, "name": "f_rest"},
+            {'params': [self._orient_conf], 'lr': training_args.orient_conf_lr, "name": "orient_conf"},
+        ]

@@ -1,0 +1,124 @@
+/*
+ * ghr.h -- C ABI of libghr_hip.so, the MI355X (gfx950) strand-aligned Gaussian tile rasterizer.
+ *
+ * Drop-in boundary for the reference's native module `diff_gaussian_rasterization._C`
+ * (ext/diff_gaussian_rasterization_hair/ext.cpp:15-19; signatures rasterize_points.h:18-69):
+ *
+ *   _C.rasterize_gaussians           (rasterize_points.cu:35-123)   -> ghr_forward_stage1 + ghr_forward_stage2
+ *   _C.rasterize_gaussians_backward  (rasterize_points.cu:125-206)  -> ghr_backward
+ *   _C.mark_visible                  (rasterize_points.cu:208-227)  -> ghr_mark_visible
+ *   CudaRasterizer::required<State>  (rasterizer_impl.h:67-73)      -> ghr_forward_sizes / ghr_binning_size
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no torch / C++ types.  All pointers are DEVICE pointers unless the
+ *    name ends in `_host`.  `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *  - Nullable pointers select the mode exactly like the reference's empty-tensor => nullptr convention
+ *    (diff_gaussian_rasterization/__init__.py:210-222; forward.cu:215,228):
+ *        conic_precomp != NULL            : "pipeline mode" (A): conic supplied by the caller (what render() does)
+ *        conic_precomp == NULL            : "kernel-geometry mode" (B): cov3D_precomp, or scales+rotations, in-kernel
+ *  - Matrices are the reference's: 16 floats, element [4*c + r] multiplies component c into output r
+ *    (auxiliary.h:58-77), i.e. world_view_transform / full_proj_transform of src/scene/cameras.py:72-80.
+ *  - Feature channels: `colors` is [P, C] row-major, C == GHR_NUM_CHANNELS (config.h:15).  Like the reference
+ *    (rasterizer_impl.cu:244-247) the library refuses to run without precomputed colors.
+ *  - Every function returns 0 on success, a negative GHR_E_* code on failure; ghr_last_error() returns a
+ *    thread-local description.  No exceptions cross the ABI.  Kernels never trap: a Gaussian that fails the near
+ *    test is culled even when `prefiltered` is set (the reference __trap()s, auxiliary.h:154-162).
+ *  - Ownership: the caller owns every buffer (workspaces included) and must keep geom/img/bin workspaces alive
+ *    and unmodified between forward and backward of the same view (the reference does this with
+ *    ctx.save_for_backward, __init__.py:102).  The library allocates nothing and never synchronises, except that
+ *    `debug != 0` makes each call hipStreamSynchronize + check errors before returning (auxiliary.h:166-173).
+ */
+#ifndef GHR_H
+#define GHR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHR_ABI_VERSION 1
+#define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
+#define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
+#define GHR_GRAD_STRIDE 16  /* floats per Gaussian in the packed gradient scratch of ghr_backward */
+
+#define GHR_OK 0
+#define GHR_E_INVALID (-1)  /* bad argument (NULL where required, C != GHR_NUM_CHANNELS, ...) */
+#define GHR_E_NOCOLORS (-2) /* "For non-RGB, provide precomputed Gaussian colors!" */
+#define GHR_E_HIP (-3)      /* a HIP runtime call or kernel launch failed */
+
+/* Inputs shared by forward and backward of one view (argument lists of rasterize_points.h:18-69). */
+typedef struct ghr_view_args {
+    int32_t P;                  /* number of Gaussians handed to the op (after the Python-side mask) */
+    int32_t W, H;               /* image_width, image_height */
+    int32_t C;                  /* feature channels; must be GHR_NUM_CHANNELS */
+    const float* background;    /* [C] */
+    const float* means3D;       /* [P,3] */
+    const float* colors;        /* [P,C] colors_precomp */
+    const float* opacities;     /* [P] (tensor [P,1]) */
+    const float* scales;        /* [P,3] or NULL */
+    const float* rotations;     /* [P,4] (r,x,y,z), NOT normalised in-kernel (forward.cu:127), or NULL */
+    const float* cov3D_precomp; /* [P,6] or NULL */
+    const float* conic_precomp; /* [P,3] (a, b, c) or NULL */
+    const float* viewmatrix;    /* [16] */
+    const float* projmatrix;    /* [16] */
+    float scale_modifier;
+    float tan_fovx, tan_fovy;
+    int32_t prefiltered;        /* accepted for API parity; culling is always silent */
+    int32_t debug;              /* != 0: synchronise + check after the call */
+} ghr_view_args;
+
+const char* ghr_last_error(void);
+int ghr_abi_version(void);
+
+/* Workspace sizes (host only).  geom: per-Gaussian state (packed 64-B render records, depths, tile rects,
+ * [mode B: cov3D]); img: per-pixel final_T / n_contrib + per-tile counts and list offsets. */
+int ghr_forward_sizes(int32_t P, int32_t W, int32_t H, int32_t mode_b, size_t* geom_bytes, size_t* img_bytes);
+/* bin: per-instance (Gaussian x tile) sort keys + the sorted point list. */
+int ghr_binning_size(uint32_t R, size_t* bin_bytes);
+
+/* Stage 1 = preprocess (K1) + per-tile instance count + tile offset scan.  Writes radii[P] (int32, 0 = culled)
+ * and asynchronously copies num_rendered R to *R_host (pinned host memory; valid once `stream` reaches the
+ * point after this call, e.g. after hipStreamSynchronize -- the reference blocks on the same 4 bytes,
+ * rasterizer_impl.cu:284-285). */
+int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void* img_ws, int32_t* radii,
+                       uint32_t* R_host);
+
+/* Stage 2 = instance scatter + per-tile depth sort (== the reference's global (tile|depth) stable radix sort,
+ * rasterizer_impl.cu:293-321) + front-to-back compositing (K7).  out_color is [C,H,W]. */
+int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
+                       float* out_color);
+
+/* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  grad_scratch: GHR_GRAD_STRIDE*P floats, zeroed by the call.
+ * Outputs (all fully written, no pre-zeroing needed), shapes of rasterize_points.cu:160-168:
+ *   dL_dmeans2D [P,3] (z = 0), dL_dconic [P,2,2] ([0][0], [0][1] = HALF of d/db as in backward.cu:554, [1][1]),
+ *   dL_dopacity [P], dL_dcolors [P,C], dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dscales [P,3], dL_drotations [P,4]. */
+int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
+                 const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                 float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations);
+
+/* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
+int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
+                     const float* projmatrix, uint8_t* present);
+
+/* Introspection for tests (device pointers into the workspaces; layout is otherwise private). */
+typedef struct ghr_ws_view {
+    const float* rec;          /* [P][16]: x, y, conic a, b, c, opacity, features[10] */
+    const float* depths;       /* [P] */
+    const uint32_t* rects;     /* [P][2]: (xmin | xmax<<16), (ymin | ymax<<16) */
+    const float* cov3D;        /* [P][6] (mode B) or NULL */
+    const float* final_T;      /* [H*W] */
+    const uint32_t* n_contrib; /* [H*W] */
+    const uint32_t* tile_start;/* [T+1] exclusive scan of per-tile instance counts == ranges */
+    const uint64_t* keys;      /* [R] per-tile sorted (depth_bits << 32 | gaussian idx) */
+    const uint32_t* point_list;/* [R] */
+} ghr_ws_view;
+int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, const void* geom_ws,
+                   const void* img_ws, const void* bin_ws, ghr_ws_view* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHR_H */

@@ -1,0 +1,202 @@
+// ghr_hostsim.cpp -- TEST SCAFFOLDING (never shipped, never on the product path).
+//
+// Runs the product's own `__host__ __device__` per-Gaussian / per-pixel functions (gaussianhaircut_amd/csrc/*.h:
+// preprocess_one, bitonic_any_n, fwd_step, bwd_step, geom_bwd_one, xcd_tile) sequentially on the CPU, with the
+// same orchestration as csrc/ghr_capi.hip, so that the `-m "not gpu"` suite can compare the kernels' arithmetic
+// with the oracle before any GPU time is spent.  What it cannot cover (LDS staging, wave reductions, atomics,
+// barriers) is covered by the `-m gpu` parity tests.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/ghr.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_binning.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_geom_bwd.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_preprocess.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_render_bwd.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_render_fwd.h"
+
+namespace {
+struct Sim {
+    int P, W, H, gx, gy, T;
+    bool mode_b;
+    std::vector<ghr::f4> rec;
+    std::vector<float> depths, cov3D, final_T;
+    std::vector<uint2> rects;
+    std::vector<int> radii;
+    std::vector<uint32_t> tile_start, point_list, n_contrib;
+    std::vector<uint64_t> keys;
+    uint32_t R;
+};
+}  // namespace
+
+extern "C" {
+
+void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_color)
+{
+    Sim* s = new Sim();
+    s->P = a->P; s->W = a->W; s->H = a->H;
+    s->gx = (a->W + 15) / 16; s->gy = (a->H + 15) / 16; s->T = s->gx * s->gy;
+    s->mode_b = a->conic_precomp == nullptr;
+    const int P = a->P, T = s->T;
+    s->rec.assign((size_t)4 * P, ghr::f4{0, 0, 0, 0});
+    s->depths.assign(P, 0.f);
+    s->rects.assign(P, uint2{0u, 0u});
+    s->cov3D.assign((size_t)6 * P, 0.f);
+    s->radii.assign(P, 0);
+    std::vector<uint32_t> count(T, 0u);
+
+    ghr::PreArgs pa;
+    pa.P = P; pa.W = a->W; pa.H = a->H; pa.gx = s->gx; pa.gy = s->gy;
+    pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;
+    pa.scales = a->scales; pa.rotations = a->rotations; pa.cov3D_precomp = a->cov3D_precomp;
+    pa.conic_precomp = a->conic_precomp; pa.view = a->viewmatrix; pa.proj = a->projmatrix;
+    pa.scale_modifier = a->scale_modifier; pa.tan_fovx = a->tan_fovx; pa.tan_fovy = a->tan_fovy;
+    pa.focal_y = a->H / (2.0f * a->tan_fovy);
+    pa.focal_x = a->W / (2.0f * a->tan_fovx);
+    pa.rec = s->rec.data(); pa.depths = s->depths.data(); pa.rects = s->rects.data(); pa.cov3D = s->cov3D.data();
+    pa.radii = s->radii.data(); pa.tile_count = count.data();
+    for (int idx = 0; idx < P; idx++) {
+        int x0, y0, x1, y1;
+        if (!ghr::preprocess_one(pa, idx, x0, y0, x1, y1)) continue;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) count[y * s->gx + x]++;
+    }
+    // k_tile_scan
+    s->tile_start.assign(T + 1, 0u);
+    for (int t = 0; t < T; t++) s->tile_start[t + 1] = s->tile_start[t] + count[t];
+    s->R = s->tile_start[T];
+    // k_scatter (appended in DESCENDING idx order on purpose: the sort must not depend on append order)
+    s->keys.assign(s->R, 0ull);
+    s->point_list.assign(s->R, 0u);
+    std::vector<uint32_t> cursor(T, 0u);
+    for (int idx = P - 1; idx >= 0; idx--) {
+        const uint2 r = s->rects[idx];
+        const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
+        if (x1 <= x0 || y1 <= y0) continue;
+        uint32_t db;
+        std::memcpy(&db, &s->depths[idx], 4);
+        const uint64_t key = ((uint64_t)db << 32) | (uint32_t)idx;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const int t = y * s->gx + x;
+                s->keys[s->tile_start[t] + cursor[t]++] = key;
+            }
+    }
+    // k_tile_sort
+    for (int t = 0; t < T; t++) {
+        const uint32_t b = s->tile_start[t], n = s->tile_start[t + 1] - b;
+        if (n > 1) ghr::bitonic_any_n(s->keys.data() + b, n, 0, 1);
+        for (uint32_t i = 0; i < n; i++) s->point_list[b + i] = (uint32_t)s->keys[b + i];
+    }
+    // k_render_fwd
+    const size_t N = (size_t)a->W * a->H;
+    s->final_T.assign(N, 0.f);
+    s->n_contrib.assign(N, 0u);
+    for (int t = 0; t < T; t++) {
+        const int tx = t % s->gx, ty = t / s->gx;
+        const uint32_t beg = s->tile_start[t], n = s->tile_start[t + 1] - beg;
+        for (int tid = 0; tid < 256; tid++) {
+            const int px = tx * 16 + (tid & 15), py = ty * 16 + (tid >> 4);
+            if (!(px < a->W && py < a->H)) continue;
+            ghr::PixFwd st;
+            st.T = 1.f; st.last = 0;
+            for (int c = 0; c < GHR_C; c++) st.C[c] = 0.f;
+            bool done = false;
+            for (uint32_t j = 0; j < n && !done; j++) {
+                const ghr::f4* r = s->rec.data() + 4 * (size_t)s->point_list[beg + j];
+                done = ghr::fwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
+            }
+            const size_t pix = (size_t)a->W * py + px;
+            s->final_T[pix] = st.T;
+            s->n_contrib[pix] = st.last;
+            for (int c = 0; c < GHR_C; c++) out_color[c * N + pix] = st.C[c] + st.T * a->background[c];
+        }
+    }
+    std::memcpy(radii_out, s->radii.data(), sizeof(int) * P);
+    return s;
+}
+
+uint32_t ghrsim_num_rendered(void* h) { return ((Sim*)h)->R; }
+const float* ghrsim_rec(void* h) { return (const float*)((Sim*)h)->rec.data(); }
+const float* ghrsim_depths(void* h) { return ((Sim*)h)->depths.data(); }
+const uint32_t* ghrsim_tile_start(void* h) { return ((Sim*)h)->tile_start.data(); }
+const uint32_t* ghrsim_point_list(void* h) { return ((Sim*)h)->point_list.data(); }
+const uint64_t* ghrsim_keys(void* h) { return ((Sim*)h)->keys.data(); }
+const float* ghrsim_final_T(void* h) { return ((Sim*)h)->final_T.data(); }
+const uint32_t* ghrsim_n_contrib(void* h) { return ((Sim*)h)->n_contrib.data(); }
+void ghrsim_free(void* h) { delete (Sim*)h; }
+
+void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, float* dL_dmeans2D, float* dL_dconic,
+                     float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D, float* dL_dcov3D, float* dL_dscales,
+                     float* dL_drotations)
+{
+    Sim* s = (Sim*)h;
+    const int P = s->P, T = s->T;
+    const size_t N = (size_t)a->W * a->H;
+    std::vector<double> acc((size_t)16 * P, 0.0);  // the GPU sums in fp32 atomics; order-free reference sum here
+    const float ddelx_dx = 0.5f * a->W, ddely_dy = 0.5f * a->H;
+    for (int t = 0; t < T; t++) {
+        const int tx = t % s->gx, ty = t / s->gx;
+        const uint32_t beg = s->tile_start[t], n = s->tile_start[t + 1] - beg;
+        for (int tid = 0; tid < 256; tid++) {
+            const int px = tx * 16 + (tid & 15), py = ty * 16 + (tid >> 4);
+            if (!(px < a->W && py < a->H)) continue;
+            const size_t pix = (size_t)a->W * py + px;
+            ghr::PixBwd st;
+            st.T_final = s->final_T[pix]; st.T = st.T_final; st.S = 0.f; st.last_alpha = 0.f; st.last_cdot = 0.f;
+            st.bgdot = 0.f;
+            for (int c = 0; c < GHR_C; c++) {
+                st.dL[c] = dL_dpix[c * N + pix];
+                st.bgdot = ghr::fma_(a->background[c], st.dL[c], st.bgdot);
+            }
+            const uint32_t last = s->n_contrib[pix];
+            for (uint32_t k = 0; k < n; k++) {
+                const uint32_t pos = n - 1 - k;
+                if (!(pos < last)) continue;
+                const uint32_t id = s->point_list[beg + pos];
+                const ghr::f4* r = s->rec.data() + 4 * (size_t)id;
+                float g[16];
+                if (ghr::bwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g))
+                    for (int i = 0; i < 16; i++) acc[(size_t)16 * id + i] += (double)g[i];
+            }
+        }
+    }
+    std::vector<float> gacc((size_t)16 * P);
+    for (size_t i = 0; i < gacc.size(); i++) gacc[i] = (float)acc[i];
+    ghr::GeomBwdArgs ga;
+    ga.P = P; ga.means3D = a->means3D; ga.radii = s->radii.data(); ga.scales = a->scales; ga.rotations = a->rotations;
+    ga.cov3D = s->cov3D.data(); ga.conic_precomp = a->conic_precomp; ga.view = a->viewmatrix; ga.proj = a->projmatrix;
+    ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
+    ga.focal_y = a->H / (2.0f * a->tan_fovy);
+    ga.focal_x = a->W / (2.0f * a->tan_fovx);
+    ga.gacc = gacc.data();
+    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
+    ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
+    for (int idx = 0; idx < P; idx++) ghr::geom_bwd_one(ga, idx);
+}
+
+// xcd_tile must be a bijection of [0, n)
+int ghrsim_xcd_bijective(uint32_t n)
+{
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t t = ghr::xcd_tile(b, n);
+        if (t >= n || seen[t]) return 0;
+        seen[t] = 1;
+    }
+    return 1;
+}
+
+// sorts `n` keys with the product's network; returns 1 if the result is ascending
+int ghrsim_bitonic(uint64_t* keys, uint32_t n)
+{
+    if (n > 1) ghr::bitonic_any_n(keys, n, 0, 1);
+    for (uint32_t i = 1; i < n; i++)
+        if (keys[i - 1] > keys[i]) return 0;
+    return 1;
+}
+
+}  // extern "C"

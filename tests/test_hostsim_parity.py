@@ -1,0 +1,84 @@
+"""CPU parity of the product's device functions (run through tests/hostsim) against the oracle.
+
+This is the `-m "not gpu"` stand-in for the kernel parity tests: same per-Gaussian / per-pixel code the HIP kernels
+inline, executed sequentially on the host.  Integer outputs must match the oracle bit for bit."""
+import numpy as np
+import pytest
+
+from gaussianhaircut_amd.utils import synthetic as syn
+from tests import helpers as hp
+
+
+def _ranges_from_tile_start(ts):
+    ranges = np.stack([ts[:-1], ts[1:]], axis=1).astype(np.uint32)
+    ranges[ts[:-1] == ts[1:]] = 0  # the reference leaves empty tiles at (0,0) (memset, rasterizer_impl.cu:314)
+    return ranges
+
+
+@pytest.mark.parametrize("cfg,mode", [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"),
+                                      ("tiny", "B_cov"), ("tiny_strands", "A_sr"), ("cfg1", "A")])
+def test_forward_matches_oracle(oracle_mod, hostsim, cfg, mode):
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
+    st = hostsim.forward(ri, mode)
+    try:
+        # K1: bit-exact per-Gaussian state
+        np.testing.assert_array_equal(st["radii"], radii_o)
+        vis = radii_o > 0
+        np.testing.assert_array_equal(st["depths"][vis].view(np.uint32), st_o.depths[vis].view(np.uint32))
+        np.testing.assert_array_equal(st["rec"][vis, 0:2].view(np.uint32), st_o.xy[vis].view(np.uint32))
+        np.testing.assert_array_equal(st["rec"][vis, 2:6].view(np.uint32), st_o.conic_opacity[vis].view(np.uint32))
+        # binning: identical instance count, tile ranges and sorted lists
+        assert st["R"] == st_o.num_rendered
+        np.testing.assert_array_equal(_ranges_from_tile_start(st["tile_start"]), st_o.ranges)
+        np.testing.assert_array_equal(st["point_list"], st_o.point_list)
+        # K7
+        frag = st_o.fragile.reshape(-1).astype(bool)
+        assert frag.mean() < 2e-3
+        ok = ~frag
+        np.testing.assert_array_equal(st["n_contrib"][ok], st_o.n_contrib[ok])
+        assert hp.image_close(st["final_T"][ok], st_o.final_T[ok]).all()
+        H, W = spec.H, spec.W
+        close = hp.image_close(st["out"].reshape(10, -1)[:, ok], out_o.reshape(10, -1)[:, ok])
+        assert close.all(), "max err %g" % np.abs(st["out"].reshape(10, -1)[:, ok] - out_o.reshape(10, -1)[:, ok]).max()
+    finally:
+        hostsim.free(st)
+
+
+@pytest.mark.parametrize("cfg,mode", [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"),
+                                      ("tiny", "B_cov"), ("tiny_strands", "A_sr")])
+def test_backward_matches_oracle(oracle_mod, hostsim, cfg, mode):
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
+    dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)  # O(1) per-pixel gradients
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, mode)
+    st = hostsim.forward(ri, mode)
+    try:
+        got = hostsim.backward(st, dL)
+        hp.assert_grads_close(got, ref)
+        if mode.startswith("B"):
+            assert np.abs(ref["dL_dmeans3D"]).sum() > 0
+        if mode == "B_sr":
+            assert np.abs(ref["dL_dscales"]).sum() > 0 and np.abs(ref["dL_drotations"]).sum() > 0
+    finally:
+        hostsim.free(st)
+
+
+def test_xcd_tile_is_a_bijection(hostsim):
+    for n in (1, 7, 8, 9, 63, 64, 65, 768, 8160, 8161, 8167):
+        assert hostsim.L.ghrsim_xcd_bijective(n) == 1, n
+
+
+def test_bitonic_network_any_length(hostsim):
+    import ctypes
+    rng = np.random.default_rng(0)
+    for n in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 1000, 4095, 4096, 4097, 5000]:
+        keys = rng.integers(0, 1 << 40, size=max(n, 1), dtype=np.uint64)
+        if n > 3:
+            keys[: n // 2] = keys[0]  # heavy ties
+        ref = np.sort(keys[:n])
+        assert hostsim.L.ghrsim_bitonic(ctypes.c_void_p(keys.ctypes.data), ctypes.c_uint32(n)) == 1
+        np.testing.assert_array_equal(keys[:n], ref)
