@@ -84,7 +84,7 @@ class WsView(ctypes.Structure):
 
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
-           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect"]
+           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events"]
 
 _lib = None
 
@@ -108,6 +108,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp]
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

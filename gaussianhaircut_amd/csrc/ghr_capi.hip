@@ -18,6 +18,7 @@
 namespace {
 
 thread_local char g_err[512] = "";
+thread_local hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
 
 int fail(int code, const char* fmt, const char* detail = "")
 {
@@ -194,8 +195,10 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
                            b.point_list);
     }
+    if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T, im.tile_start,
                        b.point_list, g.rec, a->background, out_color, im.final_T, im.n_contrib);
+    if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }
 
@@ -219,10 +222,12 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
 
     GHR_HIP(hipMemsetAsync(grad_scratch, 0, sizeof(float) * GHR_GRAD_STRIDE * (size_t)a->P, s));
+    if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
         hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T,
                            im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib, dL_dpix,
                            grad_scratch);
+    if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
     ga.cov3D = g.cov3D; ga.conic_precomp = a->conic_precomp; ga.view = a->viewmatrix; ga.proj = a->projmatrix;
@@ -247,6 +252,13 @@ int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float*
     hipLaunchKernelGGL(ghr::k_mark_visible, dim3((P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, P, means3D,
                        viewmatrix, present);
     return finish(s, 0);
+}
+
+int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop)
+{
+    g_ev[0] = (hipEvent_t)fwd_start; g_ev[1] = (hipEvent_t)fwd_stop;
+    g_ev[2] = (hipEvent_t)bwd_start; g_ev[3] = (hipEvent_t)bwd_stop;
+    return GHR_OK;
 }
 
 int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, const void* geom_ws,

@@ -1,0 +1,73 @@
+"""The measured gradient step: shape of the reference's stage-1 loop body (``src/train_gaussians.py:96-181``) without
+densification / logging / GUI -- lr schedule, render, losses, backward, [grad all-reduce], NaN guard, Adam."""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import List, Optional
+
+import torch
+
+from .gaussian_renderer import render
+from .parallel import FlatGradBucket
+from .utils.loss_utils import l1_loss, or_loss, ssim
+
+PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
+
+
+def view_loss(render_pkg, cam, opt):
+    """train_gaussians.py:113-140."""
+    image, mask = render_pkg["render"], render_pkg["mask"]
+    gt_image, gt_mask = cam.original_image, cam.original_mask
+    Ll1 = l1_loss(image, gt_image, mask=gt_mask[1:].detach())
+    Lssim = 1.0 - ssim(image * gt_mask[1:], gt_image * gt_mask[1:])
+    Lmask = l1_loss(mask, gt_mask)
+    loss = Ll1 * opt.lambda_dl1 + Lssim * opt.lambda_dssim + Lmask * opt.lambda_dmask
+    if opt.lambda_dorient != 0.0:
+        w = torch.ones_like(gt_mask[:1]) * cam.original_orient_conf
+        Lorient = or_loss(render_pkg["orient_angle"], cam.original_orient_angle, render_pkg["orient_conf"], weight=w,
+                          mask=gt_mask[:1])
+        Lorient = torch.where(torch.isnan(Lorient), torch.zeros_like(Lorient), Lorient)
+        loss = loss + Lorient * opt.lambda_dorient
+    return loss
+
+
+def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
+                  global_views: Optional[int] = None, pipe=PIPE):
+    """One global gradient step over this rank's views.  Returns the (detached) summed local loss."""
+    gaussians.update_learning_rate(iteration)
+    V = global_views or len(cams)
+    total = None
+    for cam in cams:
+        pkg = render(cam, gaussians, pipe, background)
+        loss = view_loss(pkg, cam, opt) / V
+        loss.backward()
+        total = loss.detach() if total is None else total + loss.detach()
+    if bucket is not None:
+        bucket.all_reduce()
+        bad = bucket.has_nan()
+    else:
+        bad = torch.stack([p.grad.isnan().any() for p in gaussians.leaf_parameters() if p.grad is not None]).any()
+    # train_gaussians.py:174-181: a NaN anywhere skips the update (device-side select, no host sync)
+    if bucket is not None:
+        bucket.flat.mul_((~bad).to(bucket.flat.dtype))
+        torch.nan_to_num_(bucket.flat, nan=0.0)
+        gaussians.optimizer.step()
+        bucket.zero()
+    else:
+        if bool(bad):
+            gaussians.optimizer.zero_grad(set_to_none=True)
+            print('NaN during backprop was found, skipping iteration...')
+        gaussians.optimizer.step()
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    return total
+
+
+@torch.no_grad()
+def make_ground_truth(gaussians_gt, cams: List, background, pipe=PIPE):
+    """Synthetic supervision: render a (perturbed) model and attach the maps the loss reads (cameras.py fields)."""
+    for cam in cams:
+        pkg = render(cam, gaussians_gt, pipe, background)
+        cam.original_image = pkg["render"].clamp(0, 1).detach()
+        cam.original_mask = pkg["mask"].clamp(0, 1).detach()
+        cam.original_orient_angle = pkg["orient_angle"].detach()
+        cam.original_orient_conf = torch.ones_like(pkg["orient_conf"]).detach()

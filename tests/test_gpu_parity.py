@@ -1,0 +1,275 @@
+"""`-m gpu` parity tests proper: the HIP path, called through the C ABI, against the oracle on the same seeded inputs.
+
+Integer / index outputs are compared bit for bit; floats within 1e-4 (rules in tests/helpers.py)."""
+import numpy as np
+import pytest
+import torch
+
+from gaussianhaircut_amd.utils import synthetic as syn
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need a ROCm device"
+    return torch.device("cuda:0")
+
+
+def _ranges(ts):
+    r = np.stack([ts[:-1], ts[1:]], axis=1).astype(np.uint32)
+    r[ts[:-1] == ts[1:]] = 0
+    return r
+
+
+def _check_forward(run, out_o, radii_o, st_o, frag_limit=2e-3):
+    ins = run.inspect()
+    np.testing.assert_array_equal(run.radii.cpu().numpy(), radii_o)
+    vis = radii_o > 0
+    np.testing.assert_array_equal(ins["depths"][vis].view(np.uint32), st_o.depths[vis].view(np.uint32))
+    np.testing.assert_array_equal(ins["rec"][vis, 0:2].view(np.uint32), st_o.xy[vis].view(np.uint32))
+    np.testing.assert_array_equal(ins["rec"][vis, 2:6].view(np.uint32), st_o.conic_opacity[vis].view(np.uint32))
+    assert run.R == st_o.num_rendered
+    np.testing.assert_array_equal(_ranges(ins["tile_start"]), st_o.ranges)
+    np.testing.assert_array_equal(ins["point_list"], st_o.point_list)
+    frag = st_o.fragile.reshape(-1).astype(bool)
+    assert frag.mean() < frag_limit
+    ok = ~frag
+    np.testing.assert_array_equal(ins["n_contrib"][ok], st_o.n_contrib[ok])
+    assert hp.image_close(ins["final_T"][ok], st_o.final_T[ok]).all()
+    got = run.out.cpu().numpy().reshape(10, -1)[:, ok]
+    ref = out_o.reshape(10, -1)[:, ok]
+    assert np.isfinite(got).all()
+    close = hp.image_close(got, ref)
+    assert close.all(), "%d px-channels off, max err %g" % ((~close).sum(), np.abs(got - ref).max())
+    # fragile pixels may differ, but only boundedly (one splat more or less)
+    return ins
+
+
+CASES = [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"),
+         ("tiny_strands", "A_sr"), ("cfg1", "A"), ("cfg1", "B_sr")]
+
+
+@pytest.mark.parametrize("cfg,mode", CASES)
+def test_forward_backward_vs_oracle(oracle_mod, dev, cfg, mode):
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
+    run = GpuRun(to_dev(ri, dev), mode)
+    _check_forward(run, out_o, radii_o, st_o)
+    dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, mode)
+    got = run.backward(torch.from_numpy(dL))
+    hp.assert_grads_close(got, ref)
+
+
+def test_cfg2_full_size_vs_oracle(oracle_mod, dev):
+    """BASELINE.json configs[1]: 100k Gaussians, 1920x1080, fwd+bwd vs the oracle at full size (tol 1e-4)."""
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS["cfg2"]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "A")
+    run = GpuRun(to_dev(ri, dev), "A", debug=False)
+    _check_forward(run, out_o, radii_o, st_o)
+    dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "A")
+    got = run.backward(torch.from_numpy(dL))
+    hp.assert_grads_close(got, ref)
+
+
+def test_cfg3_full_size_properties_and_oracle(oracle_mod, dev):
+    """BASELINE.json configs[2] shape: 500k strand-aligned Gaussians at 1080p.  Oracle comparison plus the
+    size-independent properties: per-tile sortedness, count conservation, determinism, linearity of the backward."""
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS["cfg3"]
+    ri = syn.raster_inputs(spec)
+    rid = to_dev(ri, dev)
+    run = GpuRun(rid, "A", debug=False)
+    ins = run.inspect()
+    ts = ins["tile_start"].astype(np.int64)
+    assert ts[0] == 0 and ts[-1] == run.R and (np.diff(ts) >= 0).all()
+    # rect areas sum to R (checksum of checksums)
+    rects = ins["rects"]
+    area = ((rects[:, 0] >> 16).astype(np.int64) - (rects[:, 0] & 0xffff)) * \
+           ((rects[:, 1] >> 16).astype(np.int64) - (rects[:, 1] & 0xffff))
+    assert area.sum() == run.R
+    # every tile list is sorted by (depth bits, idx) and refers to Gaussians whose rect contains the tile
+    keys = ins["keys"]
+    seg = np.repeat(np.arange(len(ts) - 1), np.diff(ts))
+    same = seg[1:] == seg[:-1]
+    assert (keys[1:][same] > keys[:-1][same]).all()
+    assert (ins["point_list"] == (keys & np.uint64(0xffffffff)).astype(np.uint32)).all()
+    assert (ins["n_contrib"] <= np.repeat(np.diff(ts), 1).max()).all()
+    assert ((ins["final_T"] >= 0) & (ins["final_T"] <= 1)).all()
+    # determinism / idempotence of the forward
+    run2 = GpuRun(rid, "A", debug=False)
+    assert torch.equal(run.out, run2.out) and torch.equal(run.radii, run2.radii)
+    np.testing.assert_array_equal(ins["point_list"], run2.inspect()["point_list"])
+    # oracle at full size
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "A")
+    _check_forward(run, out_o, radii_o, st_o)
+    dL = syn.grad_image(spec, 303).numpy() * (spec.H * spec.W)
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "A")
+    g1 = run.backward(torch.from_numpy(dL))
+    hp.assert_grads_close(g1, ref)
+    # linearity in dL/dpixel: bwd(2 dL) == 2 bwd(dL) up to fp32 atomic reordering
+    g2 = run.backward(torch.from_numpy(2 * dL))
+    hp.assert_grads_close({k: v for k, v in g2.items()}, {k: 2 * v for k, v in g1.items()})
+
+
+def _manual_inputs(dev, xyz, scales, opac, W=64, H=48, colors=None):
+    """A few hand-placed isotropic Gaussians in front of the SURVEY camera (mode B inputs)."""
+    from gaussianhaircut_amd.scene.cameras import make_camera
+    import math
+    cam = make_camera(W, H, device="cpu")
+    P = xyz.shape[0]
+    rot = torch.zeros(P, 4)
+    rot[:, 0] = 1
+    colors = colors if colors is not None else torch.rand(P, 10, generator=torch.Generator().manual_seed(5))
+    return dict(P=P, W=W, H=H, means3D=xyz.float(), means2D=torch.zeros(P, 3), colors=colors.float(),
+                opacities=opac.reshape(P, 1).float(), cov3D=torch.zeros(P, 6), conic=torch.zeros(P, 3),
+                scales=scales.float(), rotations=rot, bg=syn.background(), viewmatrix=cam.world_view_transform,
+                projmatrix=cam.full_proj_transform, tanfovx=math.tan(float(cam.FoVx) * 0.5),
+                tanfovy=math.tan(float(cam.FoVy) * 0.5), campos=cam.camera_center)
+
+
+def _run_manual(oracle_mod, dev, ri, check_bwd=True):
+    from tests.gpu_helpers import GpuRun, to_dev
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "B_sr")
+    run = GpuRun(to_dev(ri, dev), "B_sr")
+    _check_forward(run, out_o, radii_o, st_o, frag_limit=0.05)
+    if check_bwd and ri["P"] > 0:
+        g = torch.Generator().manual_seed(11)
+        dL = torch.randn(10, ri["H"], ri["W"], generator=g).numpy()
+        dL[:, st_o.fragile.astype(bool)] = 0
+        ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "B_sr")
+        hp.assert_grads_close(run.backward(torch.from_numpy(dL)), ref)
+    return run, st_o
+
+
+def test_edge_empty_input(dev):
+    from gaussianhaircut_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    ri = _manual_inputs(dev, torch.zeros(0, 3), torch.zeros(0, 3), torch.zeros(0))
+    rs = GaussianRasterizationSettings(ri["H"], ri["W"], ri["tanfovx"], ri["tanfovy"], ri["bg"].to(dev), 1.0,
+                                       ri["viewmatrix"].to(dev), ri["projmatrix"].to(dev), 3, ri["campos"].to(dev),
+                                       True, False)
+    e = torch.zeros(0, 3, device=dev)
+    color, radii = GaussianRasterizer(rs)(means3D=e, means2D=e, opacities=torch.zeros(0, 1, device=dev),
+                                          colors_precomp=torch.zeros(0, 10, device=dev), scales=e,
+                                          rotations=torch.zeros(0, 4, device=dev))
+    assert color.shape == (10, ri["H"], ri["W"]) and radii.numel() == 0
+    assert (color == 0).all()  # the reference returns the zero-filled image when P == 0 (rasterize_points.cu:70,87)
+
+
+def test_edge_all_culled_and_near_plane(oracle_mod, dev):
+    # behind the camera, inside the near band (view z = 0.125 <= 0.2: culled), just past it (0.25), well in front
+    z = torch.tensor([-10.0, -3.875, -3.75, -3.0])  # camera sits at z = -4 looking +z => view z = z + 4 (exact)
+    xyz = torch.stack([torch.zeros(4), torch.zeros(4), z], dim=1)
+    ri = _manual_inputs(dev, xyz, torch.full((4, 3), 0.05), torch.full((4,), 0.8))
+    run, st = _run_manual(oracle_mod, dev, ri)
+    r = run.radii.cpu().numpy()
+    assert r[0] == 0 and r[1] == 0 and r[2] > 0 and r[3] > 0
+    ri0 = _manual_inputs(dev, xyz[:2], torch.full((2, 3), 0.05), torch.full((2,), 0.8))
+    run0, st0 = _run_manual(oracle_mod, dev, ri0, check_bwd=True)
+    assert run0.R == 0
+    assert torch.allclose(run0.out, ri0["bg"].to(dev)[:, None, None].expand_as(run0.out))
+
+
+def test_edge_borders_huge_and_ragged_image(oracle_mod, dev):
+    # Gaussians on the image border / outside it, one covering the whole frame; 70x37 is not a multiple of 16
+    xyz = torch.tensor([[0.0, 0.0, 0.0], [1.4, 0.0, 0.0], [-1.45, 1.0, 0.0], [0.0, -1.05, 0.3], [5.0, 5.0, 0.0],
+                        [0.2, 0.1, -1.0]])
+    scales = torch.tensor([[3.0, 3.0, 3.0], [0.05, 0.2, 0.05], [0.1, 0.1, 0.1], [0.02, 0.02, 0.02],
+                           [0.1, 0.1, 0.1], [0.3, 0.01, 0.01]])
+    ri = _manual_inputs(dev, xyz, scales, torch.tensor([0.3, 0.9, 0.7, 1.0, 0.5, 0.99]), W=70, H=37)
+    run, st = _run_manual(oracle_mod, dev, ri)
+    assert run.R > 0
+
+
+def test_edge_depth_ties_and_long_tile_list(oracle_mod, dev):
+    """> 4096 instances in ONE tile (LDS sort capacity) with many exactly equal depths: exercises the in-place
+    global sort path and the tie-break by ascending Gaussian index."""
+    P = 5000
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.zeros(P, 3)
+    xyz[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 0.05
+    xyz[:, 2] = torch.randint(0, 7, (P,), generator=g).float() * 0.01  # 7 distinct depths => massive ties
+    ri = _manual_inputs(dev, xyz, torch.full((P, 3), 0.004), torch.full((P,), 0.02), W=64, H=64)
+    run, st = _run_manual(oracle_mod, dev, ri)
+    counts = np.diff(run.inspect()["tile_start"].astype(np.int64))
+    assert counts.max() > 4096
+
+
+def test_analytic_single_gaussian(dev):
+    """One isotropic Gaussian at the image centre: alpha(d) = min(.99, o * exp(-d^2 / (2 s^2))) in closed form."""
+    from tests.gpu_helpers import GpuRun, to_dev
+    import math
+    W = H = 65  # centre pixel 32 is exactly the projection of the origin: ndc 0 -> ((0+1)*65-1)/2 = 32
+    o, s_world = 0.8, 0.1
+    ri = _manual_inputs(dev, torch.zeros(1, 3), torch.full((1, 3), s_world), torch.tensor([o]), W=W, H=H,
+                        colors=torch.ones(1, 10))
+    run = GpuRun(to_dev(ri, dev), "B_sr")
+    focal = H / (2 * ri["tanfovy"])
+    var = (s_world * focal / 4.0) ** 2 + 0.3  # cov2D = (f s / z)^2 + 0.3 low-pass
+    ys, xs = np.mgrid[0:H, 0:W]
+    d2 = (xs - 32.0) ** 2 + (ys - 32.0) ** 2
+    alpha = np.minimum(0.99, o * np.exp(-0.5 * d2 / var))
+    alpha[alpha < 1 / 255] = 0
+    radius = math.ceil(3 * math.sqrt(var + math.sqrt(0.1)))  # forward.cu:255: max(0.1, mid^2 - det) under the root
+    out = run.out.cpu().numpy()
+    # inside the splat's tile rect the image is alpha * 1 (+ T * bg, bg = 0 for channel 0)
+    rect_ok = (np.abs(xs - 32) <= radius) & (np.abs(ys - 32) <= radius)
+    assert np.abs(out[0][rect_ok] - alpha[rect_ok]).max() < 2e-5
+    assert int(run.radii.cpu()[0]) == radius
+
+
+def test_api_rejects_cpu_tensors_and_bad_args(dev):
+    from gaussianhaircut_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    ri = _manual_inputs(dev, torch.zeros(2, 3), torch.full((2, 3), 0.1), torch.full((2,), 0.5))
+    rs = GaussianRasterizationSettings(ri["H"], ri["W"], ri["tanfovx"], ri["tanfovy"], ri["bg"].to(dev), 1.0,
+                                       ri["viewmatrix"].to(dev), ri["projmatrix"].to(dev), 3, ri["campos"].to(dev),
+                                       True, False)
+    r = GaussianRasterizer(rs)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(means3D=ri["means3D"], means2D=ri["means2D"], opacities=ri["opacities"], colors_precomp=ri["colors"],
+          scales=ri["scales"], rotations=ri["rotations"])
+    d = {k: v.to(dev) for k, v in ri.items() if isinstance(v, torch.Tensor)}
+    with pytest.raises(Exception, match="excatly one of either SHs"):
+        r(means3D=d["means3D"], means2D=d["means2D"], opacities=d["opacities"], scales=d["scales"],
+          rotations=d["rotations"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation"):
+        r(means3D=d["means3D"], means2D=d["means2D"], opacities=d["opacities"], colors_precomp=d["colors"])
+    with pytest.raises(RuntimeError, match="provide precomputed Gaussian colors"):
+        r(means3D=d["means3D"], means2D=d["means2D"], opacities=d["opacities"], shs=torch.zeros(2, 16, 3, device=dev),
+          scales=d["scales"], rotations=d["rotations"])
+    vis = r.markVisible(torch.tensor([[0.0, 0, 0], [0, 0, -10.0]], device=dev))
+    assert vis.tolist() == [True, False]
+
+
+def test_render_api_end_to_end_grads(oracle_mod, dev):
+    """render() -> loss -> backward through the PyTorch projection graph: leaf gradients are finite, and the image
+    equals the oracle driven with the same rasterizer-level inputs."""
+    from gaussianhaircut_amd.gaussian_renderer import render
+    from gaussianhaircut_amd.trainer import PIPE
+    spec = syn.CONFIGS["tiny"]
+    model = syn.make_model(spec, dev)
+    cam = syn.make_view(spec, dev)
+    pkg = render(cam, model, PIPE, syn.background(dev))
+    assert pkg["render"].shape == (3, spec.H, spec.W) and pkg["mask"].shape == (2, spec.H, spec.W)
+    assert pkg["orient_angle"].shape == (1, spec.H, spec.W) and pkg["radii"].shape == (spec.P,)
+    loss = pkg["render"].mean() + pkg["mask"].mean() + (pkg["orient_angle"] * pkg["orient_conf"]).mean()
+    loss.backward()
+    for p in model.leaf_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert pkg["viewspace_points"].grad is not None
+    ri = syn.raster_inputs(spec, "cpu", syn.make_model(spec, "cpu"), syn.make_view(spec, "cpu"))
+    out_o, _, st_o = hp.oracle_forward(oracle_mod, ri, "A")
+    ok = ~st_o.fragile.astype(bool)
+    img = pkg["render"].detach().cpu().numpy()
+    # GPU-side torch projection vs CPU-side torch projection differ by rounding: loose tolerance, same picture
+    assert np.abs(img[:, ok] - out_o[:3][:, ok]).mean() < 1e-3
