@@ -1,0 +1,234 @@
+#!/usr/bin/env python
+"""bench.py -- the measured hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A *step* is one global gradient step of the reference's stage-1 loop shape (src/train_gaussians.py:96-181, no
+densification): per rank ``views_per_gpu`` views of the 500k strand-aligned model at 1920x1080 -- render() (PyTorch
+projection + HIP rasterizer forward), losses, backward (HIP rasterizer backward + autograd), one flat all-reduce of the
+Gaussian gradients when N > 1 (RCCL), Adam.  Weak scaling: per-GPU work is fixed as N grows.
+
+One JSON line on rank 0:  value = Gaussians rasterized per second over the whole job = N * views_per_gpu * P / t_step
+(inputs resident in HBM; P = Gaussians of the model, every one of them goes through projection, cull and -- if
+visible -- the rasterizer, forward and backward, each step).
+  roofline     : k_render_bwd (the dominant kernel), algorithmic bytes / HIP-event duration recorded around the kernel
+                 inside the timed steps on the launch stream, against 8 TB/s HBM.
+  cpu_baseline : the CPU oracle (oracle/ghr_oracle.c, OpenMP) on ONE view of the same workload, rasterizer fwd+bwd only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "tiny"])
+    ap.add_argument("--views-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-op-only", action="store_true")
+    args = ap.parse_args()
+
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd import diff_gaussian_rasterization as dgr
+    from gaussianhaircut_amd.parallel import FlatGradBucket, init_distributed
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    from gaussianhaircut_amd.utils import synthetic as syn
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    rank, world = init_distributed()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = _lib.lib()
+
+    spec = syn.CONFIGS[args.workload]
+    V = args.views_per_gpu
+    global_views = V * world
+    opt = OptimizationParams()
+
+    # ---- model replica (identical on every rank: CPU-seeded), per-rank views, synthetic ground truth ----------------
+    model = syn.make_model(spec, dev)
+    all_cams = ring_cameras(global_views, spec.W, spec.H, device=dev)  # camera 0 == the SURVEY front camera
+    cams = all_cams[rank::world][:V]
+    bg = syn.background(dev)
+    with torch.no_grad():
+        gt = syn.make_model(spec, dev)
+        g = torch.Generator(device="cpu").manual_seed(202)
+        gt._xyz.add_((0.002 * torch.randn(gt._xyz.shape, generator=g)).to(dev))
+        gt._features_dc.add_((0.05 * torch.randn(gt._features_dc.shape, generator=g)).to(dev))
+        make_ground_truth(gt, cams, bg)
+        del gt
+    model.training_setup(opt)
+    bucket = FlatGradBucket(model.leaf_parameters())
+    torch.cuda.synchronize()
+
+    # ---- HIP events around the two render kernels, recorded by the library on the launch stream -------------------
+    K, Wm = args.steps, args.warmup
+    n_ev = K * V
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
+    for quad in evs:
+        for e in quad:
+            e.record()  # materialise the hipEvent_t
+    torch.cuda.synchronize()
+
+    ev_i = [0]
+    from gaussianhaircut_amd import trainer as _tr
+    from gaussianhaircut_amd.gaussian_renderer import render as _render
+
+    def render_with_events(cam, pc, pipe, bgc, scaling_modifier=1.0):
+        q = evs[ev_i[0] % n_ev]
+        ev_i[0] += 1
+        L.ghr_set_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in q])
+        return _render(cam, pc, pipe, bgc, scaling_modifier)
+
+    def step(it, timed):
+        _tr.render = render_with_events if timed else _render
+        if not timed:
+            L.ghr_set_profile_events(None, None, None, None)
+        return training_step(model, cams, bg, opt, it, bucket=bucket, global_views=global_views)
+
+    for i in range(Wm):
+        step(i + 1, False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(Wm + i + 1, True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    L.ghr_set_profile_events(None, None, None, None)
+    _tr.render = _render
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    stats = dict(dgr.LAST_STATS)
+    P_model = spec.P
+    ms_per_step = 1e3 * elapsed / K
+    value = world * V * P_model / (elapsed / K)
+
+    fwd_ms = [q[0].elapsed_time(q[1]) for q in evs]
+    bwd_ms = [q[2].elapsed_time(q[3]) for q in evs]
+    fwd_avg, bwd_avg = sum(fwd_ms) / len(fwd_ms), sum(bwd_ms) / len(bwd_ms)
+
+    R, Pv = stats.get("num_rendered", 0), stats.get("P", 0)
+    N_pix = spec.W * spec.H
+    T_tiles = ((spec.W + 15) // 16) * ((spec.H + 15) // 16)
+    # K8's share of B_bwd = per instance 68 B read + 64 B gradient payload, per pixel 48 B, ranges 8 B/tile
+    bytes_bwd_kernel = 132 * R + 48 * N_pix + 8 * T_tiles
+    bytes_fwd_kernel = 68 * R + 48 * N_pix + 8 * T_tiles
+    achieved = bytes_bwd_kernel / (bwd_avg * 1e-3) / 1e9 if bwd_avg > 0 else 0.0
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_k_render_bwd.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "k_render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
+                "note": "VALU/LDS-bound gradient walk; algorithmic bytes per SURVEY.md 8(d)"}
+
+    out = {
+        "metric": "gaussians_rasterized_per_sec_fwd_bwd_1080p", "value": round(value, 1), "unit": "Gaussians/s",
+        "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d Gaussians (%s), %d view(s)/GPU/step at %dx%d, render+loss+backward%s+Adam" %
+                   (spec.name, P_model, spec.kind, V, spec.W, spec.H, "+RCCL grad all-reduce" if world > 1 else ""),
+                   "views_per_gpu": V, "global_views": global_views, "parallelism": "view-dp%d" % world,
+                   "P_rasterized_per_view": Pv, "num_rendered_per_view": R},
+        "grad_steps_per_sec": round(K / elapsed, 3),
+        "kernels_ms": {"k_render_fwd": round(fwd_avg, 4), "k_render_bwd": round(bwd_avg, 4),
+                       "k_render_fwd_hbm_frac": round(bytes_fwd_kernel / (fwd_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+                       if fwd_avg > 0 else None},
+        "roofline": roofline,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_op_only:
+            out["op_only"] = op_only_bench(dev)
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(spec, model, cams[0])
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def op_only_bench(dev, cfg="cfg2", iters=20, warm=5):
+    """Rasterizer op alone (C ABI, no autograd): BASELINE.json configs[1], Gaussians / (t_fwd + t_bwd)."""
+    from gaussianhaircut_amd.utils import synthetic as syn
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS[cfg]
+    ri = to_dev(syn.raster_inputs(spec), dev)
+    dL = syn.grad_image(spec, 101, dev) * (spec.H * spec.W)
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf, tb = [], []
+    for i in range(iters + warm):
+        e[0].record()
+        run = GpuRun(ri, "A", debug=False)
+        e[1].record()
+        run.backward(dL)
+        e[2].record()
+        torch.cuda.synchronize()
+        if i >= warm:
+            tf.append(e[0].elapsed_time(e[1]))
+            tb.append(e[1].elapsed_time(e[2]))
+    tf.sort(), tb.sort()
+    mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
+    return {"workload": spec.name, "P": ri["P"], "num_rendered": run.R, "fwd_ms": round(mf, 4), "bwd_ms": round(mb, 4),
+            "gaussians_per_sec_fwd_bwd": round(ri["P"] / ((mf + mb) * 1e-3), 1),
+            "note": "includes workspace allocation + the host sync on num_rendered in forward"}
+
+
+def cpu_baseline(spec, model, cam):
+    """The oracle (CPU restatement of the reference's CUDA semantics; 'port') on one view of the same workload."""
+    import oracle
+    from gaussianhaircut_amd.utils import synthetic as syn
+    from tests import helpers as hp
+    cpu_model_inputs = syn.raster_inputs(spec, "cpu")
+    dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
+    t0 = time.perf_counter()
+    out_o, radii_o, st = hp.oracle_forward(oracle, cpu_model_inputs, "A")
+    t1 = time.perf_counter()
+    hp.oracle_backward(oracle, st, cpu_model_inputs, dL, "A")
+    t2 = time.perf_counter()
+    return {"value": round(spec.P / (t2 - t0), 1), "unit": "Gaussians/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "1 view of %s, rasterizer fwd (%.2f s) + bwd (%.2f s) only; projection/loss/Adam not included" %
+                      (spec.name, t1 - t0, t2 - t1)}
+
+
+if __name__ == "__main__":
+    main()

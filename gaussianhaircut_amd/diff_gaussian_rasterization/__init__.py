@@ -28,6 +28,9 @@ except ImportError:  # imported as top-level `diff_gaussian_rasterization` (refe
 
 NUM_CHANNELS = _lib.NUM_CHANNELS
 
+# last forward's sizes (read by bench.py for the roofline's algorithmic byte count)
+LAST_STATS = {"num_rendered": 0, "P": 0}
+
 # pinned host word per device that receives num_rendered from stage 1
 _pinned_R = {}
 
@@ -160,6 +163,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                     print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
                 raise ex
 
+        LAST_STATS["num_rendered"], LAST_STATS["P"] = num_rendered, P
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.mark_non_differentiable(radii)

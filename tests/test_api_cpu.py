@@ -1,0 +1,137 @@
+"""Host logic that needs no GPU: the C ABI loads and exports every declared symbol, argument validation mirrors the
+reference's messages, the product path refuses CPU tensors (no fallback), render() plumbing (with the TEST-ONLY oracle
+backend patched in), Adam groups, lr schedule."""
+import ctypes
+import math
+import re
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianhaircut_amd import _lib
+from gaussianhaircut_amd.diff_gaussian_rasterization import (GaussianRasterizationSettings, GaussianRasterizer)
+from gaussianhaircut_amd.gaussian_renderer import render
+from gaussianhaircut_amd.scene.gaussian_model import GaussianModel, OptimizationParams
+from gaussianhaircut_amd.trainer import PIPE, training_step, make_ground_truth
+from gaussianhaircut_amd.utils import synthetic as syn
+from tests.oracle_backend import oracle_rasterizer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "ghr.h")).read()
+    declared = set(re.findall(r"\b(ghr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"ghr_view_args", "ghr_ws_view"}
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.ghr_abi_version() == 1
+
+
+def test_workspace_sizes_and_error_codes():
+    g, i = _lib.forward_sizes(1000, 1920, 1080, False)
+    gb, _ = _lib.forward_sizes(1000, 1920, 1080, True)
+    assert g >= 1000 * (64 + 4 + 8) and gb >= g + 1000 * 24
+    assert i >= 1920 * 1080 * 8 + 8160 * 8
+    assert _lib.binning_size(1000) >= 12000 and _lib.binning_size(0) > 0
+    L = _lib.lib()
+    a = _lib.ViewArgs()
+    a.P, a.W, a.H, a.C = 4, 64, 64, 3
+    assert L.ghr_forward_stage1(None, ctypes.byref(a), None, None, None, None) == _lib.GHR_E_INVALID
+    assert b"GHR_NUM_CHANNELS" in L.ghr_last_error()
+    a.C = 10
+    assert L.ghr_forward_stage1(None, ctypes.byref(a), None, None, None, None) == _lib.GHR_E_NOCOLORS
+    assert L.ghr_last_error() == b"For non-RGB, provide precomputed Gaussian colors!"
+    with pytest.raises(RuntimeError, match="provide precomputed Gaussian colors"):
+        _lib.check(_lib.GHR_E_NOCOLORS)
+
+
+def _settings(ri):
+    return GaussianRasterizationSettings(ri["H"], ri["W"], ri["tanfovx"], ri["tanfovy"], ri["bg"], 1.0,
+                                         ri["viewmatrix"], ri["projmatrix"], 3, ri["campos"], True, False)
+
+
+def test_argument_validation_messages_and_no_cpu_fallback():
+    ri = syn.raster_inputs(syn.CONFIGS["tiny"])
+    r = GaussianRasterizer(_settings(ri))
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(ri["means3D"], ri["means2D"], ri["opacities"], scales=ri["scales"], rotations=ri["rotations"])
+    with pytest.raises(Exception, match="Please provide excatly one of either SHs or precomputed colors!"):
+        r(ri["means3D"], ri["means2D"], ri["opacities"], shs=torch.zeros(1), colors_precomp=ri["colors"],
+          scales=ri["scales"], rotations=ri["rotations"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(ri["means3D"], ri["means2D"], ri["opacities"], colors_precomp=ri["colors"], scales=ri["scales"])
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair or precomputed 3D covariance"):
+        r(ri["means3D"], ri["means2D"], ri["opacities"], colors_precomp=ri["colors"], scales=ri["scales"],
+          rotations=ri["rotations"], cov3D_precomp=ri["cov3D"])
+    # the product path must fail loudly on CPU tensors: there is no CPU / eager fallback
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        r(ri["means3D"], ri["means2D"], ri["opacities"], colors_precomp=ri["colors"], cov3D_precomp=ri["cov3D"],
+          conic_precomp=ri["conic"])
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        r.markVisible(ri["means3D"])
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gaussianhaircut_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "ghr_oracle" not in src, f
+
+
+def test_render_dict_and_gradients_with_oracle_backend():
+    spec = syn.CONFIGS["tiny"]
+    model, cam = syn.make_model(spec), syn.make_view(spec)
+    with oracle_rasterizer():
+        pkg = render(cam, model, PIPE, syn.background())
+        assert set(pkg) == {"render", "mask", "orient_angle", "orient_conf", "viewspace_points", "visibility_filter",
+                            "radii"}
+        assert pkg["render"].shape == (3, spec.H, spec.W) and pkg["mask"].shape == (2, spec.H, spec.W)
+        assert pkg["orient_angle"].shape == (1, spec.H, spec.W) and pkg["orient_conf"].shape == (1, spec.H, spec.W)
+        assert pkg["radii"].shape == (spec.P,) and pkg["radii"].dtype == torch.int32
+        assert (pkg["visibility_filter"] == (pkg["radii"] > 0)).all()
+        assert ((pkg["orient_angle"] >= 0) & (pkg["orient_angle"] <= 1)).all()
+        (pkg["render"].sum() + pkg["mask"].sum() + pkg["orient_conf"].sum()).backward()
+    for p in model.leaf_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert model._xyz.grad.abs().sum() > 0 and model._scaling.grad.abs().sum() > 0
+    assert pkg["viewspace_points"].grad is not None  # densification signal (gaussian_renderer/__init__.py:30-34)
+
+
+def test_adam_groups_and_lr_schedule():
+    spec = syn.CONFIGS["tiny"]
+    model = syn.make_model(spec)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    names = [g["name"] for g in model.optimizer.param_groups]
+    assert names == ["xyz", "f_dc", "f_rest", "opacity", "label", "scaling", "rotation", "orient_conf"]
+    assert model.optimizer.defaults["eps"] == 1e-15
+    lrs = {g["name"]: g["lr"] for g in model.optimizer.param_groups}
+    assert lrs["f_rest"] == pytest.approx(opt.feature_lr / 20) and lrs["opacity"] == 0.05
+    n_float = sum(p.numel() for g in model.optimizer.param_groups for p in g["params"]) // spec.P
+    assert n_float == 3 + 3 + 45 + 1 + 1 + 3 + 4 + 1  # 61 fp32 per Gaussian
+    lr0 = model.update_learning_rate(0)
+    lr_end = model.update_learning_rate(opt.position_lr_max_steps)
+    assert lr0 == pytest.approx(opt.position_lr_init) and lr_end == pytest.approx(opt.position_lr_final)
+    mid = model.update_learning_rate(opt.position_lr_max_steps // 2)
+    assert mid == pytest.approx(math.sqrt(opt.position_lr_init * opt.position_lr_final), rel=1e-6)
+
+
+def test_training_step_decreases_loss_with_oracle_backend():
+    spec = syn.CONFIGS["tiny"]
+    model, cam = syn.make_model(spec), syn.make_view(spec)
+    opt = OptimizationParams()
+    with oracle_rasterizer():
+        gt = syn.make_model(spec)
+        with torch.no_grad():
+            gt._features_dc.add_(0.3)
+        make_ground_truth(gt, [cam], syn.background())
+        model.training_setup(opt)
+        losses = [float(training_step(model, [cam], syn.background(), opt, it + 1)) for it in range(6)]
+    assert losses[-1] < losses[0]
