@@ -18,7 +18,8 @@
 namespace {
 
 thread_local char g_err[512] = "";
-thread_local hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
+// Process-wide (NOT thread_local): torch's autograd engine calls ghr_backward from its own worker thread.
+hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
 
 int fail(int code, const char* fmt, const char* detail = "")
 {

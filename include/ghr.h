@@ -103,8 +103,8 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present);
 
-/* Profiling hook used by bench.py: raw hipEvent_t handles (as void*) that this thread's NEXT calls record on the
- * caller's stream immediately before / after the compositing kernel (ghr_forward_stage2: k_render_fwd) and the
+/* Profiling hook used by bench.py: raw hipEvent_t handles (as void*) that the NEXT calls (from any thread --
+ * autograd runs backward on a worker thread) record on the caller's stream immediately before / after the compositing kernel (ghr_forward_stage2: k_render_fwd) and the
  * gradient-walk kernel (ghr_backward: k_render_bwd).  NULL disables a pair.  Sticky until changed. */
 int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop);
 

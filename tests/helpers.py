@@ -92,7 +92,18 @@ class _ViewArgs(ctypes.Structure):
 class HostSim:
     """CPU execution of the product's host+device functions (tests/hostsim/ghr_hostsim.cpp)."""
 
+    @staticmethod
+    def build():
+        """Compile only (no dlopen): __graft_entry__.build() must not load a second HIP-linked library before torch."""
+        return HostSim._build()
+
     def __init__(self):
+        import torch  # noqa: F401  -- load torch's HIP runtime first so every HIP-linked .so shares ONE runtime
+        so = HostSim._build()
+        self._load(so)
+
+    @staticmethod
+    def _build():
         src = os.path.join(ROOT, "tests", "hostsim", "ghr_hostsim.cpp")
         out_dir = os.path.join(ROOT, "tests", "hostsim", "_build")
         so = os.path.join(out_dir, "libghr_hostsim.so")
@@ -103,6 +114,9 @@ class HostSim:
             hipcc = "/opt/rocm/bin/hipcc"
             subprocess.run([hipcc, "--offload-arch=gfx950", "-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off",
                             "-fPIC", "-shared", "-o", so, src], check=True)
+        return so
+
+    def _load(self, so):
         L = ctypes.CDLL(so)
         L.ghrsim_forward.restype = ctypes.c_void_p
         L.ghrsim_num_rendered.restype = ctypes.c_uint32
