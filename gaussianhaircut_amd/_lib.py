@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libghr_hip.so")
 SOURCES = ["ghr_capi.hip"]
 HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h",
-           "ghr_geom_bwd.h"]
+           "ghr_geom_bwd.h", "ghr_project.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
                "-shared"]
 
@@ -76,6 +76,16 @@ class ViewArgs(ctypes.Structure):
     ]
 
 
+class ModelArgs(ctypes.Structure):
+    """``ghr_model_args`` (include/ghr.h)."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("P", "W", "H", "sh_degree", "sh_coeffs")] + \
+               [(n, ctypes.c_void_p) for n in ("xyz", "log_scales", "rotations", "opacity_logit", "label_logit",
+                                               "orient_conf_log", "features_dc", "features_rest", "viewmatrix",
+                                               "projmatrix", "campos", "background")] + \
+               [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "conic_eps")] + \
+               [("debug", ctypes.c_int32)]
+
+
 class WsView(ctypes.Structure):
     """``ghr_ws_view`` (include/ghr.h) -- test introspection."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "cov3D", "final_T", "n_contrib",
@@ -84,7 +94,8 @@ class WsView(ctypes.Structure):
 
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
-           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events"]
+           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_model_forward_stage1",
+           "ghr_model_backward"]
 
 _lib = None
 
@@ -109,6 +120,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
+    L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
+    L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

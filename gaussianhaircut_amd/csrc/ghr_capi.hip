@@ -12,6 +12,7 @@
 #include "ghr_device.h"
 #include "ghr_geom_bwd.h"
 #include "ghr_preprocess.h"
+#include "ghr_project.h"
 #include "ghr_render_bwd.h"
 #include "ghr_render_fwd.h"
 
@@ -89,19 +90,25 @@ size_t carve_bin(char* base, size_t R, Bin* b)
 }
 inline char* align_base(const void* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
 
-int check_view(const ghr_view_args* a)
+int check_dims(const ghr_view_args* a)
 {
     if (!a) return fail(GHR_E_INVALID, "ghr_view_args is NULL");
     if (a->P < 0 || a->W <= 0 || a->H <= 0) return fail(GHR_E_INVALID, "bad P/W/H");
     if (a->C != GHR_NUM_CHANNELS) return fail(GHR_E_INVALID, "C must equal GHR_NUM_CHANNELS (10)");
+    if ((a->W + GHR_TILE - 1) / GHR_TILE > 65535 || (a->H + GHR_TILE - 1) / GHR_TILE > 65535)
+        return fail(GHR_E_INVALID, "image too large for 16-bit tile coordinates");
+    return GHR_OK;
+}
+
+int check_view(const ghr_view_args* a)
+{
+    if (int rc = check_dims(a)) return rc;
     if (a->P == 0) return GHR_OK;
     if (!a->colors) return fail(GHR_E_NOCOLORS, "For non-RGB, provide precomputed Gaussian colors!");
     if (!a->means3D || !a->opacities || !a->background || !a->viewmatrix || !a->projmatrix)
         return fail(GHR_E_INVALID, "means3D/opacities/background/viewmatrix/projmatrix must be non-NULL");
     if (!a->conic_precomp && !a->cov3D_precomp && !(a->scales && a->rotations))
         return fail(GHR_E_INVALID, "kernel-geometry mode needs cov3D_precomp or scales+rotations");
-    if ((a->W + GHR_TILE - 1) / GHR_TILE > 65535 || (a->H + GHR_TILE - 1) / GHR_TILE > 65535)
-        return fail(GHR_E_INVALID, "image too large for 16-bit tile coordinates");
     return GHR_OK;
 }
 
@@ -173,8 +180,9 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
                        float* out_color)
 {
-    if (int rc = check_view(a)) return rc;
+    if (int rc = check_dims(a)) return rc;  // stage 2 only reads P, W, H, C, background (+ debug)
     if (!out_color) return fail(GHR_E_INVALID, "out_color is NULL");
+    if (a->P > 0 && !a->background) return fail(GHR_E_INVALID, "background is NULL");
     hipStream_t s = (hipStream_t)stream;
     const int gx = grid_x(a->W), gy = grid_x(a->H);
     const int T = gx * gy;
@@ -185,9 +193,9 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         return finish(s, a->debug);
     }
     if (!geom_ws || !img_ws || (R > 0 && !bin_ws)) return fail(GHR_E_INVALID, "workspace is NULL");
-    const bool mode_b = a->conic_precomp == nullptr;
+    // the cov3D plane (mode B) lies behind everything stage 2 touches, so the carve is mode-independent here
     Geom g; Img im; Bin b;
-    carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
+    carve_geom(align_base(geom_ws), (size_t)a->P, false, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
     if (R > 0) {
@@ -240,6 +248,91 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
     return finish(s, a->debug);
+}
+
+namespace {
+int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
+{
+    if (!m) return fail(GHR_E_INVALID, "ghr_model_args is NULL");
+    if (m->P < 0 || m->W <= 0 || m->H <= 0) return fail(GHR_E_INVALID, "bad P/W/H");
+    if (m->sh_degree < 0 || m->sh_degree > 3 || m->sh_coeffs < (m->sh_degree + 1) * (m->sh_degree + 1) ||
+        m->sh_coeffs > GHR_SH_MAX)
+        return fail(GHR_E_INVALID, "bad sh_degree / sh_coeffs");
+    if (m->P > 0 && (!m->xyz || !m->log_scales || !m->rotations || !m->opacity_logit || !m->label_logit ||
+                     !m->orient_conf_log || !m->features_dc || (m->sh_coeffs > 1 && !m->features_rest) ||
+                     !m->viewmatrix || !m->projmatrix || !m->campos || !m->background))
+        return fail(GHR_E_INVALID, "ghr_model_args: NULL parameter tensor");
+    a->P = m->P; a->W = m->W; a->H = m->H; a->gx = grid_x(m->W); a->gy = grid_x(m->H);
+    a->sh_degree = m->sh_degree; a->sh_coeffs = m->sh_coeffs;
+    a->xyz = m->xyz; a->log_scales = m->log_scales; a->rotations = m->rotations;
+    a->opacity_logit = m->opacity_logit; a->label_logit = m->label_logit; a->orient_conf_log = m->orient_conf_log;
+    a->features_dc = m->features_dc; a->features_rest = m->features_rest;
+    a->view = m->viewmatrix; a->proj = m->projmatrix; a->campos = m->campos;
+    a->scale_modifier = m->scale_modifier; a->tan_fovx = m->tan_fovx; a->tan_fovy = m->tan_fovy;
+    a->focal_y = m->H / (2.0f * m->tan_fovy);
+    a->focal_x = m->W / (2.0f * m->tan_fovx);
+    a->conic_eps = m->conic_eps;
+    a->rec = nullptr; a->depths = nullptr; a->rects = nullptr; a->radii = nullptr; a->means2D = nullptr;
+    a->tile_count = nullptr;
+    return GHR_OK;
+}
+}  // namespace
+
+int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_ws, void* img_ws, int32_t* radii,
+                             float* means2D_out, uint32_t* R_host)
+{
+    ghr::ModelArgs a;
+    if (int rc = fill_model(m, &a)) return rc;
+    if (!R_host) return fail(GHR_E_INVALID, "R_host is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if (a.P == 0) { *R_host = 0; return GHR_OK; }
+    if (!geom_ws || !img_ws || !radii) return fail(GHR_E_INVALID, "workspace/radii is NULL");
+    const int T = a.gx * a.gy;
+    Geom g; Img im;
+    carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
+    carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
+    a.tile_count = im.tile_count;
+    hipLaunchKernelGGL(ghr::k_project, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a);
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev);
+    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return finish(s, m->debug);
+}
+
+int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
+                       const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                       float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
+                       float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
+                       float* d_features_rest)
+{
+    ghr::ModelArgs a;
+    if (int rc = fill_model(m, &a)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (a.P == 0) return GHR_OK;
+    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || !grad_scratch || !d_means2D || !d_xyz ||
+        !d_log_scales || !d_rotations || !d_opacity_logit || !d_label_logit || !d_orient_conf_log || !d_features_dc ||
+        (a.sh_coeffs > 1 && !d_features_rest))
+        return fail(GHR_E_INVALID, "ghr_model_backward: NULL buffer");
+    const int T = a.gx * a.gy;
+    Geom g; Img im; Bin b;
+    carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
+    carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    GHR_HIP(hipMemsetAsync(grad_scratch, 0, sizeof(float) * GHR_GRAD_STRIDE * (size_t)a.P, s));
+    if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
+    if (R > 0)
+        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a.W, a.H, a.gx, (uint32_t)T,
+                           im.tile_start, b.point_list, g.rec, m->background, im.final_T, im.n_contrib, dL_dpix,
+                           grad_scratch);
+    if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
+    a.radii = const_cast<int*>(radii);
+    ghr::ModelGrads mg;
+    mg.gacc = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
+    mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
+    mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
+    hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a, mg);
+    return finish(s, m->debug);
 }
 
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

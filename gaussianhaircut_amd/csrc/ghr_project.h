@@ -1,0 +1,452 @@
+// ghr_project.h -- fused "model -> rasterizer state" kernel and its hand-derived backward.
+//
+// Replaces, for the free-Gaussian model, the ~60 small PyTorch kernels render() runs per view over all P rows
+// (measured on MI355X: 16 aten::bmm calls on P x 3 x 3 alone cost 68 ms of a 95 ms step at P = 500k):
+//   src/scene/gaussian_model.py:107-141   activations (exp / sigmoid / normalize)
+//   :230-315  get_covariance, get_covariance_2d, get_conic           :317-342  get_mean_2d, get_depths
+//   :344-393  get_direction_2d ("strand direction" channels)         :143-228  filter_points
+//   src/utils/sh_utils.py:57-112 eval_sh ; src/gaussian_renderer/__init__.py:58-83 colour assembly + mask gathers
+// and, in backward, everything autograd would do for that graph -- including the strand-direction term
+// d(dir2D)/d(rotation, scaling, xyz) and the SH view-direction term -- in ONE pass over the Gaussians.
+//
+// Forward = K1 with the conic / features computed in-register from the raw parameters (same cull, radius, rect and
+// packed record as k_preprocess, so binning / render kernels are unchanged).  The arithmetic follows the PYTHON
+// pipeline (that is what the reference actually runs; its in-kernel geometry is dormant):
+//   conic = (c, -b, a) / (det + eps)   with eps = 1e-12 (gaussian_model.py:312), then K1's own
+//   cov = conic^-1 for the radius (forward.cu:242-257), so radii match the reference's mode-A chain.
+// Backward differentiates exactly that pipeline (torch semantics: clamp() passes gradient only inside the range,
+// normalize() is differentiated, clamp_min(sh + 0.5, 0) masks), NOT the dormant CUDA K9/K10.
+#pragma once
+#include "ghr_preprocess.h"
+
+namespace ghr {
+
+#define GHR_SH_MAX 16  // (3 + 1)^2 coefficients per colour channel
+
+struct ModelArgs {
+    int P, W, H, gx, gy;
+    int sh_degree;   // active degree (0..3)
+    int sh_coeffs;   // K = (max_degree + 1)^2 coefficients stored per channel (<= 16)
+    const float* xyz;             // [P,3]
+    const float* log_scales;      // [P,3]  scaling = exp(.)                     gaussian_model.py:108-109
+    const float* rotations;       // [P,4]  raw quaternion (r,x,y,z), normalised here (general_utils.py:79-83)
+    const float* opacity_logit;   // [P]    sigmoid
+    const float* label_logit;     // [P]    sigmoid
+    const float* orient_conf_log; // [P]    exp
+    const float* features_dc;     // [P,1,3]
+    const float* features_rest;   // [P,K-1,3]
+    const float* view;            // [16] world_view_transform
+    const float* proj;            // [16] full_proj_transform
+    const float* campos;          // [3]
+    float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y, conic_eps;
+    // forward outputs
+    f4* rec;
+    float* depths;
+    uint2* rects;
+    int* radii;
+    float* means2D;  // [P,3] NDC (viewspace_points values), may be null
+    uint32_t* tile_count;
+};
+
+struct ModelGrads {
+    const float* gacc;  // [P][16] packed gradients from k_render_bwd
+    float* d_means2D;   // [P,3]  dL/d(NDC mean) (densification signal), z = 0
+    float* d_xyz;       // [P,3]
+    float* d_log_scales;// [P,3]
+    float* d_rotations; // [P,4]
+    float* d_opacity_logit;   // [P]
+    float* d_label_logit;     // [P]
+    float* d_orient_conf_log; // [P]
+    float* d_features_dc;     // [P,1,3]
+    float* d_features_rest;   // [P,K-1,3]
+};
+
+GHR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// SH basis values (sh_utils.py:57-112 / auxiliary.h:21-39) for a unit direction.
+GHR_HD void sh_basis(int deg, float x, float y, float z, float* b)
+{
+    b[0] = 0.28209479177387814f;
+    if (deg > 0) {
+        const float C1 = 0.4886025119029199f;
+        b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = 1.0925484305920792f * xy;
+            b[5] = -1.0925484305920792f * yz;
+            b[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+            b[7] = -1.0925484305920792f * xz;
+            b[8] = 0.5462742152960396f * (xx - yy);
+            if (deg > 2) {
+                b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+                b[10] = 2.890611442640554f * xy * z;
+                b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+                b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+                b[14] = 1.445305721320277f * z * (xx - yy);
+                b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+// d(basis_k)/d(x,y,z) (cf. backward.cu:58-122, written per basis function)
+GHR_HD void sh_basis_grad(int deg, float x, float y, float z, float* dx, float* dy, float* dz)
+{
+    dx[0] = dy[0] = dz[0] = 0.f;
+    if (deg > 0) {
+        const float C1 = 0.4886025119029199f;
+        dx[1] = 0; dy[1] = -C1; dz[1] = 0;
+        dx[2] = 0; dy[2] = 0; dz[2] = C1;
+        dx[3] = -C1; dy[3] = 0; dz[3] = 0;
+        if (deg > 1) {
+            const float c0 = 1.0925484305920792f, c2 = 0.31539156525252005f, c4 = 0.5462742152960396f;
+            dx[4] = c0 * y; dy[4] = c0 * x; dz[4] = 0;
+            dx[5] = 0; dy[5] = -c0 * z; dz[5] = -c0 * y;
+            dx[6] = -2.f * c2 * x; dy[6] = -2.f * c2 * y; dz[6] = 4.f * c2 * z;
+            dx[7] = -c0 * z; dy[7] = 0; dz[7] = -c0 * x;
+            dx[8] = 2.f * c4 * x; dy[8] = -2.f * c4 * y; dz[8] = 0;
+            if (deg > 2) {
+                const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                const float k0 = -0.5900435899266435f, k1 = 2.890611442640554f, k2 = -0.4570457994644658f,
+                            k3 = 0.3731763325901154f, k5 = 1.445305721320277f;
+                dx[9] = k0 * 6.f * xy; dy[9] = k0 * 3.f * (xx - yy); dz[9] = 0;
+                dx[10] = k1 * yz; dy[10] = k1 * xz; dz[10] = k1 * xy;
+                dx[11] = k2 * -2.f * xy; dy[11] = k2 * (4.f * zz - xx - 3.f * yy); dz[11] = k2 * 8.f * yz;
+                dx[12] = k3 * -6.f * xz; dy[12] = k3 * -6.f * yz; dz[12] = k3 * (6.f * zz - 3.f * xx - 3.f * yy);
+                dx[13] = k2 * (4.f * zz - 3.f * xx - yy); dy[13] = k2 * -2.f * xy; dz[13] = k2 * 8.f * xz;
+                dx[14] = k5 * 2.f * xz; dy[14] = k5 * -2.f * yz; dz[14] = k5 * (xx - yy);
+                dx[15] = k0 * 3.f * (xx - yy); dy[15] = k0 * -6.f * xy; dz[15] = 0;
+            }
+        }
+    }
+}
+
+// Everything both passes need, recomputed from the raw parameters (cheaper than storing it: 61 floats in, ~300 flop).
+struct ProjCtx {
+    float s[3], s0[3];    // scaling * modifier, scaling
+    float qn[4], qlen;    // normalised quaternion, |q|
+    float ax[3][3];       // ax[i] = i-th principal axis = row i of the reference's R (general_utils.py:104-112)
+    float t[3];           // view-space mean (unclamped)
+    float clx, cly;       // clamp(tx/tz), clamp(ty/tz)
+    bool inx, iny;        // inside the 1.3*tanfov clamp range
+    float u[3], v[3];     // T[:,0], T[:,1] with T = W @ J (gaussian_model.py:279-290)
+    float p[3], r[3];     // p_i = ax_i . u, r_i = ax_i . v
+    float a, b, c, det, k;  // cov2D (with +0.3), det, k = 1/(det+eps)
+    int jmax;             // longest axis (gaussian_model.py:384-388)
+    float Wc[3][3];       // Wc[c] = column c of view[:3,:3]
+    float j00, j20, j11, j21, txp, typ;
+};
+
+GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
+{
+    const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c.s0[i] = expf(a.log_scales[3 * idx + i]);
+        c.s[i] = c.s0[i] * a.scale_modifier;
+    }
+    const float q0 = a.rotations[4 * idx], q1 = a.rotations[4 * idx + 1], q2 = a.rotations[4 * idx + 2],
+                q3 = a.rotations[4 * idx + 3];
+    c.qlen = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+    const float il = 1.0f / c.qlen;
+    const float w = q0 * il, x = q1 * il, y = q2 * il, z = q3 * il;
+    c.qn[0] = w; c.qn[1] = x; c.qn[2] = y; c.qn[3] = z;
+    c.ax[0][0] = 1 - 2 * (y * y + z * z); c.ax[0][1] = 2 * (x * y + w * z); c.ax[0][2] = 2 * (x * z - w * y);
+    c.ax[1][0] = 2 * (x * y - w * z); c.ax[1][1] = 1 - 2 * (x * x + z * z); c.ax[1][2] = 2 * (y * z + w * x);
+    c.ax[2][0] = 2 * (x * z + w * y); c.ax[2][1] = 2 * (y * z - w * x); c.ax[2][2] = 1 - 2 * (x * x + y * y);
+    const float* V = a.view;  // V[4*row + col]; t = xyz @ V[:3,:3] + V[3,:3]
+#pragma unroll
+    for (int col = 0; col < 3; col++) {
+        c.t[col] = mx * V[col] + my * V[4 + col] + mz * V[8 + col] + V[12 + col];
+        c.Wc[col][0] = V[col]; c.Wc[col][1] = V[4 + col]; c.Wc[col][2] = V[8 + col];
+    }
+    const float tz = c.t[2];
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = c.t[0] / tz, tytz = c.t[1] / tz;
+    c.inx = !(txtz < -limx || txtz > limx);
+    c.iny = !(tytz < -limy || tytz > limy);
+    c.clx = fminf(limx, fmaxf(-limx, txtz));
+    c.cly = fminf(limy, fmaxf(-limy, tytz));
+    c.txp = c.clx * tz;
+    c.typ = c.cly * tz;
+    c.j00 = a.focal_x / tz;
+    c.j11 = a.focal_y / tz;
+    c.j20 = -(a.focal_x * c.txp) / (tz * tz);
+    c.j21 = -(a.focal_y * c.typ) / (tz * tz);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c.u[i] = c.Wc[0][i] * c.j00 + c.Wc[2][i] * c.j20;
+        c.v[i] = c.Wc[1][i] * c.j11 + c.Wc[2][i] * c.j21;
+    }
+    float sa = 0.f, sb = 0.f, sc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        c.p[i] = c.ax[i][0] * c.u[0] + c.ax[i][1] * c.u[1] + c.ax[i][2] * c.u[2];
+        c.r[i] = c.ax[i][0] * c.v[0] + c.ax[i][1] * c.v[1] + c.ax[i][2] * c.v[2];
+        const float s2 = c.s[i] * c.s[i];
+        sa += s2 * c.p[i] * c.p[i];
+        sb += s2 * c.p[i] * c.r[i];
+        sc += s2 * c.r[i] * c.r[i];
+    }
+    c.a = sa + 0.3f;
+    c.b = sb;
+    c.c = sc + 0.3f;
+    c.det = c.a * c.c - c.b * c.b;
+    c.k = 1.0f / (c.det + a.conic_eps);
+    c.jmax = 0;  // first maximum == argsort(descending)[0] up to ties
+    if (c.s0[1] > c.s0[c.jmax]) c.jmax = 1;
+    if (c.s0[2] > c.s0[c.jmax]) c.jmax = 2;
+}
+
+GHR_HD float sh_coeff(const ModelArgs& a, int idx, int k, int ch)
+{
+    return k == 0 ? a.features_dc[3 * (size_t)idx + ch]
+                  : a.features_rest[((size_t)idx * (a.sh_coeffs - 1) + (k - 1)) * 3 + ch];
+}
+
+// Forward for one Gaussian.  Returns false when culled.
+GHR_HD bool project_one(const ModelArgs& a, int idx, int& x0, int& y0, int& x1, int& y1)
+{
+    a.radii[idx] = 0;
+    a.rects[idx] = uint2{0u, 0u};
+    ProjCtx c;
+    proj_setup(a, idx, c);
+    const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+
+    // get_mean_2d (gaussian_model.py:332-335); proj is used row-vector style: hom = xyz @ P[:3,:] + P[3,:]
+    const float* pm = a.proj;
+    const float hx = mx * pm[0] + my * pm[4] + mz * pm[8] + pm[12];
+    const float hy = mx * pm[1] + my * pm[5] + mz * pm[9] + pm[13];
+    const float hz = mx * pm[2] + my * pm[6] + mz * pm[10] + pm[14];
+    const float hw = mx * pm[3] + my * pm[7] + mz * pm[11] + pm[15];
+    const float p_w = 1.0f / (hw + 0.0000001f);
+    const float ndcx = hx * p_w, ndcy = hy * p_w;
+    if (a.means2D) {
+        a.means2D[3 * idx] = ndcx;
+        a.means2D[3 * idx + 1] = ndcy;
+        a.means2D[3 * idx + 2] = hz * p_w;
+    }
+
+    // filter_points (gaussian_model.py:166-172) == K1's cull (auxiliary.h:154)
+    if (!(c.t[2] > 0.2f)) return false;
+    if (c.det == 0.0f) return false;
+    // get_conic (gaussian_model.py:311-313)
+    const float cx = c.c * c.k, cy = -c.b * c.k, cz = c.a * c.k;
+    // K1 mode A from here (forward.cu:242-262)
+    const float det_inv = (cx * cz - cy * cy);
+    if (det_inv == 0.0f) return false;
+    const float det = 1.f / det_inv;
+    const float cva = cz * det, cvc = cx * det;
+    const float mid = 0.5f * (cva + cvc);
+    const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(mid + sq, mid - sq)));
+    const float pixx = ndc2pix(ndcx, a.W), pixy = ndc2pix(ndcy, a.H);
+    tile_rect(pixx, pixy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return false;
+
+    // colours (gaussian_renderer/__init__.py:58-74)
+    const float dxv = mx - a.campos[0], dyv = my - a.campos[1], dzv = mz - a.campos[2];
+    const float dl = 1.0f / sqrtf(dxv * dxv + dyv * dyv + dzv * dzv);
+    float basis[GHR_SH_MAX];
+    sh_basis(a.sh_degree, dxv * dl, dyv * dl, dzv * dl, basis);
+    const int nk = (a.sh_degree + 1) * (a.sh_degree + 1);
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float acc = 0.f;
+        for (int k = 0; k < nk; k++) acc += basis[k] * sh_coeff(a, idx, k, ch);
+        rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
+    }
+    const float label = sigmoidf_(a.label_logit[idx]);
+    const float conf = expf(a.orient_conf_log[idx]);
+    const float opac = sigmoidf_(a.opacity_logit[idx]);
+    const float sj = c.s0[c.jmax];
+    const float d2x = sj * c.p[c.jmax], d2y = sj * c.r[c.jmax];
+
+    f4* r = a.rec + 4 * (size_t)idx;
+    r[0] = f4{pixx, pixy, cx, cy};
+    r[1] = f4{cz, opac, rgb[0], rgb[1]};
+    r[2] = f4{rgb[2], label, 1.0f, d2x};
+    r[3] = f4{d2y, 0.0f, conf, c.t[2]};
+    a.depths[idx] = c.t[2];
+    a.radii[idx] = (int)my_radius;
+    a.rects[idx] = uint2{(uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16)};
+    return true;
+}
+
+// Backward for one Gaussian: packed rasterizer gradients -> raw-parameter gradients.  Writes every output element.
+GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx)
+{
+    const float* ga = g.gacc + 16 * (size_t)idx;
+    const int K = a.sh_coeffs;
+    float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
+    float dlo = 0, dll = 0, dlc = 0;
+    float dsh[GHR_SH_MAX][3];
+#pragma unroll
+    for (int k = 0; k < GHR_SH_MAX; k++) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
+    const float gmx = ga[0], gmy = ga[1];
+    g.d_means2D[3 * idx] = gmx;
+    g.d_means2D[3 * idx + 1] = gmy;
+    g.d_means2D[3 * idx + 2] = 0.f;
+
+    if (a.radii[idx] > 0) {
+        ProjCtx c;
+        proj_setup(a, idx, c);
+        const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+        const float gA = ga[2], gB = 2.0f * ga[3], gC = ga[4];  // wrapper's [xx, 2*xy, yy] restack (__init__.py:149-153)
+        const float gop = ga[5];
+        const float* gc = ga + 6;  // colours: rgb 0-2, label 3, one 4, dir2D 5-7, conf 8, depth 9
+
+        // ---- activations
+        const float o = sigmoidf_(a.opacity_logit[idx]);
+        dlo = gop * o * (1.f - o);
+        const float l = sigmoidf_(a.label_logit[idx]);
+        dll = gc[3] * l * (1.f - l);
+        dlc = gc[8] * expf(a.orient_conf_log[idx]);
+
+        // ---- conic = (c, -b, a) * k, k = 1/(det + eps)
+        const float S = gA * c.c - gB * c.b + gC * c.a;
+        const float k2S = c.k * c.k * S;
+        const float La = gC * c.k - k2S * c.c;
+        const float Lc = gA * c.k - k2S * c.a;
+        const float Lb = -gB * c.k + 2.f * k2S * c.b;
+
+        // ---- a,b,c = sum_i s_i^2 {p_i^2, p_i r_i, r_i^2};  dir2D = s0_j (p_j, r_j)
+        float Lp[3], Lr[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float s2 = c.s[i] * c.s[i];
+            Lp[i] = s2 * (2.f * c.p[i] * La + c.r[i] * Lb);
+            Lr[i] = s2 * (2.f * c.r[i] * Lc + c.p[i] * Lb);
+            // d/d(log s_i): s_i = exp(ls_i) * mod  =>  ds_i/dls_i = s_i
+            dls[i] = 2.f * s2 * (c.p[i] * c.p[i] * La + c.p[i] * c.r[i] * Lb + c.r[i] * c.r[i] * Lc);
+        }
+        {
+            const int j = c.jmax;
+            const float sj = c.s0[j];
+            Lp[j] += sj * gc[5];
+            Lr[j] += sj * gc[6];
+            dls[j] += sj * (c.p[j] * gc[5] + c.r[j] * gc[6]);
+        }
+        // ---- p_i = ax_i . u, r_i = ax_i . v
+        float G[3][3], Lu[3] = {0, 0, 0}, Lv[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                G[i][m] = Lp[i] * c.u[m] + Lr[i] * c.v[m];
+                Lu[m] += Lp[i] * c.ax[i][m];
+                Lv[m] += Lr[i] * c.ax[i][m];
+            }
+        // ---- rotation: rows of R(q_hat), then the normalisation q_hat = q/|q|
+        {
+            const float w = c.qn[0], x = c.qn[1], y = c.qn[2], z = c.qn[3];
+            float dn[4];
+            dn[0] = 2 * z * (G[0][1] - G[1][0]) + 2 * y * (G[2][0] - G[0][2]) + 2 * x * (G[1][2] - G[2][1]);
+            dn[1] = 2 * y * (G[0][1] + G[1][0]) + 2 * z * (G[0][2] + G[2][0]) + 2 * w * (G[1][2] - G[2][1]) -
+                    4 * x * (G[1][1] + G[2][2]);
+            dn[2] = 2 * x * (G[0][1] + G[1][0]) + 2 * w * (G[2][0] - G[0][2]) + 2 * z * (G[1][2] + G[2][1]) -
+                    4 * y * (G[0][0] + G[2][2]);
+            dn[3] = 2 * w * (G[0][1] - G[1][0]) + 2 * x * (G[0][2] + G[2][0]) + 2 * y * (G[1][2] + G[2][1]) -
+                    4 * z * (G[0][0] + G[1][1]);
+            const float dotp = dn[0] * w + dn[1] * x + dn[2] * y + dn[3] * z;
+            const float il = 1.0f / c.qlen;
+#pragma unroll
+            for (int m = 0; m < 4; m++) dq[m] = (dn[m] - c.qn[m] * dotp) * il;
+        }
+        // ---- u, v -> Jacobian entries -> view-space mean t
+        float Lt[3] = {0, 0, 0};
+        {
+            const float Lj00 = Lu[0] * c.Wc[0][0] + Lu[1] * c.Wc[0][1] + Lu[2] * c.Wc[0][2];
+            const float Lj20 = Lu[0] * c.Wc[2][0] + Lu[1] * c.Wc[2][1] + Lu[2] * c.Wc[2][2];
+            const float Lj11 = Lv[0] * c.Wc[1][0] + Lv[1] * c.Wc[1][1] + Lv[2] * c.Wc[1][2];
+            const float Lj21 = Lv[0] * c.Wc[2][0] + Lv[1] * c.Wc[2][1] + Lv[2] * c.Wc[2][2];
+            const float tz = c.t[2], itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
+            const float fx = a.focal_x, fy = a.focal_y;
+            const float Ltxp = Lj20 * (-fx * itz2), Ltyp = Lj21 * (-fy * itz2);
+            Lt[2] = Lj00 * (-fx * itz2) + Lj11 * (-fy * itz2) + Lj20 * (2.f * fx * c.txp * itz3) +
+                    Lj21 * (2.f * fy * c.typ * itz3);
+            // tx' = clamp(tx/tz) * tz (torch.clamp: gradient 1 inside the range, 0 outside)
+            Lt[0] = c.inx ? Ltxp : 0.f;
+            Lt[1] = c.iny ? Ltyp : 0.f;
+            Lt[2] += (c.inx ? 0.f : c.clx * Ltxp) + (c.iny ? 0.f : c.cly * Ltyp);
+            Lt[2] += gc[9];  // depth channel = view z
+        }
+        const float* V = a.view;
+#pragma unroll
+        for (int row = 0; row < 3; row++) dxyz[row] += V[4 * row] * Lt[0] + V[4 * row + 1] * Lt[1] + V[4 * row + 2] * Lt[2];
+
+        // ---- NDC mean
+        {
+            const float* pm = a.proj;
+            const float hx = mx * pm[0] + my * pm[4] + mz * pm[8] + pm[12];
+            const float hy = mx * pm[1] + my * pm[5] + mz * pm[9] + pm[13];
+            const float hw = mx * pm[3] + my * pm[7] + mz * pm[11] + pm[15];
+            const float w_ = 1.0f / (hw + 0.0000001f);
+            const float Lhx = gmx * w_, Lhy = gmy * w_, Lhw = -w_ * w_ * (gmx * hx + gmy * hy);
+#pragma unroll
+            for (int row = 0; row < 3; row++) dxyz[row] += pm[4 * row] * Lhx + pm[4 * row + 1] * Lhy + pm[4 * row + 3] * Lhw;
+        }
+        // ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz
+        {
+            const float dxv = mx - a.campos[0], dyv = my - a.campos[1], dzv = mz - a.campos[2];
+            const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
+            const float x = dxv * il, y = dyv * il, z = dzv * il;
+            float basis[GHR_SH_MAX], bx[GHR_SH_MAX], by[GHR_SH_MAX], bz[GHR_SH_MAX];
+            sh_basis(a.sh_degree, x, y, z, basis);
+            sh_basis_grad(a.sh_degree, x, y, z, bx, by, bz);
+            const int nk = (a.sh_degree + 1) * (a.sh_degree + 1);
+            float Ld[3] = {0, 0, 0};
+            for (int ch = 0; ch < 3; ch++) {
+                float acc = 0.f;
+                for (int k = 0; k < nk; k++) acc += basis[k] * sh_coeff(a, idx, k, ch);
+                const float gch = (acc + 0.5f >= 0.0f) ? gc[ch] : 0.f;  // clamp_min backward: grad where x >= min
+                for (int k = 0; k < nk; k++) {
+                    const float cf = sh_coeff(a, idx, k, ch);
+                    dsh[k][ch] = basis[k] * gch;
+                    Ld[0] += gch * bx[k] * cf;
+                    Ld[1] += gch * by[k] * cf;
+                    Ld[2] += gch * bz[k] * cf;
+                }
+            }
+            const float dotp = Ld[0] * x + Ld[1] * y + Ld[2] * z;  // d(normalize)
+            dxyz[0] += (Ld[0] - x * dotp) * il;
+            dxyz[1] += (Ld[1] - y * dotp) * il;
+            dxyz[2] += (Ld[2] - z * dotp) * il;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        g.d_xyz[3 * idx + i] = dxyz[i];
+        g.d_log_scales[3 * idx + i] = dls[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) g.d_rotations[4 * idx + i] = dq[i];
+    g.d_opacity_logit[idx] = dlo;
+    g.d_label_logit[idx] = dll;
+    g.d_orient_conf_log[idx] = dlc;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) g.d_features_dc[3 * (size_t)idx + ch] = dsh[0][ch];
+    for (int k = 1; k < K; k++)
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) g.d_features_rest[((size_t)idx * (K - 1) + (k - 1)) * 3 + ch] = dsh[k][ch];
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
+{
+    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    int x0, y0, x1, y1;
+    if (!project_one(a, idx, x0, y0, x1, y1)) return;
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+}
+
+__global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
+{
+    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    project_bwd_one(a, g, idx);
+}
+
+}  // namespace ghr

@@ -47,8 +47,21 @@ def _package(renders, screenspace_points, radii):
             "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
 
 
+def _use_fused(pc, pipe) -> bool:
+    """The fused HIP path covers exactly the free-Gaussian ``GaussianModel`` parametrisation (exp / sigmoid / normalize
+    activations, longest-axis direction); anything else (strand models, the reference's own classes) takes the generic
+    path below, which only relies on the model's public interface."""
+    from ..scene.gaussian_model import GaussianModel
+    return type(pc) is GaussianModel and getattr(pipe, "fused_projection", True) and pc.get_xyz.is_cuda
+
+
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
     """Render the scene (reference :23-113).  ``bg_color`` (10 floats) must be on the GPU."""
+    if _use_fused(pc, pipe):
+        from .fused import render_model_fused
+        renders, radii, screenspace_points = render_model_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
+                                                                getattr(pipe, "debug", False))
+        return _package(renders, screenspace_points, radii)
     conic = pc.get_conic(viewpoint_camera, scaling_modifier)  # must precede direction / filter (cached state)
     screenspace_points = pc.get_mean_2d(viewpoint_camera)
     try:

@@ -1,0 +1,114 @@
+"""Fused fast path of ``render()`` for the free-Gaussian ``GaussianModel``: raw parameters in, 10-channel image out.
+
+One autograd.Function around ``ghr_model_forward_stage1`` + ``ghr_forward_stage2`` / ``ghr_model_backward``
+(include/ghr.h): projection, SH, feature assembly, culling, rasterization and -- in backward -- the whole chain back to
+the leaf parameters run in hand-written HIP kernels instead of ~60 PyTorch kernels + autograd
+(src/gaussian_renderer/__init__.py:29-96 of the reference).
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream
+
+
+def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug):
+    m = _lib.ModelArgs()
+    m.P, m.W, m.H, m.sh_degree, m.sh_coeffs = int(P), int(W), int(H), int(sh_degree), int(K)
+    (m.xyz, m.log_scales, m.rotations, m.opacity_logit, m.label_logit, m.orient_conf_log, m.features_dc,
+     m.features_rest) = [_ptr(t) for t in tensors]
+    m.viewmatrix, m.projmatrix, m.campos, m.background = _ptr(view), _ptr(proj), _ptr(campos), _ptr(bg)
+    m.scale_modifier, m.tan_fovx, m.tan_fovy, m.conic_eps = float(scale_modifier), float(tanfovx), float(tanfovy), eps
+    m.debug = int(bool(debug))
+    return m
+
+
+class _RenderModelFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest,
+                screenspace_points, cfg):
+        L = _lib.lib()
+        if not xyz.is_cuda:
+            raise RuntimeError("gaussianhaircut_amd: parameters are on %s; the HIP renderer has no CPU path" % xyz.device)
+        dev = xyz.device
+        P, W, H = xyz.shape[0], cfg["W"], cfg["H"]
+        params = [t.detach().float().contiguous() for t in (xyz, log_scales, rotations, opacity_logit, label_logit,
+                                                            orient_conf_log, f_dc, f_rest)]
+        K = 1 + f_rest.shape[1]
+        view, proj = cfg["view"].float().contiguous(), cfg["proj"].float().contiguous()
+        campos, bg = cfg["campos"].float().contiguous(), cfg["bg"].float().contiguous()
+        with torch.cuda.device(dev):
+            color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            radii = torch.empty((P,), dtype=torch.int32, device=dev)
+            gbytes, ibytes = _lib.forward_sizes(P, W, H, False)
+            geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
+            img = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
+            m = _model_args(P, W, H, cfg["sh_degree"], K, params, view, proj, campos, bg, cfg["scale_modifier"],
+                            cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+            pinned = _pinned(dev)
+            _lib.check(L.ghr_model_forward_stage1(_stream(), ctypes.byref(m), _ptr(geom), _ptr(img), _ptr(radii),
+                                                  _ptr(screenspace_points.detach()), ctypes.c_void_p(pinned.data_ptr())))
+            torch.cuda.current_stream().synchronize()  # num_rendered sizes the binning workspace (cf. rasterizer_impl.cu:284)
+            R = int(pinned[0].item()) if P > 0 else 0
+            binb = torch.empty((_lib.binning_size(R),), dtype=torch.uint8, device=dev)
+            va = _lib.ViewArgs()
+            va.P, va.W, va.H, va.C = P, W, H, NUM_CHANNELS
+            va.background = _ptr(bg)
+            va.debug = int(bool(cfg["debug"]))
+            _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), R, _ptr(geom), _ptr(img), _ptr(binb),
+                                            _ptr(color)))
+        LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
+        ctx.cfg, ctx.R, ctx.K = cfg, R, K
+        ctx.mark_non_differentiable(radii)
+        ctx.save_for_backward(*params, view, proj, campos, bg, radii, geom, img, binb)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _):
+        L = _lib.lib()
+        cfg, R, K = ctx.cfg, ctx.R, ctx.K
+        *params, view, proj, campos, bg, radii, geom, img, binb = ctx.saved_tensors
+        xyz = params[0]
+        dev, P = xyz.device, xyz.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            d_m2d = torch.empty((P, 3), **f32)
+            d_xyz = torch.empty((P, 3), **f32)
+            d_ls = torch.empty((P, 3), **f32)
+            d_rot = torch.empty((P, 4), **f32)
+            d_op = torch.empty((P, 1), **f32)
+            d_label = torch.empty((P, 1), **f32)
+            d_conf = torch.empty((P, 1), **f32)
+            d_fdc = torch.empty((P, 1, 3), **f32)
+            d_frest = torch.empty((P, K - 1, 3), **f32)
+            scratch = torch.empty((P, _lib.GRAD_STRIDE), **f32)
+            dL = grad_color.float().contiguous()
+            m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
+                            cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+            if P > 0:
+                _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), R, _ptr(radii), _ptr(geom), _ptr(img),
+                                                _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
+                                                _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
+                                                _ptr(d_fdc), _ptr(d_frest)))
+        return d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d, None
+
+
+def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
+    """Returns (renders[10,H,W], radii[P], screenspace_points[P,3] leaf whose .grad receives dL/d(NDC mean))."""
+    import math
+    xyz = pc.get_xyz
+    P = xyz.shape[0]
+    # "zero tensor used to make pytorch return gradients of the 2D (screen-space) means" of the original 3DGS;
+    # here it also carries the NDC means as values, like the reference's get_mean_2d() output.
+    screenspace_points = torch.zeros((P, 3), dtype=torch.float32, device=xyz.device, requires_grad=True)
+    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
+               proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
+               sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
+               tanfovx=math.tan(float(cam.FoVx) * 0.5), tanfovy=math.tan(float(cam.FoVy) * 0.5),
+               conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug))
+    renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
+                                             pc._features_dc, pc._features_rest, screenspace_points, cfg)
+    return renders, radii, screenspace_points

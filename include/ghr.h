@@ -99,6 +99,49 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dscales, float* dL_drotations);
 
+/* ---- fused model path ------------------------------------------------------------------------
+ * One kernel computes, from the RAW parameters of the reference's GaussianModel, everything render() would build with
+ * ~60 PyTorch kernels before calling the rasterizer (src/gaussian_renderer/__init__.py:29-83):
+ *   activations (gaussian_model.py:107-141), get_conic (:230-315), get_mean_2d / get_depths (:317-342),
+ *   get_direction_2d (:344-393), eval_sh + clamp (sh_utils.py:57-112), the 10-channel feature vector, filter_points
+ *   (:143-228) -- and feeds K1's cull / radius / tile rect directly.  ghr_model_backward runs K8 and then maps the
+ *   packed per-Gaussian gradients to raw-parameter gradients (what autograd does for that graph), in one pass.
+ * Semantics are the PYTHON pipeline's (torch.clamp / normalize / clamp_min gradients, conic eps), tolerance 1e-4. */
+typedef struct ghr_model_args {
+    int32_t P, W, H;
+    int32_t sh_degree;            /* active SH degree 0..3 */
+    int32_t sh_coeffs;            /* K = (max_sh_degree + 1)^2 <= 16 */
+    const float* xyz;             /* [P,3]   _xyz */
+    const float* log_scales;      /* [P,3]   _scaling (exp activation) */
+    const float* rotations;       /* [P,4]   _rotation, raw (normalised in-kernel like build_rotation) */
+    const float* opacity_logit;   /* [P]     _opacity (sigmoid) */
+    const float* label_logit;     /* [P]     _label (sigmoid) */
+    const float* orient_conf_log; /* [P]     _orient_conf (exp) */
+    const float* features_dc;     /* [P,1,3] */
+    const float* features_rest;   /* [P,K-1,3] */
+    const float* viewmatrix;      /* [16] */
+    const float* projmatrix;      /* [16] */
+    const float* campos;          /* [3] */
+    const float* background;      /* [C] */
+    float scale_modifier, tan_fovx, tan_fovy;
+    float conic_eps;              /* 1e-12 (gaussian_model.py:312) */
+    int32_t debug;
+} ghr_model_args;
+
+/* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
+ * carries P, W, H, C and background; every other field may be NULL).  means2D_out [P,3] (NDC) may be NULL. */
+int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_ws, void* img_ws, int32_t* radii,
+                             float* means2D_out, uint32_t* R_host);
+
+/* Backward of the fused path.  Outputs are fully written: d_means2D [P,3], d_xyz [P,3], d_log_scales [P,3],
+ * d_rotations [P,4], d_opacity_logit [P], d_label_logit [P], d_orient_conf_log [P], d_features_dc [P,1,3],
+ * d_features_rest [P,K-1,3]. */
+int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
+                       const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                       float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
+                       float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
+                       float* d_features_rest);
+
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present);

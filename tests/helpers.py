@@ -195,3 +195,36 @@ class HostSim:
 
     def free(self, st):
         self.L.ghrsim_free(st["handle"])
+
+
+# --------------------------------------------------------------------------------------------------------------------
+class ModelArgsC(ctypes.Structure):
+    """Mirror of ghr::ModelArgs (gaussianhaircut_amd/csrc/ghr_project.h) for the host-sim."""
+    _fields_ = [(n, ctypes.c_int) for n in ("P", "W", "H", "gx", "gy", "sh_degree", "sh_coeffs")] + \
+               [(n, ctypes.c_void_p) for n in ("xyz", "log_scales", "rotations", "opacity_logit", "label_logit",
+                                               "orient_conf_log", "features_dc", "features_rest", "view", "proj",
+                                               "campos")] + \
+               [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "focal_x", "focal_y",
+                                              "conic_eps")] + \
+               [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "radii", "means2D", "tile_count")]
+
+
+def model_args_from(model, cam, keep, conic_eps=1e-12):
+    """Fill ModelArgsC from a (CPU) GaussianModel + Camera; `keep` collects the numpy arrays backing the pointers."""
+    import math
+    a = ModelArgsC()
+    arr = dict(xyz=np32(model._xyz), log_scales=np32(model._scaling), rotations=np32(model._rotation),
+               opacity_logit=np32(model._opacity).reshape(-1), label_logit=np32(model._label).reshape(-1),
+               orient_conf_log=np32(model._orient_conf).reshape(-1), features_dc=np32(model._features_dc),
+               features_rest=np32(model._features_rest), view=np32(cam.world_view_transform).reshape(-1),
+               proj=np32(cam.full_proj_transform).reshape(-1), campos=np32(cam.camera_center))
+    keep.append(arr)
+    for k, v in arr.items():
+        setattr(a, k, v.ctypes.data)
+    a.P, a.W, a.H = arr["xyz"].shape[0], int(cam.image_width), int(cam.image_height)
+    a.sh_degree, a.sh_coeffs = int(model.active_sh_degree), (model.max_sh_degree + 1) ** 2
+    a.scale_modifier = 1.0
+    a.tan_fovx, a.tan_fovy = math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5)
+    a.focal_x, a.focal_y = a.W / (2.0 * a.tan_fovx), a.H / (2.0 * a.tan_fovy)
+    a.conic_eps = conic_eps
+    return a

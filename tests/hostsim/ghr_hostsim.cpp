@@ -15,6 +15,7 @@
 #include "../../gaussianhaircut_amd/csrc/ghr_binning.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_geom_bwd.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_preprocess.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_project.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_render_bwd.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_render_fwd.h"
 
@@ -177,6 +178,39 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     for (int idx = 0; idx < P; idx++) ghr::geom_bwd_one(ga, idx);
 }
+
+// ---- fused projection (ghr_project.h): forward state + colours, and raw-parameter gradients from packed gacc ----
+// out_rec: [P][16], out_radii [P], out_means2D [P][3]
+void ghrsim_project_forward(const ghr::ModelArgs* a_in, float* out_rec, int* out_radii, float* out_means2D,
+                            float* out_depths)
+{
+    ghr::ModelArgs a = *a_in;
+    const int P = a.P;
+    a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
+    std::vector<ghr::f4> rec((size_t)4 * P, ghr::f4{0, 0, 0, 0});
+    std::vector<uint2> rects(P);
+    std::vector<uint32_t> count((size_t)a.gx * a.gy, 0u);
+    a.rec = rec.data(); a.depths = out_depths; a.rects = rects.data(); a.radii = out_radii; a.means2D = out_means2D;
+    a.tile_count = count.data();
+    for (int i = 0; i < P; i++) { int x0, y0, x1, y1; out_depths[i] = 0.f; ghr::project_one(a, i, x0, y0, x1, y1); }
+    std::memcpy(out_rec, rec.data(), sizeof(float) * 16 * (size_t)P);
+}
+
+void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
+                             float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
+                             float* d_fdc, float* d_frest)
+{
+    ghr::ModelArgs a = *a_in;
+    a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
+    a.radii = const_cast<int*>(radii);
+    ghr::ModelGrads g;
+    g.gacc = gacc; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
+    g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
+    g.d_features_rest = d_frest;
+    for (int i = 0; i < a.P; i++) ghr::project_bwd_one(a, g, i);
+}
+
+int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }
 
 // xcd_tile must be a bijection of [0, n)
 int ghrsim_xcd_bijective(uint32_t n)

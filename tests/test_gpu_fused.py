@@ -1,0 +1,72 @@
+"""`-m gpu`: the fused model path (k_project / k_project_bwd behind render()) against the generic path it replaces
+(PyTorch projection graph + autograd around the same HIP rasterizer)."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianhaircut_amd.gaussian_renderer import render
+from gaussianhaircut_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+FUSED = SimpleNamespace(debug=False, fused_projection=True)
+GENERIC = SimpleNamespace(debug=False, fused_projection=False)
+
+
+def _run(spec, pipe, dev, weights, deg):
+    model = syn.make_model(spec, dev)
+    model.active_sh_degree = deg
+    cam = syn.make_view(spec, dev)
+    pkg = render(cam, model, pipe, syn.background(dev))
+    full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
+    loss = (full * weights[:6]).sum() + (pkg["orient_angle"] * weights[6:7]).sum() * 0.1
+    loss.backward()
+    grads = {n: getattr(model, n).grad.detach().cpu().numpy() for n in
+             ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest")}
+    grads["viewspace"] = pkg["viewspace_points"].grad.detach().cpu().numpy()
+    return pkg, grads
+
+
+@pytest.mark.parametrize("cfg,deg", [("tiny", 3), ("tiny_strands", 3), ("ragged", 1), ("cfg1", 2)])
+def test_fused_render_matches_generic_path(cfg, deg):
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS[cfg]
+    g = torch.Generator().manual_seed(5)
+    weights = torch.randn(7, spec.H, spec.W, generator=g).to(dev)
+    pf, gf = _run(spec, FUSED, dev, weights, deg)
+    pg, gg = _run(spec, GENERIC, dev, weights, deg)
+    assert (pf["radii"] != pg["radii"]).float().mean() < 1e-3  # differently-rounded fp32 may flip a ceil()
+    assert torch.equal(pf["visibility_filter"], pf["radii"] > 0)
+    for k in ("render", "mask", "orient_conf", "orient_angle"):
+        a, b = pf[k].detach().cpu().numpy(), pg[k].detach().cpu().numpy()
+        err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
+        assert np.quantile(err, 0.999) < 1e-4, (k, np.quantile(err, 0.999), err.max())
+    vf, vg = pf["viewspace_points"].detach().cpu().numpy(), pg["viewspace_points"].detach().cpu().numpy()
+    assert np.abs(vf[:, :2] - vg[:, :2]).max() < 1e-5
+    for k in gg:
+        a, b = gf[k].reshape(len(gf[k]), -1), gg[k].reshape(len(gg[k]), -1)
+        assert np.isfinite(a).all()
+        scale = np.abs(b).max() + 1e-30
+        rows = np.abs(b).max(axis=1, keepdims=True)
+        err = np.abs(a - b) / (rows + 1e-3 * scale)
+        assert np.quantile(err, 0.995) < 2e-3, (k, np.quantile(err, 0.995), err.max())
+
+
+def test_fused_training_step_runs_and_learns():
+    from gaussianhaircut_amd.parallel import FlatGradBucket
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    model, cam, bg = syn.make_model(spec, dev), syn.make_view(spec, dev), syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, [cam], bg)
+    opt = OptimizationParams()
+    model.training_setup(opt)
+    bucket = FlatGradBucket(model.leaf_parameters())
+    losses = [float(training_step(model, [cam], bg, opt, i + 1, bucket=bucket)) for i in range(8)]
+    assert losses[-1] < losses[0] and np.isfinite(losses).all()
