@@ -82,8 +82,8 @@ def main():
         gt._features_dc.add_((0.05 * torch.randn(gt._features_dc.shape, generator=g)).to(dev))
         make_ground_truth(gt, cams, bg)
         del gt
-    model.training_setup(opt)
-    bucket = FlatGradBucket(model.leaf_parameters())
+    model.training_setup(opt)  # FusedAdam on ROCm: flat params / grads / moments
+    bucket = None
     torch.cuda.synchronize()
 
     # ---- HIP events around the two render kernels, recorded by the library on the launch stream -------------------

@@ -16,7 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libghr_hip.so")
 SOURCES = ["ghr_capi.hip"]
 HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h",
-           "ghr_geom_bwd.h", "ghr_project.h"]
+           "ghr_geom_bwd.h", "ghr_project.h", "ghr_loss.h", "ghr_adam.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
                "-shared"]
 
@@ -95,7 +95,7 @@ class WsView(ctypes.Structure):
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_model_forward_stage1",
-           "ghr_model_backward"]
+           "ghr_model_backward", "ghr_loss_forward", "ghr_loss_backward", "ghr_adam_step"]
 
 _lib = None
 
@@ -121,6 +121,10 @@ def lib() -> ctypes.CDLL:
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
+    L.ghr_loss_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp]
+    L.ghr_loss_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp]
+    L.ghr_adam_step.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, i32, ctypes.POINTER(ctypes.c_int64),
+                                ctypes.POINTER(ctypes.c_float), f32, f32, f32, i32, i32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:

@@ -1,0 +1,79 @@
+// ghr_adam.h -- fused multi-group Adam over ONE flat parameter / gradient / moment buffer.
+//
+// Reference: torch.optim.Adam(l, lr=0.0, eps=1e-15) over 8 parameter groups (src/scene/gaussian_model.py:431-444),
+// stepped at src/train_gaussians.py:174-181 behind a NaN guard that skips the whole update.  PyTorch's foreach Adam
+// runs ~10 multi-tensor kernels over 61 floats/Gaussian (1.19 ms at 500k on MI355X); here one pass reads p, g, m, v
+// and writes p, m, v (28 B/param, the HBM floor), zeroes the gradient for the next step (folds zero_grad), and applies
+// the NaN guard on-device (no host sync): if the flag is set nothing is updated and the step counter does not advance,
+// exactly like optimizer.zero_grad(set_to_none=True); optimizer.step() in the reference.
+#pragma once
+#include "ghr_device.h"
+
+namespace ghr {
+
+#define GHR_ADAM_MAX_GROUPS 16
+
+struct AdamArgs {
+    long long n;          // total elements
+    float* p;             // flat parameters
+    float* g;             // flat gradients (zeroed on exit when zero_grad != 0)
+    float* m;             // exp_avg
+    float* v;             // exp_avg_sq
+    int* state;           // [0] = step count (incremented by the kernel's block 0 when not skipped), [1] = NaN flag
+    int n_groups;
+    long long end[GHR_ADAM_MAX_GROUPS];  // exclusive end offset of each group in the flat buffer
+    float lr[GHR_ADAM_MAX_GROUPS];
+    float beta1, beta2, eps;
+    int zero_grad;
+};
+
+// state[1] |= any(isnan(g)).  grid-stride.
+__global__ void __launch_bounds__(256) k_adam_nan_flag(const float* __restrict__ g, long long n, int* state)
+{
+    bool bad = false;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float x = g[i];
+        bad |= (x != x);
+    }
+    if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(&state[1], 1);
+}
+
+GHR_HD void adam_update(float& p, float g, float& m, float& v, float lr, float beta1, float beta2, float eps,
+                        float bias1, float bias2_sqrt)
+{
+    // torch/optim/adam.py (_single_tensor_adam): exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(g,g,1-beta2)
+    m = m + (g - m) * (1.f - beta1);
+    v = v * beta2 + (1.f - beta2) * g * g;
+    const float step_size = lr / bias1;
+    const float denom = sqrtf(v) / bias2_sqrt + eps;
+    p = p - step_size * (m / denom);
+}
+
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a)
+{
+    const int skip = a.state[1];
+    const int step = a.state[0] + 1;  // this update's step number (all blocks read before block 0 may bump it: see tail)
+    const float bias1 = 1.f - powf(a.beta1, (float)step);
+    const float bias2_sqrt = sqrtf(1.f - powf(a.beta2, (float)step));
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        if (!skip) {
+            int gi = 0;
+            while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;
+            float p = a.p[i], m = a.m[i], v = a.v[i];
+            adam_update(p, a.g[i], m, v, a.lr[gi], a.beta1, a.beta2, a.eps, bias1, bias2_sqrt);
+            a.p[i] = p; a.m[i] = m; a.v[i] = v;
+        }
+        if (a.zero_grad) a.g[i] = 0.f;
+    }
+}
+
+// Runs after k_adam on the same stream: advance the step counter unless skipped, clear the flag.
+__global__ void k_adam_finish(int* state)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (!state[1]) state[0] += 1;
+        state[1] = 0;
+    }
+}
+
+}  // namespace ghr

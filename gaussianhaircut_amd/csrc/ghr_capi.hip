@@ -10,7 +10,9 @@
 
 #include "ghr_binning.h"
 #include "ghr_device.h"
+#include "ghr_adam.h"
 #include "ghr_geom_bwd.h"
+#include "ghr_loss.h"
 #include "ghr_preprocess.h"
 #include "ghr_project.h"
 #include "ghr_render_bwd.h"
@@ -333,6 +335,64 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a, mg);
     return finish(s, m->debug);
+}
+
+namespace ghr {
+__global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, float w_mask, float n_pix, float* out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        out[0] = w_l1 * (sums[0] / (3.f * n_pix)) + w_ssim * (1.f - sums[1] / (3.f * n_pix)) +
+                 w_mask * (sums[2] / (2.f * n_pix));
+}
+}  // namespace ghr
+
+int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, const float* mask, const float* gt_image,
+                     const float* gt_mask, float w_l1, float w_ssim, float w_mask, float* maps, float* sums,
+                     float* loss_out)
+{
+    if (W <= 0 || H <= 0 || !image || !mask || !gt_image || !gt_mask || !maps || !sums || !loss_out)
+        return fail(GHR_E_INVALID, "ghr_loss_forward: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    GHR_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(float), s));
+    ghr::LossArgs a{W, H, image, mask, gt_image, gt_mask, maps, sums};
+    const dim3 grid((W + GHR_SSIM_T - 1) / GHR_SSIM_T, (H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
+    hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(GHR_SSIM_T, GHR_SSIM_T), 0, s, a);
+    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, w_l1, w_ssim, w_mask, (float)W * (float)H,
+                       loss_out);
+    return finish(s, 0);
+}
+
+int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, const float* mask,
+                      const float* gt_image, const float* gt_mask, const float* maps, const float* grad_loss,
+                      float w_l1, float w_ssim, float w_mask, float* d_image, float* d_mask)
+{
+    if (W <= 0 || H <= 0 || !image || !mask || !gt_image || !gt_mask || !maps || !d_image || !d_mask)
+        return fail(GHR_E_INVALID, "ghr_loss_backward: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ghr::LossBwdArgs a{W, H, image, mask, gt_image, gt_mask, maps, grad_loss, w_l1, w_ssim, w_mask, d_image, d_mask};
+    const dim3 grid((W + GHR_SSIM_T - 1) / GHR_SSIM_T, (H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
+    hipLaunchKernelGGL(ghr::k_loss_bwd, grid, dim3(GHR_SSIM_T, GHR_SSIM_T), 0, s, a);
+    return finish(s, 0);
+}
+
+int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
+                  const int64_t* group_end_host, const float* lr_host, float beta1, float beta2, float eps,
+                  int32_t nan_guard, int32_t zero_grad)
+{
+    if (n < 0 || !p || !g || !m || !v || !state || n_groups <= 0 || n_groups > GHR_ADAM_MAX_GROUPS ||
+        !group_end_host || !lr_host)
+        return fail(GHR_E_INVALID, "ghr_adam_step: bad args");
+    if (n == 0) return GHR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ghr::AdamArgs a;
+    a.n = n; a.p = p; a.g = g; a.m = m; a.v = v; a.state = state; a.n_groups = n_groups;
+    for (int i = 0; i < n_groups; i++) { a.end[i] = group_end_host[i]; a.lr[i] = lr_host[i]; }
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (nan_guard) hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
+    hipLaunchKernelGGL(ghr::k_adam, dim3(blocks), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state);
+    return finish(s, 0);
 }
 
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

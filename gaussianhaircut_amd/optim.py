@@ -1,0 +1,90 @@
+"""``FusedAdam``: the reference's ``torch.optim.Adam(groups, lr=0.0, eps=1e-15)`` (src/scene/gaussian_model.py:431-444)
+as ONE HIP kernel over flat buffers (csrc/ghr_adam.h).
+
+Every parameter's storage is re-pointed into one contiguous fp32 buffer (``flat_param``) and every ``.grad`` into
+``flat_grad`` (so the data-parallel all-reduce is one collective on ``flat_grad`` with no packing); moments live in
+``exp_avg`` / ``exp_avg_sq``.  ``param_groups`` keeps the reference's shape (``name`` / ``lr`` / ``params``), so
+``update_learning_rate`` and friends work unchanged.  The NaN guard of src/train_gaussians.py:174-181 runs on-device.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .diff_gaussian_rasterization import _ptr, _stream
+
+
+class FusedAdam:
+    def __init__(self, param_groups: List[Dict], betas=(0.9, 0.999), eps: float = 1e-15, nan_guard: bool = True):
+        self.param_groups = [dict(g) for g in param_groups]
+        self.betas, self.eps, self.nan_guard = betas, eps, nan_guard
+        params = [p for g in self.param_groups for p in g["params"]]
+        assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
+            "FusedAdam needs fp32 parameters on a ROCm device (use torch.optim.Adam elsewhere)"
+        dev = params[0].device
+        n = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.state_dev = torch.zeros(2, dtype=torch.int32, device=dev)  # {step, nan flag}
+        off, ends = 0, []
+        for g in self.param_groups:
+            for p in g["params"]:
+                k = p.numel()
+                self.flat_param[off:off + k].copy_(p.data.reshape(-1))
+                p.data = self.flat_param[off:off + k].view(p.shape)
+                p.grad = self.flat_grad[off:off + k].view(p.shape)
+                off += k
+            ends.append(off)
+        self._ends = (ctypes.c_int64 * len(ends))(*ends)
+        self.params = params
+
+    # ---- gradient-bucket interface (same as parallel.FlatGradBucket)
+    @property
+    def flat(self):
+        return self.flat_grad
+
+    def zero(self):
+        self.flat_grad.zero_()
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.flat_grad.zero_()  # grads alias the flat buffer: never dropped
+
+    def all_reduce(self, average_over=None, async_op=False):
+        work = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+        if average_over and average_over != 1 and not async_op:
+            self.flat_grad.div_(average_over)
+        return work
+
+    def has_nan(self):
+        return torch.isnan(self.flat_grad).any()
+
+    # ---- optimizer interface
+    def step(self, zero_grad: bool = True):
+        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        with torch.cuda.device(self.flat_param.device):
+            _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
+                                                _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
+                                                _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
+                                                self.betas[0], self.betas[1], self.eps, int(self.nan_guard),
+                                                int(zero_grad)))
+
+    def state_dict(self):
+        return {"flat_param": self.flat_param, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "state": self.state_dev, "lrs": [g["lr"] for g in self.param_groups],
+                "names": [g.get("name") for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.flat_param.copy_(sd["flat_param"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.state_dev.copy_(sd["state"])
+        for g, lr in zip(self.param_groups, sd["lrs"]):
+            g["lr"] = lr

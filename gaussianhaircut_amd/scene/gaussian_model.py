@@ -242,12 +242,20 @@ class GaussianModel:
             groups.append({'params': [self._orient_conf], 'lr': training_args.orient_conf_lr, "name": "orient_conf"})
         return groups
 
-    def training_setup(self, training_args):
+    def training_setup(self, training_args, fused=None):
+        """``fused=None`` picks the single-kernel HIP Adam (optim.FusedAdam) when the parameters live on a ROCm
+        device, ``torch.optim.Adam`` otherwise; both use the reference's groups, lrs and eps = 1e-15."""
         self.percent_dense = training_args.percent_dense
         P, dev = self.get_xyz.shape[0], self.get_xyz.device
         self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
         self.denom = torch.zeros((P, 1), device=dev)
-        self.optimizer = torch.optim.Adam(self.param_groups(training_args), lr=0.0, eps=1e-15)
+        if fused is None:
+            fused = self.get_xyz.is_cuda
+        if fused:
+            from ..optim import FusedAdam
+            self.optimizer = FusedAdam(self.param_groups(training_args), eps=1e-15)
+        else:
+            self.optimizer = torch.optim.Adam(self.param_groups(training_args), lr=0.0, eps=1e-15)
         self.xyz_scheduler_args = get_expon_lr_func(lr_init=training_args.position_lr_init * self.spatial_lr_scale,
                                                     lr_final=training_args.position_lr_final * self.spatial_lr_scale,
                                                     lr_delay_mult=training_args.position_lr_delay_mult,

@@ -14,10 +14,15 @@ from .utils.loss_utils import l1_loss, or_loss, ssim
 PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
-def view_loss(render_pkg, cam, opt):
-    """train_gaussians.py:113-140."""
+def view_loss(render_pkg, cam, opt, fused=None):
+    """train_gaussians.py:113-140.  On a ROCm device the L1 / SSIM / mask terms run as one fused HIP op."""
     image, mask = render_pkg["render"], render_pkg["mask"]
     gt_image, gt_mask = cam.original_image, cam.original_mask
+    if fused is None:
+        fused = image.is_cuda
+    if fused and opt.lambda_dorient == 0.0:
+        from .fused_loss import photometric_loss
+        return photometric_loss(image, mask, gt_image, gt_mask, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask)
     Ll1 = l1_loss(image, gt_image, mask=gt_mask[1:].detach())
     Lssim = 1.0 - ssim(image * gt_mask[1:], gt_image * gt_mask[1:])
     Lmask = l1_loss(mask, gt_mask)
@@ -42,6 +47,12 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         loss = view_loss(pkg, cam, opt) / V
         loss.backward()
         total = loss.detach() if total is None else total + loss.detach()
+    from .optim import FusedAdam
+    if isinstance(gaussians.optimizer, FusedAdam):
+        # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
+        gaussians.optimizer.all_reduce()
+        gaussians.optimizer.step(zero_grad=True)
+        return total
     if bucket is not None:
         bucket.all_reduce()
         bad = bucket.has_nan()

@@ -142,6 +142,27 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
                        float* d_features_rest);
 
+/* ---- fused photometric loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-26,91-121) -------------
+ * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|),
+ * m = gt_mask[1].  image/gt_image [3,H,W], mask/gt_mask [2,H,W].  maps: 9*H*W floats of scratch kept for backward.
+ * loss_out: device scalar.  sums: 3 device floats of scratch. */
+int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, const float* mask, const float* gt_image,
+                     const float* gt_mask, float w_l1, float w_ssim, float w_mask, float* maps, float* sums,
+                     float* loss_out);
+/* grad_loss: device scalar dL/dloss (NULL = 1).  d_image [3,H,W], d_mask [2,H,W] fully written. */
+int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, const float* mask,
+                      const float* gt_image, const float* gt_mask, const float* maps, const float* grad_loss,
+                      float w_l1, float w_ssim, float w_mask, float* d_image, float* d_mask);
+
+/* ---- fused Adam (src/scene/gaussian_model.py:431-444; src/train_gaussians.py:174-181) ---------------------------
+ * One pass over flat buffers p/g/m/v of n floats split into n_groups contiguous groups (group_end[i] = exclusive end
+ * offset, lr[i] = its learning rate; host arrays).  state: 2 device ints {step, nan_flag}, zero-initialised once.
+ * nan_guard != 0: skip the whole update (and do not advance step) when any gradient is NaN, on-device.
+ * zero_grad != 0: the gradient buffer is zeroed for the next step. */
+int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
+                  const int64_t* group_end_host, const float* lr_host, float beta1, float beta2, float eps,
+                  int32_t nan_guard, int32_t zero_grad);
+
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,
                      const float* projmatrix, uint8_t* present);

@@ -19,7 +19,7 @@ with torch.no_grad():
     make_ground_truth(syn.make_model(spec, dev), cams, bg)
 opt = OptimizationParams()
 model.training_setup(opt)
-bucket = FlatGradBucket(model.leaf_parameters())
+bucket = None
 for i in range(3):
     training_step(model, cams, bg, opt, i + 1, bucket=bucket, global_views=1)
 torch.cuda.synchronize()
