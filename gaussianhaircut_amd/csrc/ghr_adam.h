@@ -23,7 +23,8 @@ struct AdamArgs {
     int n_groups;
     long long end[GHR_ADAM_MAX_GROUPS];  // exclusive end offset of each group in the flat buffer
     float lr[GHR_ADAM_MAX_GROUPS];
-    float beta1, beta2, eps;
+    double beta1, beta2;  // double like torch's Python-side scalars: 1 - beta^step cancels badly in fp32
+    float eps;
     int zero_grad;
 };
 
@@ -38,13 +39,12 @@ __global__ void __launch_bounds__(256) k_adam_nan_flag(const float* __restrict__
     if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(&state[1], 1);
 }
 
-GHR_HD void adam_update(float& p, float g, float& m, float& v, float lr, float beta1, float beta2, float eps,
-                        float bias1, float bias2_sqrt)
+GHR_HD void adam_update(float& p, float g, float& m, float& v, float step_size, float w1, float beta2, float w2,
+                        float eps, float bias2_sqrt)
 {
     // torch/optim/adam.py (_single_tensor_adam): exp_avg.lerp_(grad, 1-beta1); exp_avg_sq.mul_(beta2).addcmul_(g,g,1-beta2)
-    m = m + (g - m) * (1.f - beta1);
-    v = v * beta2 + (1.f - beta2) * g * g;
-    const float step_size = lr / bias1;
+    m = m + (g - m) * w1;
+    v = v * beta2 + w2 * g * g;
     const float denom = sqrtf(v) / bias2_sqrt + eps;
     p = p - step_size * (m / denom);
 }
@@ -53,14 +53,15 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
 {
     const int skip = a.state[1];
     const int step = a.state[0] + 1;  // this update's step number (all blocks read before block 0 may bump it: see tail)
-    const float bias1 = 1.f - powf(a.beta1, (float)step);
-    const float bias2_sqrt = sqrtf(1.f - powf(a.beta2, (float)step));
+    const double bias1 = 1.0 - pow(a.beta1, (double)step);
+    const float bias2_sqrt = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+    const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         if (!skip) {
             int gi = 0;
             while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;
             float p = a.p[i], m = a.m[i], v = a.v[i];
-            adam_update(p, a.g[i], m, v, a.lr[gi], a.beta1, a.beta2, a.eps, bias1, bias2_sqrt);
+            adam_update(p, a.g[i], m, v, (float)((double)a.lr[gi] / bias1), w1, b2, w2, a.eps, bias2_sqrt);
             a.p[i] = p; a.m[i] = m; a.v[i] = v;
         }
         if (a.zero_grad) a.g[i] = 0.f;

@@ -340,9 +340,16 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
 namespace ghr {
 __global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, float w_mask, float n_pix, float* out)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0)
-        out[0] = w_l1 * (sums[0] / (3.f * n_pix)) + w_ssim * (1.f - sums[1] / (3.f * n_pix)) +
-                 w_mask * (sums[2] / (2.f * n_pix));
+    // one wave: lane l folds slots l, l+64, ... in double, then a butterfly over the 64 lanes
+    double s0 = 0, s1 = 0, s2 = 0;
+    for (int i = threadIdx.x; i < GHR_LOSS_SLOTS; i += 64) {
+        s0 += sums[3 * i]; s1 += sums[3 * i + 1]; s2 += sums[3 * i + 2];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+    }
+    if (threadIdx.x == 0)
+        out[0] = (float)(w_l1 * (s0 / (3.0 * n_pix)) + w_ssim * (1.0 - s1 / (3.0 * n_pix)) + w_mask * (s2 / (2.0 * n_pix)));
 }
 }  // namespace ghr
 
@@ -353,7 +360,7 @@ int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, con
     if (W <= 0 || H <= 0 || !image || !mask || !gt_image || !gt_mask || !maps || !sums || !loss_out)
         return fail(GHR_E_INVALID, "ghr_loss_forward: bad args");
     hipStream_t s = (hipStream_t)stream;
-    GHR_HIP(hipMemsetAsync(sums, 0, 3 * sizeof(float), s));
+    GHR_HIP(hipMemsetAsync(sums, 0, 3 * GHR_LOSS_SLOTS * sizeof(float), s));
     ghr::LossArgs a{W, H, image, mask, gt_image, gt_mask, maps, sums};
     const dim3 grid((W + GHR_SSIM_T - 1) / GHR_SSIM_T, (H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
     hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(GHR_SSIM_T, GHR_SSIM_T), 0, s, a);
@@ -376,7 +383,7 @@ int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, co
 }
 
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
-                  const int64_t* group_end_host, const float* lr_host, float beta1, float beta2, float eps,
+                  const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
                   int32_t nan_guard, int32_t zero_grad)
 {
     if (n < 0 || !p || !g || !m || !v || !state || n_groups <= 0 || n_groups > GHR_ADAM_MAX_GROUPS ||

@@ -101,4 +101,30 @@ GHR_HD float fast_rcp(float x)
 }
 GHR_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// ---- exact culling of list entries per pixel strip ---------------------------------------------------------------------
+// A splat only contributes to pixels where alpha = min(.99, o*exp(power)) >= 1/255 (forward.cu:369-371), i.e. inside the
+// ellipse  d^T C d <= 2 ln(255 o).  The reference walks every pixel of every tile in the 3-sigma SQUARE of the largest
+// eigenvalue (forward.cu:254-260), so for strand-aligned (needle) Gaussians most visited pixels fail that test.  This
+// returns a CONSERVATIVE axis-aligned box {xmin, xmax, ymin, ymax} (pixel coordinates) of that ellipse; pixels outside
+// it are guaranteed to be skipped by the per-pixel test, so not visiting them leaves every output bit-identical.
+// Margins: 1 % + 0.01 px on the half extents (>= 2e-5 relative slack on alpha, vs ~5e-7 error of the fast exp);
+// degenerate cases (opacity within 1e-3 of the threshold, non-positive-definite conic, non-finite) return the full plane.
+GHR_HD f4 alpha_bbox(const f4& r0, const f4& r1)
+{
+    const float BIG = 3.0e38f;
+    const float o = r1.y, cx = r0.z, cy = r0.w, cz = r1.x;
+    if (o < 0.999f * (1.0f / 255.0f)) return f4{BIG, -BIG, BIG, -BIG};  // alpha <= o < 1/255 everywhere: empty
+    const float L = logf(255.0f * o);
+    const float det = cx * cz - cy * cy;
+    if (!(L >= 1.0e-3f) || !(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return f4{-BIG, BIG, -BIG, BIG};
+    const float k = 2.0f * L / det;
+    const float hx = 1.01f * sqrtf(k * cz) + 0.01f, hy = 1.01f * sqrtf(k * cx) + 0.01f;
+    if (!(hx < BIG) || !(hy < BIG)) return f4{-BIG, BIG, -BIG, BIG};
+    return f4{r0.x - hx, r0.x + hx, r0.y - hy, r0.y + hy};
+}
+GHR_HD bool bbox_hits(const f4& bb, float x0, float x1, float y0, float y1)
+{
+    return !(bb.y < x0 || bb.x > x1 || bb.w < y0 || bb.z > y1);
+}
+
 }  // namespace ghr

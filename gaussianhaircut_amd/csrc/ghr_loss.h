@@ -19,6 +19,7 @@ namespace ghr {
 #define GHR_SSIM_R 5
 #define GHR_SSIM_T 16
 #define GHR_SSIM_E (GHR_SSIM_T + 2 * GHR_SSIM_R)  // 26
+#define GHR_LOSS_SLOTS 256
 
 __device__ __constant__ float c_ssim_w[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
                                              2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
@@ -49,7 +50,8 @@ struct LossArgs {
     const float* gt_image;  // [3,H,W]
     const float* gt_mask;   // [2,H,W]; channel 1 masks the colour terms
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
-    float* sums;            // [3]: sum |image-gt|*m, sum ssim_map, sum |mask-gt_mask|   (zeroed by the caller)
+    float* sums;            // [GHR_LOSS_SLOTS][3] partial sums {|image-gt|*m, ssim_map, |mask-gt_mask|}, zeroed by the caller;
+                            // block b adds into slot b % SLOTS (one hot address would serialise ~73k atomics)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -134,9 +136,10 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
     const float s1 = block_sum_256(ssim_v, s_red);
     const float s2 = block_sum_256(ml1_v, s_red);
     if (tid == 0) {
-        atomicAdd(&a.sums[0], s0);
-        atomicAdd(&a.sums[1], s1);
-        atomicAdd(&a.sums[2], s2);
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
+        atomicAdd(&a.sums[3 * slot + 0], s0);
+        atomicAdd(&a.sums[3 * slot + 1], s1);
+        atomicAdd(&a.sums[3 * slot + 2], s2);
     }
 #endif
 }

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                                                           const float* __restrict__ dL_dpix, float* gacc)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK];
+    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
     __shared__ uint32_t s_id[GHR_BLOCK];
     __shared__ float s_acc[GHR_BLOCK * 16];
     __shared__ uint32_t s_max[4];
@@ -135,6 +135,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
+    const float sx0 = (float)(tx * GHR_TILE_X), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * GHR_TILE_Y + 4 * wave), sy1 = sy0 + 3.0f;
 
     const uint32_t beg = tile_start[tile];
     const uint32_t n = tile_start[tile + 1] - beg;
@@ -173,8 +175,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             // walk back to front: batch entry j is list position n_eff-1-(base+j)
             const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)id;
+            const f4 a0 = r[0], a1 = r[1];
             s_id[tid] = id;
-            s_r0[tid] = r[0]; s_r1[tid] = r[1]; s_r2[tid] = r[2]; s_r3[tid] = r[3];
+            s_r0[tid] = a0; s_r1[tid] = a1; s_r2[tid] = r[2]; s_r3[tid] = r[3];
+            s_bb[tid] = alpha_bbox(a0, a1);
         }
         {
             f4* z = reinterpret_cast<f4*>(s_acc) + 4 * tid;
@@ -183,17 +187,25 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         }
         __syncthreads();
 
-        for (uint32_t j = 0; j < cnt; j++) {
-            const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
-            float g[16];
+        // per-wave ordered list (ballot mask) of the entries whose alpha>=1/255 box touches this wave's 16x4 strip
+        for (uint32_t sub = 0; sub < cnt; sub += 64) {
+            const uint32_t e = sub + lane;
+            const bool hit = e < cnt && bbox_hits(s_bb[e], sx0, sx1, sy0, sy1);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+            while (todo) {
+                const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
+                float g[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) g[i] = 0.f;
-            bool c = false;
-            if (pos < last_contributor)
-                c = bwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
-            if (__builtin_amdgcn_ballot_w64(c) != 0) {  // wave-uniform
-                const float v = wave_reduce16(g, lane);
-                if ((lane & 3) == 0) atomicAdd(&s_acc[j * 16 + comp], v);  // ds_add_f32, 16 lanes, 16 distinct banks
+                for (int i = 0; i < 16; i++) g[i] = 0.f;
+                bool c = false;
+                if (pos < last_contributor)
+                    c = bwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
+                if (__builtin_amdgcn_ballot_w64(c) != 0) {  // wave-uniform
+                    const float v = wave_reduce16(g, lane);
+                    if ((lane & 3) == 0) atomicAdd(&s_acc[j * 16 + comp], v);  // ds_add_f32, 16 lanes, 16 banks
+                }
             }
         }
         __syncthreads();

@@ -54,11 +54,14 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           float* __restrict__ out_color, float* __restrict__ final_T,
                                                           uint32_t* __restrict__ n_contrib)
 {
-    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK];
+    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // this wave's pixel strip: 16 columns x 4 rows
+    const float sx0 = (float)(tx * GHR_TILE_X), sx1 = sx0 + 15.0f;
+    const float sy0 = (float)(ty * GHR_TILE_Y + 4 * (tid >> 6)), sy1 = sy0 + 3.0f;
     const int px = tx * GHR_TILE_X + (tid & 15), py = ty * GHR_TILE_Y + (tid >> 4);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
@@ -91,15 +94,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
         // forward.cu:335-337: stop when the whole tile is done.  The barrier also protects the LDS planes.
         if (__syncthreads_count(done) == GHR_BLOCK) break;
         s_r0[tid] = g0; s_r1[tid] = g1; s_r2[tid] = g2; s_r3[tid] = g3;
+        s_bb[tid] = alpha_bbox(g0, g1);
         __syncthreads();
         if (base + GHR_BLOCK < n) GHR_GATHER(base + GHR_BLOCK);
 
         const uint32_t cnt = min((uint32_t)GHR_BLOCK, n - base);
-        if (__builtin_amdgcn_ballot_w64(!done) != 0) {  // wave-uniform: skip the batch once all 64 pixels are done
-            for (uint32_t j = 0; j < cnt; j++) {
+        // Each lane tests one entry's alpha>=1/255 box against the wave's strip; the ballot is the (ordered) list of
+        // entries this wave has to evaluate at all.  Skipped entries would have been rejected by every lane.
+        for (uint32_t sub = 0; sub < cnt; sub += 64) {
+            if (__builtin_amdgcn_ballot_w64(!done) == 0) break;  // wave-uniform: all 64 pixels finished
+            const uint32_t e = sub + lane;
+            const bool hit = e < cnt && bbox_hits(s_bb[e], sx0, sx1, sy0, sy1);
+            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
+            while (todo) {
+                const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
                 if (!done) done = fwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
-                // once every lane of the wave is done nothing below can change
-                if ((j & 15u) == 15u && __builtin_amdgcn_ballot_w64(!done) == 0) break;
             }
         }
     }

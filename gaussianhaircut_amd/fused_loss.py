@@ -21,7 +21,7 @@ class _PhotometricLoss(torch.autograd.Function):
         dev = image.device
         with torch.cuda.device(dev):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
-            sums = torch.empty(3, dtype=torch.float32, device=dev)
+            sums = torch.empty(768, dtype=torch.float32, device=dev)  # GHR_LOSS_SUMS
             loss = torch.empty((), dtype=torch.float32, device=dev)
             _lib.check(_lib.lib().ghr_loss_forward(_stream(), W, H, _ptr(image_c), _ptr(mask_c), _ptr(gt_image_c),
                                                    _ptr(gt_mask_c), w_l1, w_ssim, w_mask, _ptr(maps), _ptr(sums),

@@ -145,7 +145,8 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
 /* ---- fused photometric loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-26,91-121) -------------
  * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|),
  * m = gt_mask[1].  image/gt_image [3,H,W], mask/gt_mask [2,H,W].  maps: 9*H*W floats of scratch kept for backward.
- * loss_out: device scalar.  sums: 3 device floats of scratch. */
+ * loss_out: device scalar.  sums: GHR_LOSS_SUMS (768) device floats of scratch. */
+#define GHR_LOSS_SUMS 768
 int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, const float* mask, const float* gt_image,
                      const float* gt_mask, float w_l1, float w_ssim, float w_mask, float* maps, float* sums,
                      float* loss_out);
@@ -160,7 +161,7 @@ int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, co
  * nan_guard != 0: skip the whole update (and do not advance step) when any gradient is NaN, on-device.
  * zero_grad != 0: the gradient buffer is zeroed for the next step. */
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
-                  const int64_t* group_end_host, const float* lr_host, float beta1, float beta2, float eps,
+                  const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
                   int32_t nan_guard, int32_t zero_grad);
 
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */

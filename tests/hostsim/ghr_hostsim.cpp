@@ -106,8 +106,10 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
             st.T = 1.f; st.last = 0;
             for (int c = 0; c < GHR_C; c++) st.C[c] = 0.f;
             bool done = false;
+            const float sx0 = (float)(tx * 16), sx1 = sx0 + 15.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
             for (uint32_t j = 0; j < n && !done; j++) {
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)s->point_list[beg + j];
+                if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_fwd's strip cull
                 done = ghr::fwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
             }
             const size_t pix = (size_t)a->W * py + px;
@@ -159,6 +161,10 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                 if (!(pos < last)) continue;
                 const uint32_t id = s->point_list[beg + pos];
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)id;
+                {
+                    const float sx0 = (float)(tx * 16), sx1 = sx0 + 15.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
+                    if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_bwd's strip cull
+                }
                 float g[16];
                 if (ghr::bwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g))
                     for (int i = 0; i < 16; i++) acc[(size_t)16 * id + i] += (double)g[i];
@@ -211,6 +217,27 @@ void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const
 }
 
 int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }
+
+// Conservativeness of alpha_bbox: returns the number of pixels in [0,W)x[0,H) that fwd_step's own arithmetic would
+// blend (alpha >= 1/255, power <= 0) but that lie OUTSIDE the box.  Must be 0.
+int ghrsim_bbox_violations(const float* rec16, int n, int W, int H)
+{
+    int bad = 0;
+    for (int i = 0; i < n; i++) {
+        const ghr::f4* r = (const ghr::f4*)(rec16 + 16 * (size_t)i);
+        const ghr::f4 bb = ghr::alpha_bbox(r[0], r[1]);
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) {
+                const float dx = r[0].x - (float)x, dy = r[0].y - (float)y;
+                const float power = -0.5f * (r[0].z * dx * dx + r[1].x * dy * dy) - r[0].w * dx * dy;
+                if (power > 0.0f) continue;
+                const float alpha = fminf(0.99f, r[1].y * ghr::fast_exp(power));
+                if (alpha < 1.0f / 255.0f) continue;
+                if (!ghr::bbox_hits(bb, (float)x, (float)x, (float)y, (float)y)) bad++;
+            }
+    }
+    return bad;
+}
 
 // xcd_tile must be a bijection of [0, n)
 int ghrsim_xcd_bijective(uint32_t n)

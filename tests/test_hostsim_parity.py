@@ -82,3 +82,29 @@ def test_bitonic_network_any_length(hostsim):
         ref = np.sort(keys[:n])
         assert hostsim.L.ghrsim_bitonic(ctypes.c_void_p(keys.ctypes.data), ctypes.c_uint32(n)) == 1
         np.testing.assert_array_equal(keys[:n], ref)
+
+
+def test_alpha_bbox_is_conservative(hostsim):
+    """The strip-culling box of k_render_fwd / k_render_bwd must contain every pixel the per-pixel alpha test accepts,
+    including needle-like conics, opacities at the 1/255 threshold, huge and degenerate splats."""
+    import ctypes
+    rng = np.random.default_rng(5)
+    n = 400
+    rec = np.zeros((n, 16), np.float32)
+    W, H = 96, 80
+    rec[:, 0] = rng.uniform(-20, W + 20, n)
+    rec[:, 1] = rng.uniform(-20, H + 20, n)
+    # random SPD conics over 6 decades of scale and strong anisotropy
+    th = rng.uniform(0, np.pi, n)
+    l1 = 10 ** rng.uniform(-4, 0.5, n)
+    l2 = l1 * 10 ** rng.uniform(0, 3, n)
+    c, s = np.cos(th), np.sin(th)
+    rec[:, 2] = l1 * c * c + l2 * s * s
+    rec[:, 3] = (l1 - l2) * c * s
+    rec[:, 4] = l1 * s * s + l2 * c * c
+    rec[:, 5] = np.concatenate([rng.uniform(0.002, 1.0, n - 60), np.full(20, 1 / 255), np.full(20, np.float32(1 / 255) * 1.0005),
+                                np.full(10, 0.99), np.full(10, 1.0)])
+    # a few degenerate conics (not positive definite / zero)
+    rec[:5, 3] = 10.0
+    rec[5:8, 2:5] = 0.0
+    assert hostsim.L.ghrsim_bbox_violations(ctypes.c_void_p(rec.ctypes.data), n, W, H) == 0
