@@ -66,6 +66,8 @@ GHR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 // SH basis values (sh_utils.py:57-112 / auxiliary.h:21-39) for a unit direction.
 GHR_HD void sh_basis(int deg, float x, float y, float z, float* b)
 {
+#pragma unroll
+    for (int k = 1; k < GHR_SH_MAX; k++) b[k] = 0.f;  // inactive coefficients contribute 0 (and get 0 gradient)
     b[0] = 0.28209479177387814f;
     if (deg > 0) {
         const float C1 = 0.4886025119029199f;
@@ -89,36 +91,40 @@ GHR_HD void sh_basis(int deg, float x, float y, float z, float* b)
         }
     }
 }
-// d(basis_k)/d(x,y,z) (cf. backward.cu:58-122, written per basis function)
-GHR_HD void sh_basis_grad(int deg, float x, float y, float z, float* dx, float* dy, float* dz)
+// sum_k v[k] * d(basis_k)/d(x,y,z)  (cf. backward.cu:58-122, written per basis function so nothing is stored)
+GHR_HD void sh_basis_grad_dot(int deg, float x, float y, float z, const float* v, float& ox, float& oy, float& oz)
 {
-    dx[0] = dy[0] = dz[0] = 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
     if (deg > 0) {
         const float C1 = 0.4886025119029199f;
-        dx[1] = 0; dy[1] = -C1; dz[1] = 0;
-        dx[2] = 0; dy[2] = 0; dz[2] = C1;
-        dx[3] = -C1; dy[3] = 0; dz[3] = 0;
+        gy += -C1 * v[1];
+        gz += C1 * v[2];
+        gx += -C1 * v[3];
         if (deg > 1) {
             const float c0 = 1.0925484305920792f, c2 = 0.31539156525252005f, c4 = 0.5462742152960396f;
-            dx[4] = c0 * y; dy[4] = c0 * x; dz[4] = 0;
-            dx[5] = 0; dy[5] = -c0 * z; dz[5] = -c0 * y;
-            dx[6] = -2.f * c2 * x; dy[6] = -2.f * c2 * y; dz[6] = 4.f * c2 * z;
-            dx[7] = -c0 * z; dy[7] = 0; dz[7] = -c0 * x;
-            dx[8] = 2.f * c4 * x; dy[8] = -2.f * c4 * y; dz[8] = 0;
+            gx += c0 * y * v[4];            gy += c0 * x * v[4];
+            gy += -c0 * z * v[5];           gz += -c0 * y * v[5];
+            gx += -2.f * c2 * x * v[6];     gy += -2.f * c2 * y * v[6];   gz += 4.f * c2 * z * v[6];
+            gx += -c0 * z * v[7];           gz += -c0 * x * v[7];
+            gx += 2.f * c4 * x * v[8];      gy += -2.f * c4 * y * v[8];
             if (deg > 2) {
                 const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                 const float k0 = -0.5900435899266435f, k1 = 2.890611442640554f, k2 = -0.4570457994644658f,
                             k3 = 0.3731763325901154f, k5 = 1.445305721320277f;
-                dx[9] = k0 * 6.f * xy; dy[9] = k0 * 3.f * (xx - yy); dz[9] = 0;
-                dx[10] = k1 * yz; dy[10] = k1 * xz; dz[10] = k1 * xy;
-                dx[11] = k2 * -2.f * xy; dy[11] = k2 * (4.f * zz - xx - 3.f * yy); dz[11] = k2 * 8.f * yz;
-                dx[12] = k3 * -6.f * xz; dy[12] = k3 * -6.f * yz; dz[12] = k3 * (6.f * zz - 3.f * xx - 3.f * yy);
-                dx[13] = k2 * (4.f * zz - 3.f * xx - yy); dy[13] = k2 * -2.f * xy; dz[13] = k2 * 8.f * xz;
-                dx[14] = k5 * 2.f * xz; dy[14] = k5 * -2.f * yz; dz[14] = k5 * (xx - yy);
-                dx[15] = k0 * 3.f * (xx - yy); dy[15] = k0 * -6.f * xy; dz[15] = 0;
+                gx += k0 * 6.f * xy * v[9];                   gy += k0 * 3.f * (xx - yy) * v[9];
+                gx += k1 * yz * v[10];                        gy += k1 * xz * v[10];       gz += k1 * xy * v[10];
+                gx += k2 * -2.f * xy * v[11];                 gy += k2 * (4.f * zz - xx - 3.f * yy) * v[11];
+                gz += k2 * 8.f * yz * v[11];
+                gx += k3 * -6.f * xz * v[12];                 gy += k3 * -6.f * yz * v[12];
+                gz += k3 * (6.f * zz - 3.f * xx - 3.f * yy) * v[12];
+                gx += k2 * (4.f * zz - 3.f * xx - yy) * v[13]; gy += k2 * -2.f * xy * v[13];
+                gz += k2 * 8.f * xz * v[13];
+                gx += k5 * 2.f * xz * v[14];                  gy += k5 * -2.f * yz * v[14]; gz += k5 * (xx - yy) * v[14];
+                gx += k0 * 3.f * (xx - yy) * v[15];           gy += k0 * -6.f * xy * v[15];
             }
         }
     }
+    ox = gx; oy = gy; oz = gz;
 }
 
 // Everything both passes need, recomputed from the raw parameters (cheaper than storing it: 61 floats in, ~300 flop).
@@ -132,10 +138,13 @@ struct ProjCtx {
     float u[3], v[3];     // T[:,0], T[:,1] with T = W @ J (gaussian_model.py:279-290)
     float p[3], r[3];     // p_i = ax_i . u, r_i = ax_i . v
     float a, b, c, det, k;  // cov2D (with +0.3), det, k = 1/(det+eps)
-    int jmax;             // longest axis (gaussian_model.py:384-388)
+    int jmax;             // longest axis (gaussian_model.py:384-388); use sel3() -- never index an array with it
+                          // (dynamic indexing sends the arrays to scratch / LDS)
     float Wc[3][3];       // Wc[c] = column c of view[:3,:3]
     float j00, j20, j11, j21, txp, typ;
 };
+
+GHR_HD float sel3(const float* v, int j) { return j == 0 ? v[0] : (j == 1 ? v[1] : v[2]); }
 
 GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
 {
@@ -194,18 +203,21 @@ GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
     c.det = c.a * c.c - c.b * c.b;
     c.k = 1.0f / (c.det + a.conic_eps);
     c.jmax = 0;  // first maximum == argsort(descending)[0] up to ties
-    if (c.s0[1] > c.s0[c.jmax]) c.jmax = 1;
-    if (c.s0[2] > c.s0[c.jmax]) c.jmax = 2;
+    float smax = c.s0[0];
+    if (c.s0[1] > smax) { c.jmax = 1; smax = c.s0[1]; }
+    if (c.s0[2] > smax) { c.jmax = 2; }
 }
 
-GHR_HD float sh_coeff(const ModelArgs& a, int idx, int k, int ch)
+// SH coefficient k (0 = DC) of channel ch.  `rest` points at THIS Gaussian's (K-1) x 3 block of features_rest (staged
+// in LDS by the kernels, global memory in the host-sim); coefficients beyond K read as 0.
+GHR_HD float sh_coeff(const ModelArgs& a, int idx, const float* rest, int k, int ch)
 {
-    return k == 0 ? a.features_dc[3 * (size_t)idx + ch]
-                  : a.features_rest[((size_t)idx * (a.sh_coeffs - 1) + (k - 1)) * 3 + ch];
+    if (k == 0) return a.features_dc[3 * (size_t)idx + ch];
+    return k < a.sh_coeffs ? rest[(k - 1) * 3 + ch] : 0.f;
 }
 
 // Forward for one Gaussian.  Returns false when culled.
-GHR_HD bool project_one(const ModelArgs& a, int idx, int& x0, int& y0, int& x1, int& y1)
+GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1)
 {
     a.radii[idx] = 0;
     a.rects[idx] = uint2{0u, 0u};
@@ -249,19 +261,19 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, int& x0, int& y0, int& x1, 
     const float dl = 1.0f / sqrtf(dxv * dxv + dyv * dyv + dzv * dzv);
     float basis[GHR_SH_MAX];
     sh_basis(a.sh_degree, dxv * dl, dyv * dl, dzv * dl, basis);
-    const int nk = (a.sh_degree + 1) * (a.sh_degree + 1);
     float rgb[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         float acc = 0.f;
-        for (int k = 0; k < nk; k++) acc += basis[k] * sh_coeff(a, idx, k, ch);
+#pragma unroll
+        for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, idx, rest, k, ch);
         rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
     }
     const float label = sigmoidf_(a.label_logit[idx]);
     const float conf = expf(a.orient_conf_log[idx]);
     const float opac = sigmoidf_(a.opacity_logit[idx]);
-    const float sj = c.s0[c.jmax];
-    const float d2x = sj * c.p[c.jmax], d2y = sj * c.r[c.jmax];
+    const float sj = sel3(c.s0, c.jmax);
+    const float d2x = sj * sel3(c.p, c.jmax), d2y = sj * sel3(c.r, c.jmax);
 
     f4* r = a.rec + 4 * (size_t)idx;
     r[0] = f4{pixx, pixy, cx, cy};
@@ -275,15 +287,14 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, int& x0, int& y0, int& x1, 
 }
 
 // Backward for one Gaussian: packed rasterizer gradients -> raw-parameter gradients.  Writes every output element.
-GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx)
+// `rest` / `d_rest`: this Gaussian's (K-1) x 3 blocks of features_rest and of its gradient (LDS in the kernel).
+GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* rest, float* d_rest)
 {
     const float* ga = g.gacc + 16 * (size_t)idx;
     const int K = a.sh_coeffs;
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
-    float dsh[GHR_SH_MAX][3];
-#pragma unroll
-    for (int k = 0; k < GHR_SH_MAX; k++) dsh[k][0] = dsh[k][1] = dsh[k][2] = 0.f;
+    float ddc[3] = {0, 0, 0};
     const float gmx = ga[0], gmy = ga[1];
     g.d_means2D[3 * idx] = gmx;
     g.d_means2D[3 * idx + 1] = gmy;
@@ -321,12 +332,13 @@ GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx)
             // d/d(log s_i): s_i = exp(ls_i) * mod  =>  ds_i/dls_i = s_i
             dls[i] = 2.f * s2 * (c.p[i] * c.p[i] * La + c.p[i] * c.r[i] * Lb + c.r[i] * c.r[i] * Lc);
         }
-        {
-            const int j = c.jmax;
-            const float sj = c.s0[j];
-            Lp[j] += sj * gc[5];
-            Lr[j] += sj * gc[6];
-            dls[j] += sj * (c.p[j] * gc[5] + c.r[j] * gc[6]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {  // dir2D = s0_j (p_j, r_j): only the longest axis j receives these terms
+            const float on = (i == c.jmax) ? 1.f : 0.f;
+            const float sj = c.s0[i] * on;
+            Lp[i] += sj * gc[5];
+            Lr[i] += sj * gc[6];
+            dls[i] += sj * (c.p[i] * gc[5] + c.r[i] * gc[6]);
         }
         // ---- p_i = ax_i . u, r_i = ax_i . v
         float G[3][3], Lu[3] = {0, 0, 0}, Lv[3] = {0, 0, 0};
@@ -387,33 +399,42 @@ GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx)
 #pragma unroll
             for (int row = 0; row < 3; row++) dxyz[row] += pm[4 * row] * Lhx + pm[4 * row + 1] * Lhy + pm[4 * row + 3] * Lhw;
         }
-        // ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz
+        // ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz.
+        // d_rest may alias rest: every element is read (cf) before it is overwritten, channel by channel.
         {
             const float dxv = mx - a.campos[0], dyv = my - a.campos[1], dzv = mz - a.campos[2];
             const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
             const float x = dxv * il, y = dyv * il, z = dzv * il;
-            float basis[GHR_SH_MAX], bx[GHR_SH_MAX], by[GHR_SH_MAX], bz[GHR_SH_MAX];
+            float basis[GHR_SH_MAX], vk[GHR_SH_MAX];
             sh_basis(a.sh_degree, x, y, z, basis);
-            sh_basis_grad(a.sh_degree, x, y, z, bx, by, bz);
-            const int nk = (a.sh_degree + 1) * (a.sh_degree + 1);
-            float Ld[3] = {0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < GHR_SH_MAX; k++) vk[k] = 0.f;
+#pragma unroll
             for (int ch = 0; ch < 3; ch++) {
+                float cf[GHR_SH_MAX];
                 float acc = 0.f;
-                for (int k = 0; k < nk; k++) acc += basis[k] * sh_coeff(a, idx, k, ch);
+#pragma unroll
+                for (int k = 0; k < GHR_SH_MAX; k++) {
+                    cf[k] = sh_coeff(a, idx, rest, k, ch);
+                    acc += basis[k] * cf[k];
+                }
                 const float gch = (acc + 0.5f >= 0.0f) ? gc[ch] : 0.f;  // clamp_min backward: grad where x >= min
-                for (int k = 0; k < nk; k++) {
-                    const float cf = sh_coeff(a, idx, k, ch);
-                    dsh[k][ch] = basis[k] * gch;
-                    Ld[0] += gch * bx[k] * cf;
-                    Ld[1] += gch * by[k] * cf;
-                    Ld[2] += gch * bz[k] * cf;
+                ddc[ch] = basis[0] * gch;
+#pragma unroll
+                for (int k = 0; k < GHR_SH_MAX; k++) {
+                    if (k > 0 && k < K) d_rest[(k - 1) * 3 + ch] = basis[k] * gch;
+                    vk[k] += gch * cf[k];
                 }
             }
+            float Ld[3];
+            sh_basis_grad_dot(a.sh_degree, x, y, z, vk, Ld[0], Ld[1], Ld[2]);
             const float dotp = Ld[0] * x + Ld[1] * y + Ld[2] * z;  // d(normalize)
             dxyz[0] += (Ld[0] - x * dotp) * il;
             dxyz[1] += (Ld[1] - y * dotp) * il;
             dxyz[2] += (Ld[2] - z * dotp) * il;
         }
+    } else {
+        for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
@@ -426,27 +447,59 @@ GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx)
     g.d_label_logit[idx] = dll;
     g.d_orient_conf_log[idx] = dlc;
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) g.d_features_dc[3 * (size_t)idx + ch] = dsh[0][ch];
-    for (int k = 1; k < K; k++)
-#pragma unroll
-        for (int ch = 0; ch < 3; ch++) g.d_features_rest[((size_t)idx * (K - 1) + (k - 1)) * 3 + ch] = dsh[k][ch];
+    for (int ch = 0; ch < 3; ch++) g.d_features_dc[3 * (size_t)idx + ch] = ddc[ch];
 }
+
+// features_rest is [P, K-1, 3]: one thread's 3(K-1) floats are contiguous but 180 B apart from its neighbour's, so
+// direct per-thread loads touch 64 cache lines per instruction.  A block's slab (256 x 3(K-1) floats) IS contiguous
+// and 16-B aligned: move it through LDS with coalesced b128 accesses; per-thread LDS reads at an odd stride (45) are
+// conflict-free.
+#define GHR_REST_MAX (3 * (GHR_SH_MAX - 1))  // 45
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void slab_copy(float* dst, const float* src, size_t n_floats, int tid)
+{
+    // src/dst start 16-B aligned (256 * 3(K-1) * 4 bytes per block is a multiple of 16); the tail is scalar
+    const size_t n4 = n_floats / 4;
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    f4* d4 = reinterpret_cast<f4*>(dst);
+    for (size_t i = tid; i < n4; i += GHR_BLOCK) d4[i] = s4[i];
+    for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
+}
+#endif
 
 __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
 {
-    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float s_rest[GHR_BLOCK * GHR_REST_MAX];
+    const int row = 3 * (a.sh_coeffs - 1);
+    const int base = blockIdx.x * GHR_BLOCK;
+    const int nb = min(GHR_BLOCK, a.P - base);
+    if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    __syncthreads();
+    const int idx = base + threadIdx.x;
     if (idx >= a.P) return;
     int x0, y0, x1, y1;
-    if (!project_one(a, idx, x0, y0, x1, y1)) return;
+    if (!project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1)) return;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+#endif
 }
 
 __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
 {
-    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
-    project_bwd_one(a, g, idx);
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float s_rest[GHR_BLOCK * GHR_REST_MAX];  // coefficients in, gradients out
+    const int row = 3 * (a.sh_coeffs - 1);
+    const int base = blockIdx.x * GHR_BLOCK;
+    const int nb = min(GHR_BLOCK, a.P - base);
+    if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    __syncthreads();
+    const int idx = base + threadIdx.x;
+    if (idx < a.P) project_bwd_one(a, g, idx, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+    __syncthreads();
+    if (row > 0) slab_copy(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x);
+#endif
 }
 
 }  // namespace ghr

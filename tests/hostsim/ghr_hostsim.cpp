@@ -198,7 +198,12 @@ void ghrsim_project_forward(const ghr::ModelArgs* a_in, float* out_rec, int* out
     std::vector<uint32_t> count((size_t)a.gx * a.gy, 0u);
     a.rec = rec.data(); a.depths = out_depths; a.rects = rects.data(); a.radii = out_radii; a.means2D = out_means2D;
     a.tile_count = count.data();
-    for (int i = 0; i < P; i++) { int x0, y0, x1, y1; out_depths[i] = 0.f; ghr::project_one(a, i, x0, y0, x1, y1); }
+    const int row = 3 * (a.sh_coeffs - 1);
+    for (int i = 0; i < P; i++) {
+        int x0, y0, x1, y1;
+        out_depths[i] = 0.f;
+        ghr::project_one(a, i, a.features_rest + (size_t)i * row, x0, y0, x1, y1);
+    }
     std::memcpy(out_rec, rec.data(), sizeof(float) * 16 * (size_t)P);
 }
 
@@ -213,7 +218,9 @@ void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const
     g.gacc = gacc; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
     g.d_features_rest = d_frest;
-    for (int i = 0; i < a.P; i++) ghr::project_bwd_one(a, g, i);
+    const int row = 3 * (a.sh_coeffs - 1);
+    for (int i = 0; i < a.P; i++)
+        ghr::project_bwd_one(a, g, i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row);
 }
 
 int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }

@@ -66,7 +66,6 @@ def test_fused_training_step_runs_and_learns():
         gt._features_dc.add_(0.3)
     make_ground_truth(gt, [cam], bg)
     opt = OptimizationParams()
-    model.training_setup(opt)
-    bucket = FlatGradBucket(model.leaf_parameters())
-    losses = [float(training_step(model, [cam], bg, opt, i + 1, bucket=bucket)) for i in range(8)]
+    model.training_setup(opt)  # FusedAdam owns the flat gradient buffer: no separate FlatGradBucket
+    losses = [float(training_step(model, [cam], bg, opt, i + 1)) for i in range(8)]
     assert losses[-1] < losses[0] and np.isfinite(losses).all()
