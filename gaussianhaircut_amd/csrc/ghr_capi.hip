@@ -218,7 +218,12 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dscales, float* dL_drotations)
 {
-    if (int rc = check_view(a)) return rc;
+    // backward reads colours / opacity from the packed records in geom_ws, not from `a`
+    if (int rc = check_dims(a)) return rc;
+    if (a->P > 0 && (!a->means3D || !a->viewmatrix || !a->projmatrix || !a->background))
+        return fail(GHR_E_INVALID, "ghr_backward: means3D/viewmatrix/projmatrix/background must be non-NULL");
+    if (a->P > 0 && !a->conic_precomp && !a->cov3D_precomp && !(a->scales && a->rotations))
+        return fail(GHR_E_INVALID, "kernel-geometry mode needs cov3D_precomp or scales+rotations");
     hipStream_t s = (hipStream_t)stream;
     if (a->P == 0) return GHR_OK;
     if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || !grad_scratch || !dL_dmeans2D ||
