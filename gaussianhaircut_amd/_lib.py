@@ -13,7 +13,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libghr_hip.so")
+LIB_PATH = os.environ.get("GHR_LIB_PATH") or os.path.join(CSRC, "libghr_hip.so")  # override: kernel experiments
 SOURCES = ["ghr_capi.hip"]
 HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h",
            "ghr_geom_bwd.h", "ghr_project.h", "ghr_loss.h", "ghr_adam.h"]

@@ -53,14 +53,14 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
     }
 }
 
-__global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const uint2* __restrict__ rects,
+__global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect4* __restrict__ rects,
                                                        const float* __restrict__ depths,
                                                        const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
                                                        uint64_t* keys)
 {
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
     if (idx >= P) return;
-    const uint2 r = rects[idx];
+    const rect4 r = rects[idx];
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
     if (x1 <= x0 || y1 <= y0) return;
     const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;

@@ -43,13 +43,13 @@ inline size_t up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 struct Geom {
     ghr::f4* rec;
     float* depths;
-    uint2* rects;
+    ghr::rect4* rects;
     float* cov3D;
 };
 struct Img {
     float* final_T;
     uint32_t* n_contrib;
-    uint32_t* tile_count;  // per-tile instance count, then append cursor
+    uint32_t* tile_count;  // [T+1]: per-tile instance count, then append cursor; [T] = gradient-slot allocator
     uint32_t* tile_start;  // [T+1]
     uint32_t* R_dev;
 };
@@ -64,7 +64,7 @@ size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
     ghr::f4* rec = (ghr::f4*)take(P * 64);
     float* depths = (float*)take(P * 4);
-    uint2* rects = (uint2*)take(P * 8);
+    ghr::rect4* rects = (ghr::rect4*)take(P * 16);
     float* cov3D = mode_b ? (float*)take(P * 24) : nullptr;
     if (g) *g = Geom{rec, depths, rects, cov3D};
     return off + ALIGN;
@@ -75,7 +75,7 @@ size_t carve_img(char* base, size_t N, size_t T, Img* im)
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
     float* final_T = (float*)take(N * 4);
     uint32_t* n_contrib = (uint32_t*)take(N * 4);
-    uint32_t* tile_count = (uint32_t*)take(T * 4);
+    uint32_t* tile_count = (uint32_t*)take((T + 1) * 4);
     uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
     uint32_t* R_dev = (uint32_t*)take(4);
     if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev};
@@ -161,7 +161,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
 
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * ((size_t)T + 1), s));
     ghr::PreArgs pa;
     pa.P = a->P; pa.W = a->W; pa.H = a->H; pa.gx = gx; pa.gy = gy;
     pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;
@@ -201,6 +201,8 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
     if (R > 0) {
+        // append cursors start at 0 (k_tile_scan left them there; re-zeroed so that stage 2 may be replayed)
+        GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.depths, im.tile_start, im.tile_count, b.keys);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
@@ -226,7 +228,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
         return fail(GHR_E_INVALID, "kernel-geometry mode needs cov3D_precomp or scales+rotations");
     hipStream_t s = (hipStream_t)stream;
     if (a->P == 0) return GHR_OK;
-    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || !grad_scratch || !dL_dmeans2D ||
+    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || (R > 0 && !grad_scratch) || !dL_dmeans2D ||
         !dL_dconic || !dL_dopacity || !dL_dcolors || !dL_dmeans3D || !dL_dcov3D || !dL_dscales || !dL_drotations)
         return fail(GHR_E_INVALID, "ghr_backward: NULL buffer");
     const bool mode_b = a->conic_precomp == nullptr;
@@ -237,12 +239,11 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
 
-    GHR_HIP(hipMemsetAsync(grad_scratch, 0, sizeof(float) * GHR_GRAD_STRIDE * (size_t)a->P, s));
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
         hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T,
                            im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib, dL_dpix,
-                           grad_scratch);
+                           g.rects, grad_scratch);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -250,7 +251,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.gacc = grad_scratch;
+    ga.ginst = grad_scratch; ga.rects = g.rects;
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
@@ -298,7 +299,7 @@ int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_w
     Geom g; Img im;
     carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * ((size_t)T + 1), s));
     a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
     a.tile_count = im.tile_count;
     hipLaunchKernelGGL(ghr::k_project, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a);
@@ -317,7 +318,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
     if (int rc = fill_model(m, &a)) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (a.P == 0) return GHR_OK;
-    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || !grad_scratch || !d_means2D || !d_xyz ||
+    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || (R > 0 && !grad_scratch) || !d_means2D || !d_xyz ||
         !d_log_scales || !d_rotations || !d_opacity_logit || !d_label_logit || !d_orient_conf_log || !d_features_dc ||
         (a.sh_coeffs > 1 && !d_features_rest))
         return fail(GHR_E_INVALID, "ghr_model_backward: NULL buffer");
@@ -326,16 +327,16 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
     carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
-    GHR_HIP(hipMemsetAsync(grad_scratch, 0, sizeof(float) * GHR_GRAD_STRIDE * (size_t)a.P, s));
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
         hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a.W, a.H, a.gx, (uint32_t)T,
                            im.tile_start, b.point_list, g.rec, m->background, im.final_T, im.n_contrib, dL_dpix,
-                           grad_scratch);
+                           g.rects, grad_scratch);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     a.radii = const_cast<int*>(radii);
+    a.rects = g.rects;
     ghr::ModelGrads mg;
-    mg.gacc = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
+    mg.ginst = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a, mg);

@@ -71,6 +71,59 @@ GHR_HD m3 transpose(const m3& a)
     return o;
 }
 
+// Per-Gaussian tile rect + gradient-slot base, one 16-B record: {x0 | x1<<16, y0 | y1<<16, inst_base, 0}.
+// The Gaussian's (y - y0) * (x1 - x0) + (x - x0)-th tile instance owns gradient slot inst_base + that ordinal
+// (k_render_bwd writes it with plain stores, the per-Gaussian backward sums the slots in ordinal order: no float
+// atomics, bit-reproducible gradients).
+typedef uint4 rect4;
+GHR_HD rect4 make_rect4(int x0, int y0, int x1, int y1, uint32_t base)
+{
+    return rect4{(uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16), base, 0u};
+}
+GHR_HD uint32_t rect4_area(const rect4& r)
+{
+    return ((r.x >> 16) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.y & 0xffffu));
+}
+// gradient slot of Gaussian `r` in tile (tx, ty); the tile must lie inside the rect
+GHR_HD uint32_t rect4_slot(const rect4& r, int tx, int ty)
+{
+    const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
+    return r.z + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
+}
+
+// Sum of a Gaussian's per-instance gradient lines in tile-ordinal order (deterministic).
+GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga)
+{
+    const uint32_t cnt = rect4_area(r);
+    const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)r.z;
+    f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    for (uint32_t k = 0; k < cnt; k++, p += 4) {
+        s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 += p[3];
+    }
+    ga[0] = s0.x; ga[1] = s0.y; ga[2] = s0.z; ga[3] = s0.w; ga[4] = s1.x; ga[5] = s1.y; ga[6] = s1.z; ga[7] = s1.w;
+    ga[8] = s2.x; ga[9] = s2.y; ga[10] = s2.z; ga[11] = s2.w; ga[12] = s3.x; ga[13] = s3.y; ga[14] = s3.z; ga[15] = s3.w;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Wave-aggregated allocation of n (per lane, may be 0) consecutive units from *counter: one atomic per wavefront.
+// Every lane of the wave must call it.
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t n, uint32_t* counter)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(counter, total);
+    base = (uint32_t)__shfl((int)base, 63);
+    return base + incl - n;
+}
+#endif
+
 // ---- chip mapping ----------------------------------------------------------------------------------------------------
 
 // Workgroup b is dispatched to XCD b % 8 (observed, speed only).  Give every XCD one contiguous run of

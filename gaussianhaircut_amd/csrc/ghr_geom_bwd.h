@@ -21,7 +21,8 @@ struct GeomBwdArgs {
     const float* view;
     const float* proj;
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
-    const float* gacc;  // [P][16]
+    const float* ginst;  // [R][16] per-instance packed gradients (slots: rect4_slot)
+    const rect4* rects;
     float* dL_dmeans2D;  // [P][3]
     float* dL_dconic;    // [P][4]
     float* dL_dopacity;  // [P]
@@ -71,9 +72,8 @@ GHR_HD void cov3d_bwd(const float* s3, float mod, const float* q4, const float* 
 #undef GHR_D
 }
 
-GHR_HD void geom_bwd_one(const GeomBwdArgs& a, int idx)
+GHR_HD void geom_bwd_one(const GeomBwdArgs& a, int idx, const float* g)
 {
-    const float* g = a.gacc + 16 * (size_t)idx;
     const float gmx = g[0], gmy = g[1], gca = g[2], gcb = g[3], gcc = g[4];
     a.dL_dmeans2D[3 * idx] = gmx;
     a.dL_dmeans2D[3 * idx + 1] = gmy;
@@ -171,7 +171,9 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_geom_bwd(GeomBwdArgs a)
 {
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
     if (idx >= a.P) return;
-    geom_bwd_one(a, idx);
+    float ga[16];
+    gather_inst_grads(a.ginst, a.rects[idx], ga);
+    geom_bwd_one(a, idx, ga);
 }
 
 }  // namespace ghr

@@ -23,10 +23,10 @@ struct PreArgs {
     // outputs
     f4* rec;
     float* depths;
-    uint2* rects;
+    rect4* rects;
     float* cov3D;  // mode B only
     int* radii;
-    uint32_t* tile_count;
+    uint32_t* tile_count;  // [T] per-tile instance counts, [T] (one past) = gradient-slot allocation counter
 };
 
 // forward.cu:118-152.  The quaternion is used as given (normalisation is commented out at :127).
@@ -88,7 +88,7 @@ GHR_HD void cov2d_eval(const Cov2DCtx& c, float& a, float& b, float& d)
 GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1, int& y1)
 {
     a.radii[idx] = 0;  // forward.cu:190-191
-    a.rects[idx] = uint2{0u, 0u};
+    a.rects[idx] = rect4{0u, 0u, 0u, 0u};
 
     const float mx = a.means3D[3 * idx], my = a.means3D[3 * idx + 1], mz = a.means3D[3 * idx + 2];
     float vx, vy, vz;
@@ -155,20 +155,24 @@ GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1,
     r[3] = f4{col[6], col[7], col[8], col[9]};
     a.depths[idx] = vz;
     a.radii[idx] = (int)my_radius;
-    a.rects[idx] = uint2{(uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16)};
+    a.rects[idx] = make_rect4(x0, y0, x1, y1, 0u);  // the caller fills in the gradient-slot base
     return true;
 }
 
 __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
-    int x0, y0, x1, y1;
-    if (!preprocess_one(a, idx, x0, y0, x1, y1)) return;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    const bool ok = idx < a.P && preprocess_one(a, idx, x0, y0, x1, y1);
+    const uint32_t base = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
+    if (!ok) return;
+    a.rects[idx].z = base;
     // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
     // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+#endif
 }
 
 // rasterizer_impl.cu:54-66 (checkFrustum): only the near test is live (auxiliary.h:154).

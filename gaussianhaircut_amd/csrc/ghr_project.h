@@ -42,14 +42,14 @@ struct ModelArgs {
     // forward outputs
     f4* rec;
     float* depths;
-    uint2* rects;
+    rect4* rects;
     int* radii;
     float* means2D;  // [P,3] NDC (viewspace_points values), may be null
-    uint32_t* tile_count;
+    uint32_t* tile_count;  // [T] counts, [T] (one past) = gradient-slot allocation counter
 };
 
 struct ModelGrads {
-    const float* gacc;  // [P][16] packed gradients from k_render_bwd
+    const float* ginst;  // [R][16] per-instance packed gradients from k_render_bwd (slots: rect4_slot)
     float* d_means2D;   // [P,3]  dL/d(NDC mean) (densification signal), z = 0
     float* d_xyz;       // [P,3]
     float* d_log_scales;// [P,3]
@@ -220,7 +220,7 @@ GHR_HD float sh_coeff(const ModelArgs& a, int idx, const float* rest, int k, int
 GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1)
 {
     a.radii[idx] = 0;
-    a.rects[idx] = uint2{0u, 0u};
+    a.rects[idx] = rect4{0u, 0u, 0u, 0u};
     ProjCtx c;
     proj_setup(a, idx, c);
     const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
@@ -282,15 +282,16 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
     r[3] = f4{d2y, 0.0f, conf, c.t[2]};
     a.depths[idx] = c.t[2];
     a.radii[idx] = (int)my_radius;
-    a.rects[idx] = uint2{(uint32_t)x0 | ((uint32_t)x1 << 16), (uint32_t)y0 | ((uint32_t)y1 << 16)};
+    a.rects[idx] = make_rect4(x0, y0, x1, y1, 0u);  // the caller fills in the gradient-slot base
     return true;
 }
 
-// Backward for one Gaussian: packed rasterizer gradients -> raw-parameter gradients.  Writes every output element.
+// Backward for one Gaussian: packed rasterizer gradients `ga[16]` (already summed over the Gaussian's tile instances)
+// -> raw-parameter gradients.  Writes every output element.
 // `rest` / `d_rest`: this Gaussian's (K-1) x 3 blocks of features_rest and of its gradient (LDS in the kernel).
-GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* rest, float* d_rest)
+GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
+                            float* d_rest)
 {
-    const float* ga = g.gacc + 16 * (size_t)idx;
     const int K = a.sh_coeffs;
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
@@ -478,9 +479,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     const int idx = base + threadIdx.x;
-    if (idx >= a.P) return;
-    int x0, y0, x1, y1;
-    if (!project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1)) return;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    const bool ok = idx < a.P && project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1);
+    const uint32_t slot0 = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
+    if (!ok) return;
+    a.rects[idx].z = slot0;
     for (int y = y0; y < y1; y++)
         for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
 #endif
@@ -496,7 +499,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     const int idx = base + threadIdx.x;
-    if (idx < a.P) project_bwd_one(a, g, idx, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+    if (idx < a.P) {
+        float ga[16];
+        gather_inst_grads(g.ginst, a.rects[idx], ga);
+        project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+    }
     __syncthreads();
     if (row > 0) slab_copy(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x);
 #endif

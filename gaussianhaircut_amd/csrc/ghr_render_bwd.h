@@ -7,8 +7,11 @@
 //        v_permlane32_swap (16 -> 8 regs), v_permlane16_swap (8 -> 4), DPP row_ror:8 (4 -> 2), DPP row_half_mirror
 //        (2 -> 1), then two DPP quad_perm adds; lane 4*c ends up holding the wave's total of component c (~35 VALU),
 //   2. accumulated across the tile's 4 wavefronts with one 16-lane ds_add_f32 into a per-batch LDS table,
-//   3. flushed once per (tile, Gaussian) with 16 global_atomic_add_f32 into ONE 64-byte gradient line.
-// => 16 global atomics per Gaussian-tile INSTANCE instead of per pixel-Gaussian pair (up to 256x fewer).
+//   3. written once per (tile, Gaussian) INSTANCE as one 64-byte line (4 plain b128 stores) into the instance's own
+//      gradient slot (rect4_slot); the per-Gaussian backward sums a Gaussian's slots in a fixed order.
+// => no global float atomics at all: the 16 dword-granular device-scope atomics per instance (measured: 40 % of this
+//    kernel's time on MI355X, every one a fabric transaction) are gone, and the cross-tile sum has a fixed order (the
+//    only order-dependent float sums left are the 4-wave ds_add_f32 accumulations inside one tile).
 //
 // The per-channel recurrences of the reference (accum_rec[ch], last_color[ch], backward.cu:519-523) are linear in the
 // channel index and only ever used through sum_ch(. * dL_dpixel[ch]); they are carried as ONE scalar
@@ -120,11 +123,12 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                                                           const f4* __restrict__ rec, const float* __restrict__ bg,
                                                           const float* __restrict__ final_T,
                                                           const uint32_t* __restrict__ n_contrib,
-                                                          const float* __restrict__ dL_dpix, float* gacc)
+                                                          const float* __restrict__ dL_dpix,
+                                                          const rect4* __restrict__ rects, float* ginst)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
-    __shared__ uint32_t s_id[GHR_BLOCK];
+    __shared__ uint32_t s_slot[GHR_BLOCK];
     __shared__ float s_acc[GHR_BLOCK * 16];
     __shared__ uint32_t s_max[4];
 
@@ -176,7 +180,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)id;
             const f4 a0 = r[0], a1 = r[1];
-            s_id[tid] = id;
+            s_slot[tid] = rect4_slot(rects[id], tx, ty);
             s_r0[tid] = a0; s_r1[tid] = a1; s_r2[tid] = r[2]; s_r3[tid] = r[3];
             s_bb[tid] = alpha_bbox(a0, a1);
         }
@@ -210,21 +214,18 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         }
         __syncthreads();
 
-        if ((uint32_t)tid < cnt) {
+        if ((uint32_t)tid < cnt) {  // every staged instance writes its line (zeros when nothing contributed)
             const f4* a4 = reinterpret_cast<const f4*>(s_acc) + 4 * tid;
-            const f4 a0 = a4[0], a1 = a4[1], a2 = a4[2], a3 = a4[3];
-            const float v[16] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w,
-                                 a2.x, a2.y, a2.z, a2.w, a3.x, a3.y, a3.z, a3.w};
-            bool any = false;
-#pragma unroll
-            for (int i = 0; i < 16; i++) any |= (v[i] != 0.f);
-            if (any) {
-                float* dst = gacc + 16 * (size_t)s_id[tid];
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    if (v[i] != 0.f) atomicAdd(dst + i, v[i]);  // global_atomic_add_f32 (no return)
-            }
+            f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)s_slot[tid];
+            dst[0] = a4[0]; dst[1] = a4[1]; dst[2] = a4[2]; dst[3] = a4[3];
         }
+    }
+    // list entries no pixel of the tile ever reached (positions >= n_eff): their slots must read as zero
+    for (uint32_t i = n_eff + tid; i < n; i += GHR_BLOCK) {
+        const uint32_t id = point_list[beg + i];
+        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)rect4_slot(rects[id], tx, ty);
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
     }
 #endif
 }

@@ -196,7 +196,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_conic = torch.empty((P, 2, 2), **f32)
             grad_scales = torch.empty((P, 3), **f32)
             grad_rotations = torch.empty((P, 4), **f32)
-            scratch = torch.empty((P, _lib.GRAD_STRIDE), **f32)
+            scratch = torch.empty((max(int(num_rendered), 1), _lib.GRAD_STRIDE), **f32)  # one line per instance
             dL = grad_out_color
             if dL.dtype != torch.float32:
                 dL = dL.float()

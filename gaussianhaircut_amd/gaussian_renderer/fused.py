@@ -84,7 +84,7 @@ class _RenderModelFused(torch.autograd.Function):
             d_conf = torch.empty((P, 1), **f32)
             d_fdc = torch.empty((P, 1, 3), **f32)
             d_frest = torch.empty((P, K - 1, 3), **f32)
-            scratch = torch.empty((P, _lib.GRAD_STRIDE), **f32)
+            scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)  # one line per instance
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])

@@ -38,10 +38,10 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 1
+#define GHR_ABI_VERSION 2
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
-#define GHR_GRAD_STRIDE 16  /* floats per Gaussian in the packed gradient scratch of ghr_backward */
+#define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
 
 #define GHR_OK 0
 #define GHR_E_INVALID (-1)  /* bad argument (NULL where required, C != GHR_NUM_CHANNELS, ...) */
@@ -90,7 +90,9 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
                        float* out_color);
 
-/* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  grad_scratch: GHR_GRAD_STRIDE*P floats, zeroed by the call.
+/* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  grad_scratch: GHR_GRAD_STRIDE*R floats (one 64-B gradient line per
+ * Gaussian-tile instance, R as returned by stage 1; may be NULL when R == 0), uninitialised on entry: every line is
+ * written by K8 with plain stores and summed per Gaussian in a fixed order -- no global float atomics.
  * Outputs (all fully written, no pre-zeroing needed), shapes of rasterize_points.cu:160-168:
  *   dL_dmeans2D [P,3] (z = 0), dL_dconic [P,2,2] ([0][0], [0][1] = HALF of d/db as in backward.cu:554, [1][1]),
  *   dL_dopacity [P], dL_dcolors [P,C], dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dscales [P,3], dL_drotations [P,4]. */
@@ -177,7 +179,7 @@ int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, voi
 typedef struct ghr_ws_view {
     const float* rec;          /* [P][16]: x, y, conic a, b, c, opacity, features[10] */
     const float* depths;       /* [P] */
-    const uint32_t* rects;     /* [P][2]: (xmin | xmax<<16), (ymin | ymax<<16) */
+    const uint32_t* rects;     /* [P][4]: (xmin | xmax<<16), (ymin | ymax<<16), first gradient slot, 0 */
     const float* cov3D;        /* [P][6] (mode B) or NULL */
     const float* final_T;      /* [H*W] */
     const uint32_t* n_contrib; /* [H*W] */

@@ -81,7 +81,7 @@ class GpuRun:
         return dict(
             rec=_slice(self.geom, v.rec, 64 * P, torch.float32).numpy().reshape(P, 16),
             depths=_slice(self.geom, v.depths, 4 * P, torch.float32).numpy(),
-            rects=_slice(self.geom, v.rects, 8 * P, torch.int32).numpy().view(np.uint32).reshape(P, 2),
+            rects=_slice(self.geom, v.rects, 16 * P, torch.int32).numpy().view(np.uint32).reshape(P, 4),
             final_T=_slice(self.img, v.final_T, 4 * N, torch.float32).numpy(),
             n_contrib=_slice(self.img, v.n_contrib, 4 * N, torch.int32).numpy().view(np.uint32),
             tile_start=_slice(self.img, v.tile_start, 4 * (T + 1), torch.int32).numpy().view(np.uint32),
@@ -98,7 +98,7 @@ class GpuRun:
                  dL_dopacity=torch.full((P, 1), nan, **f), dL_dcolors=torch.full((P, 10), nan, **f),
                  dL_dmeans3D=torch.full((P, 3), nan, **f), dL_dcov3D=torch.full((P, 6), nan, **f),
                  dL_dscales=torch.full((P, 3), nan, **f), dL_drotations=torch.full((P, 4), nan, **f))
-        scratch = torch.full((P, 16), nan, **f)
+        scratch = torch.full((max(self.R, 1), 16), nan, **f)
         dL = dL.to(dev).float().contiguous()
         _lib.check(self.L.ghr_backward(_stream(), ctypes.byref(self.args), self.R, _ptr(self.radii), _ptr(self.geom),
                                        _ptr(self.img), _ptr(self.bin) if self.R else None, _ptr(dL), _ptr(scratch),

@@ -25,7 +25,7 @@ struct Sim {
     bool mode_b;
     std::vector<ghr::f4> rec;
     std::vector<float> depths, cov3D, final_T;
-    std::vector<uint2> rects;
+    std::vector<ghr::rect4> rects;
     std::vector<int> radii;
     std::vector<uint32_t> tile_start, point_list, n_contrib;
     std::vector<uint64_t> keys;
@@ -44,10 +44,11 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
     const int P = a->P, T = s->T;
     s->rec.assign((size_t)4 * P, ghr::f4{0, 0, 0, 0});
     s->depths.assign(P, 0.f);
-    s->rects.assign(P, uint2{0u, 0u});
+    s->rects.assign(P, ghr::rect4{0u, 0u, 0u, 0u});
     s->cov3D.assign((size_t)6 * P, 0.f);
     s->radii.assign(P, 0);
     std::vector<uint32_t> count(T, 0u);
+    uint32_t slot_alloc = 0;
 
     ghr::PreArgs pa;
     pa.P = P; pa.W = a->W; pa.H = a->H; pa.gx = s->gx; pa.gy = s->gy;
@@ -62,6 +63,8 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
     for (int idx = 0; idx < P; idx++) {
         int x0, y0, x1, y1;
         if (!ghr::preprocess_one(pa, idx, x0, y0, x1, y1)) continue;
+        s->rects[idx].z = slot_alloc;  // k_preprocess: wave_alloc on the slot counter (any disjoint assignment is valid)
+        slot_alloc += (uint32_t)((x1 - x0) * (y1 - y0));
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) count[y * s->gx + x]++;
     }
@@ -74,7 +77,7 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
     s->point_list.assign(s->R, 0u);
     std::vector<uint32_t> cursor(T, 0u);
     for (int idx = P - 1; idx >= 0; idx--) {
-        const uint2 r = s->rects[idx];
+        const ghr::rect4 r = s->rects[idx];
         const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
         if (x1 <= x0 || y1 <= y0) continue;
         uint32_t db;
@@ -139,7 +142,9 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     Sim* s = (Sim*)h;
     const int P = s->P, T = s->T;
     const size_t N = (size_t)a->W * a->H;
-    std::vector<double> acc((size_t)16 * P, 0.0);  // the GPU sums in fp32 atomics; order-free reference sum here
+    // one 64-B line per Gaussian-tile instance (rect4_slot), as k_render_bwd writes them; the per-pixel sum inside
+    // an instance is order-free on the GPU (wave butterfly + ds_add), so it is accumulated in double here
+    std::vector<double> acc((size_t)16 * s->R, 0.0);
     const float ddelx_dx = 0.5f * a->W, ddely_dy = 0.5f * a->H;
     for (int t = 0; t < T; t++) {
         const int tx = t % s->gx, ty = t / s->gx;
@@ -166,23 +171,29 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                     if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_bwd's strip cull
                 }
                 float g[16];
-                if (ghr::bwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g))
-                    for (int i = 0; i < 16; i++) acc[(size_t)16 * id + i] += (double)g[i];
+                if (ghr::bwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g)) {
+                    const size_t slot = ghr::rect4_slot(s->rects[id], tx, ty);
+                    for (int i = 0; i < 16; i++) acc[16 * slot + i] += (double)g[i];
+                }
             }
         }
     }
-    std::vector<float> gacc((size_t)16 * P);
-    for (size_t i = 0; i < gacc.size(); i++) gacc[i] = (float)acc[i];
+    std::vector<float> ginst((size_t)16 * s->R + 16);
+    for (size_t i = 0; i < acc.size(); i++) ginst[i] = (float)acc[i];
     ghr::GeomBwdArgs ga;
     ga.P = P; ga.means3D = a->means3D; ga.radii = s->radii.data(); ga.scales = a->scales; ga.rotations = a->rotations;
     ga.cov3D = s->cov3D.data(); ga.conic_precomp = a->conic_precomp; ga.view = a->viewmatrix; ga.proj = a->projmatrix;
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.gacc = gacc.data();
+    ga.ginst = ginst.data(); ga.rects = s->rects.data();
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
-    for (int idx = 0; idx < P; idx++) ghr::geom_bwd_one(ga, idx);
+    for (int idx = 0; idx < P; idx++) {
+        float g16[16];
+        ghr::gather_inst_grads(ga.ginst, ga.rects[idx], g16);
+        ghr::geom_bwd_one(ga, idx, g16);
+    }
 }
 
 // ---- fused projection (ghr_project.h): forward state + colours, and raw-parameter gradients from packed gacc ----
@@ -194,7 +205,7 @@ void ghrsim_project_forward(const ghr::ModelArgs* a_in, float* out_rec, int* out
     const int P = a.P;
     a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
     std::vector<ghr::f4> rec((size_t)4 * P, ghr::f4{0, 0, 0, 0});
-    std::vector<uint2> rects(P);
+    std::vector<ghr::rect4> rects(P);
     std::vector<uint32_t> count((size_t)a.gx * a.gy, 0u);
     a.rec = rec.data(); a.depths = out_depths; a.rects = rects.data(); a.radii = out_radii; a.means2D = out_means2D;
     a.tile_count = count.data();
@@ -215,12 +226,12 @@ void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const
     a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
     a.radii = const_cast<int*>(radii);
     ghr::ModelGrads g;
-    g.gacc = gacc; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
+    g.ginst = nullptr; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
     g.d_features_rest = d_frest;
     const int row = 3 * (a.sh_coeffs - 1);
     for (int i = 0; i < a.P; i++)
-        ghr::project_bwd_one(a, g, i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row);
+        ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row);
 }
 
 int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }
