@@ -180,4 +180,20 @@ GHR_HD bool bbox_hits(const f4& bb, float x0, float x1, float y0, float y1)
     return !(bb.y < x0 || bb.x > x1 || bb.w < y0 || bb.z > y1);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// Per-lane 64-bit list of the batch entries sub..sub+63 whose alpha box touches this lane's cell: lane L tests entry
+// sub+L against the wave's four cells (x ranges cx0[g]..cx0[g]+3, shared y range), four ballots, and every lane
+// keeps the ballot of its own group.
+__device__ __forceinline__ unsigned long long cell_masks(const f4& bb, bool valid, float wx0, float cy0, float cy1,
+                                                         int grp)
+{
+    const bool yhit = valid && !(bb.w < cy0 || bb.z > cy1);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 || bb.x > wx0 + 3.0f));
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 4.0f || bb.x > wx0 + 7.0f));
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 8.0f || bb.x > wx0 + 11.0f));
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 12.0f || bb.x > wx0 + 15.0f));
+    return grp == 0 ? m0 : (grp == 1 ? m1 : (grp == 2 ? m2 : m3));
+}
+#endif
+
 }  // namespace ghr

@@ -2,21 +2,28 @@
 // Follows R:cuda_rasterizer/backward.cu:403-561 (renderCUDA).
 //
 // The reference issues 16 global atomicAdds per contributing (pixel, Gaussian) pair (backward.cu:527,549-558).
-// Here the 16 gradient components {mean2D.x, .y, conic.a, .b, .c, opacity, colors[10]} of one list entry are
-//   1. reduced across the 64 lanes of a wavefront with a register "halving butterfly":
-//        v_permlane32_swap (16 -> 8 regs), v_permlane16_swap (8 -> 4), DPP row_ror:8 (4 -> 2), DPP row_half_mirror
-//        (2 -> 1), then two DPP quad_perm adds; lane 4*c ends up holding the wave's total of component c (~35 VALU),
-//   2. accumulated across the tile's 4 wavefronts with one 16-lane ds_add_f32 into a per-batch LDS table,
+// Here (same "cell group" mapping as k_render_fwd: wave = 16x4 pixel strip, each 16-lane DPP row = one 4x4 cell
+// walking its own list of the batch entries whose alpha box touches the cell) the 16 gradient components
+// {mean2D.x, .y, conic.a, .b, .c, opacity, colors[10]} of one list entry are
+//   1. reduced across the 16 lanes of the cell with a register "halving butterfly" of DPP row operations
+//      (row_ror:8, row_half_mirror, quad_perm): 16 -> 8 -> 4 -> 2 -> 1 values per lane, lane l ends up holding the
+//      cell's total of component l (45 VALU, no LDS, no cross-row traffic),
+//   2. accumulated across the tile's 16 cells with one ds_add_f32 per lane into a per-batch LDS table,
 //   3. written once per (tile, Gaussian) INSTANCE as one 64-byte line (4 plain b128 stores) into the instance's own
 //      gradient slot (rect4_slot); the per-Gaussian backward sums a Gaussian's slots in a fixed order.
 // => no global float atomics at all: the 16 dword-granular device-scope atomics per instance (measured: 40 % of this
 //    kernel's time on MI355X, every one a fabric transaction) are gone, and the cross-tile sum has a fixed order (the
-//    only order-dependent float sums left are the 4-wave ds_add_f32 accumulations inside one tile).
+//    only order-dependent float sums left are the ds_add_f32 accumulations inside one tile).
 //
 // The per-channel recurrences of the reference (accum_rec[ch], last_color[ch], backward.cu:519-523) are linear in the
 // channel index and only ever used through sum_ch(. * dL_dpixel[ch]); they are carried as ONE scalar
 //   S = sum_ch accum_rec[ch]*dL_dpixel[ch],   S <- last_alpha*last_cdot + (1-last_alpha)*S,  cdot = sum_ch c[ch]*dL[ch]
 // which is the same real-number value (fp32 rounding differs at the 1e-7 level) and frees 20 VGPRs.
+//
+// bwd_step is branch-free: a pair that does not contribute (position >= n_contrib, power > 0, alpha < 1/255) runs the
+// same arithmetic with alpha = G = 0, which leaves T untouched (T * rcp(1) == T), turns the S update into the exact
+// flush S <- last_alpha*last_cdot + (1-last_alpha)*S the next contributing entry would have performed (then
+// S <- 0*x + 1*S, exact), and makes all 16 gradient terms exact zeros -- no divergence, no zero-fill of g[].
 #pragma once
 #include "ghr_device.h"
 
@@ -27,18 +34,20 @@ struct PixBwd {
     float dL[GHR_C];
 };
 
-// One list entry applied to one pixel (backward.cu:494-558).  Writes the 16 per-pair gradient terms to g[] and
-// returns true if the pair contributes; g[] is untouched otherwise.
-GHR_HD bool bwd_step(PixBwd& s, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2, const f4& r3,
-                     float ddelx_dx, float ddely_dy, float* g)
+// One list entry applied to one pixel (backward.cu:494-558).  `live` = the entry lies below the pixel's n_contrib
+// (backward.cu:490-492).  Always writes the 16 per-pair gradient terms to g[] (exact zeros when the pair does not
+// contribute) and returns whether it contributed.
+GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2,
+                     const f4& r3, float ddelx_dx, float ddely_dy, float* g)
 {
     const float dx = r0.x - pxf, dy = r0.y - pyf;
     const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // unfused (decision input)
-    if (power > 0.0f) return false;
-    const float G = fast_exp(power);
+    const float G_raw = fast_exp(power);
     const float o = r1.y;
-    const float alpha = fminf(0.99f, o * G);
-    if (alpha < 1.0f / 255.0f) return false;
+    const float alpha_raw = fminf(0.99f, o * G_raw);
+    const bool c = live && !(power > 0.0f) && !(alpha_raw < 1.0f / 255.0f);
+    const float alpha = c ? alpha_raw : 0.0f;
+    const float G = c ? G_raw : 0.0f;
 
     const float inv1ma = fast_rcp(1.f - alpha);
     s.T = s.T * inv1ma;  // backward.cu:507
@@ -72,48 +81,46 @@ GHR_HD bool bwd_step(PixBwd& s, float pxf, float pyf, const f4& r0, const f4& r1
     g[4] = -0.5f * gdy * dy * dL_dG;     // :555
     g[5] = G * dL_dalpha;                // :558
 #pragma unroll
-    for (int c = 0; c < GHR_C; c++) g[6 + c] = w * s.dL[c];  // :508,:527
-    return true;
+    for (int i = 0; i < GHR_C; i++) g[6 + i] = w * s.dL[i];  // :508,:527
+    return c;
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float dpp_add(float v, int ctrl_sel)
+// value of `v` in the DPP partner lane.  ctrl: 0 = row_ror:8 (l ^ 8), 1 = row_half_mirror (l ^ 7),
+// 2 = quad_perm [2,3,0,1] (l ^ 2), 3 = quad_perm [1,0,3,2] (l ^ 1)
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v)
 {
-    // ctrl: 0 = row_ror:8, 1 = row_half_mirror, 2 = quad_perm [2,3,0,1], 3 = quad_perm [1,0,3,2]
-    uint32_t u = __float_as_uint(v), p;
-    switch (ctrl_sel) {
-        case 0: p = __builtin_amdgcn_update_dpp(0u, u, 0x128, 0xf, 0xf, false); break;
-        case 1: p = __builtin_amdgcn_update_dpp(0u, u, 0x141, 0xf, 0xf, false); break;
-        case 2: p = __builtin_amdgcn_update_dpp(0u, u, 0x4E, 0xf, 0xf, false); break;
-        default: p = __builtin_amdgcn_update_dpp(0u, u, 0xB1, 0xf, 0xf, false); break;
-    }
-    return v + __uint_as_float(p);
+    constexpr int ctrl = CTRL == 0 ? 0x128 : (CTRL == 1 ? 0x141 : (CTRL == 2 ? 0x4E : 0xB1));
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), ctrl, 0xf, 0xf, false));
 }
 
-// Sum 16 per-lane values over the 64 lanes of the wave.  On return lane L holds the total of component
-// comp(L) = 8*b5 + 4*b4 + 2*b3 + b2 (b_i = bit i of L), replicated over the 4 lanes of its quad.
-__device__ __forceinline__ float wave_reduce16(const float* g, int lane)
+// Sum 16 per-lane values over the 16 lanes of a DPP row.  On return lane l (0..15 within its row) holds the row's
+// total of component l.  Each stage pairs a lane with a partner that differs in one more bit of l, keeps half of its
+// values and receives the partner's copy of the same half: 8 + 4 + 2 + 1 exchanges.
+__device__ __forceinline__ float row_reduce16(const float* g, int l)
 {
+    const bool b3 = (l & 8) != 0, b2 = (l & 4) != 0, b1 = (l & 2) != 0, b0 = (l & 1) != 0;
     float h[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {  // lanes 0-31 keep component i, lanes 32-63 keep component 8+i
-        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(g[i]), __float_as_uint(g[8 + i]), false, false);
-        h[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int i = 0; i < 8; i++) {  // partner l ^ 8; lanes with b3 keep components 8..15
+        const float keep = b3 ? g[8 + i] : g[i], send = b3 ? g[i] : g[8 + i];
+        h[i] = keep + dpp_get<0>(send);
     }
     float q[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {  // even rows keep h[i], odd rows keep h[4+i]
-        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[i]), __float_as_uint(h[4 + i]), false, false);
-        q[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    for (int i = 0; i < 4; i++) {  // partner l ^ 7 (flips b2); lanes with b2 keep the upper 4 of their 8
+        const float keep = b2 ? h[4 + i] : h[i], send = b2 ? h[i] : h[4 + i];
+        q[i] = keep + dpp_get<1>(send);
     }
-    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-    float d0 = dpp_add(q[0], 0), d1 = dpp_add(q[1], 0), d2 = dpp_add(q[2], 0), d3 = dpp_add(q[3], 0);
-    const float e0 = b3 ? d2 : d0, e1 = b3 ? d3 : d1;  // lanes with bit3 keep q[2],q[3]
-    const float f0 = dpp_add(e0, 1), f1 = dpp_add(e1, 1);
-    float v = b2 ? f1 : f0;  // lanes with bit2 keep e1
-    v = dpp_add(v, 2);
-    v = dpp_add(v, 3);
-    return v;
+    float e[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {  // partner l ^ 2
+        const float keep = b1 ? q[2 + i] : q[i], send = b1 ? q[i] : q[2 + i];
+        e[i] = keep + dpp_get<2>(send);
+    }
+    const float keep = b0 ? e[1] : e[0], send = b0 ? e[0] : e[1];  // partner l ^ 1
+    return keep + dpp_get<3>(send);
 }
 #endif
 
@@ -134,13 +141,14 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int px = tx * GHR_TILE_X + (tid & 15), py = ty * GHR_TILE_Y + (tid >> 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l = lane & 15;
+    // this lane's pixel: cell (wave, grp) of the tile, 4x4 pixels, lane l -> (l & 3, l >> 2)
+    const int px = tx * GHR_TILE_X + 4 * grp + (l & 3), py = ty * GHR_TILE_Y + 4 * wave + (l >> 2);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
-    const float sx0 = (float)(tx * GHR_TILE_X), sx1 = sx0 + 15.0f;
-    const float sy0 = (float)(ty * GHR_TILE_Y + 4 * wave), sy1 = sy0 + 3.0f;
+    const float wx0 = (float)(tx * GHR_TILE_X);
+    const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave), cy1 = cy0 + 3.0f;
 
     const uint32_t beg = tile_start[tile];
     const uint32_t n = tile_start[tile + 1] - beg;
@@ -160,17 +168,16 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     }
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // backward.cu:464-465
 
-    // Entries at list positions >= max_pixels(n_contrib) are skipped by every pixel (backward.cu:490-492): start
-    // the walk there instead of at the end of the list.
-    uint32_t m = last_contributor;
+    // Entries at list positions >= max(n_contrib) are skipped by every pixel concerned (backward.cu:490-492):
+    // the tile starts its walk at the tile maximum, and every cell drops the entries above its own maximum.
+    uint32_t gmax = last_contributor;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+    for (int off = 8; off >= 1; off >>= 1) gmax = max(gmax, (uint32_t)__shfl_xor((int)gmax, off));
+    uint32_t m = max(gmax, (uint32_t)__shfl_xor((int)gmax, 16));
+    m = max(m, (uint32_t)__shfl_xor((int)m, 32));
     if (lane == 0) s_max[wave] = m;
     __syncthreads();
     const uint32_t n_eff = min(n, max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3])));
-
-    // component handled by this lane after wave_reduce16
-    const int comp = ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
 
     for (uint32_t base = 0; base < n_eff; base += GHR_BLOCK) {
         const uint32_t cnt = min((uint32_t)GHR_BLOCK, n_eff - base);
@@ -191,25 +198,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         }
         __syncthreads();
 
-        // per-wave ordered list (ballot mask) of the entries whose alpha>=1/255 box touches this wave's 16x4 strip
         for (uint32_t sub = 0; sub < cnt; sub += 64) {
+            // per-GROUP ordered list (64-bit mask) of the entries whose alpha >= 1/255 box touches the group's cell
             const uint32_t e = sub + lane;
-            const bool hit = e < cnt && bbox_hits(s_bb[e], sx0, sx1, sy0, sy1);
-            unsigned long long todo = __builtin_amdgcn_ballot_w64(hit);
-            while (todo) {
+            unsigned long long todo = cell_masks(s_bb[e < cnt ? e : 0], e < cnt, wx0, cy0, cy1, grp);
+            // entry j sits at list position n_eff-1-(base+j); positions >= gmax are dead for this cell
+            const long long jmin = (long long)n_eff - (long long)gmax - (long long)(base + sub);
+            if (jmin > 0) todo = jmin >= 64 ? 0ull : (todo & (~0ull << jmin));
+            while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
                 float g[16];
-#pragma unroll
-                for (int i = 0; i < 16; i++) g[i] = 0.f;
-                bool c = false;
-                if (pos < last_contributor)
-                    c = bwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
-                if (__builtin_amdgcn_ballot_w64(c) != 0) {  // wave-uniform
-                    const float v = wave_reduce16(g, lane);
-                    if ((lane & 3) == 0) atomicAdd(&s_acc[j * 16 + comp], v);  // ds_add_f32, 16 lanes, 16 banks
-                }
+                bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy,
+                         g);
+                const float v = row_reduce16(g, l);
+                atomicAdd(&s_acc[j * 16 + l], v);  // ds_add_f32: lane l adds component l of the cell's total
             }
         }
         __syncthreads();

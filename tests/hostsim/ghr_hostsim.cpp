@@ -109,10 +109,11 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
             st.T = 1.f; st.last = 0;
             for (int c = 0; c < GHR_C; c++) st.C[c] = 0.f;
             bool done = false;
-            const float sx0 = (float)(tx * 16), sx1 = sx0 + 15.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
+            // k_render_fwd's cull: the 4x4-pixel cell this pixel belongs to
+            const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sx1 = sx0 + 3.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
             for (uint32_t j = 0; j < n && !done; j++) {
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)s->point_list[beg + j];
-                if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_fwd's strip cull
+                if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_fwd's cell cull
                 done = ghr::fwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
             }
             const size_t pix = (size_t)a->W * py + px;
@@ -161,17 +162,24 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                 st.bgdot = ghr::fma_(a->background[c], st.dL[c], st.bgdot);
             }
             const uint32_t last = s->n_contrib[pix];
+            // the kernel drops entries above the CELL's max n_contrib; emulate with the cell of this pixel
+            uint32_t cell_max = 0;
+            for (int q = 0; q < 16; q++) {
+                const int qx = tx * 16 + 4 * ((tid & 15) >> 2) + (q & 3), qy = ty * 16 + 4 * (tid >> 6) + (q >> 2);
+                if (qx < a->W && qy < a->H) cell_max = std::max(cell_max, s->n_contrib[(size_t)a->W * qy + qx]);
+            }
             for (uint32_t k = 0; k < n; k++) {
                 const uint32_t pos = n - 1 - k;
-                if (!(pos < last)) continue;
+                if (!(pos < cell_max)) continue;
                 const uint32_t id = s->point_list[beg + pos];
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)id;
                 {
-                    const float sx0 = (float)(tx * 16), sx1 = sx0 + 15.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
-                    if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_bwd's strip cull
+                    const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sx1 = sx0 + 3.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
+                    if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_bwd's cell cull
                 }
                 float g[16];
-                if (ghr::bwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g)) {
+                // branch-free step: non-contributing visits (pos >= n_contrib of THIS pixel included) run with alpha = 0
+                if (ghr::bwd_step(st, pos < last, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g)) {
                     const size_t slot = ghr::rect4_slot(s->rects[id], tx, ty);
                     for (int i = 0; i < 16; i++) acc[16 * slot + i] += (double)g[i];
                 }
