@@ -6,8 +6,9 @@
            bench.py --gpus N --steps K --warmup W
 
 A *step* is one global gradient step of the reference's stage-1 loop shape (src/train_gaussians.py:96-181, no
-densification): per rank ``views_per_gpu`` views of the 500k strand-aligned model at 1920x1080 -- render() (PyTorch
-projection + HIP rasterizer forward), losses, backward (HIP rasterizer backward + autograd), one flat all-reduce of the
+densification): per rank ``views_per_gpu`` views of the 500k strand-aligned model at 1920x1080 -- render() (fused HIP
+projection + rasterizer forward), the four stage-1 losses incl. the orientation term (lambda_dorient = 0.1 as in
+run.sh:112-115), backward (HIP loss / rasterizer / projection backward), one flat all-reduce of the
 Gaussian gradients when N > 1 (RCCL), Adam.  Weak scaling: per-GPU work is fixed as N grows.
 
 One JSON line on rank 0:  value = Gaussians rasterized per second over the whole job = N * views_per_gpu * P / t_step
@@ -69,6 +70,7 @@ def main():
     V = args.views_per_gpu
     global_views = V * world
     opt = OptimizationParams()
+    opt.lambda_dorient = 0.1  # the reference's stage-1 command line (run.sh:112-115)
 
     # ---- model replica (identical on every rank: CPU-seeded), per-rank views, synthetic ground truth ----------------
     model = syn.make_model(spec, dev)
@@ -164,7 +166,7 @@ def main():
         "metric": "gaussians_rasterized_per_sec_fwd_bwd_1080p", "value": round(value, 1), "unit": "Gaussians/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d Gaussians (%s), %d view(s)/GPU/step at %dx%d, render+loss+backward%s+Adam" %
+        "config": {"workload": "%s: %d Gaussians (%s), %d view(s)/GPU/step at %dx%d, render + 4 stage-1 losses (L1, SSIM, mask, orientation 0.1) + backward%s + Adam" %
                    (spec.name, P_model, spec.kind, V, spec.W, spec.H, "+RCCL grad all-reduce" if world > 1 else ""),
                    "views_per_gpu": V, "global_views": global_views, "parallelism": "view-dp%d" % world,
                    "P_rasterized_per_view": Pv, "num_rendered_per_view": R},

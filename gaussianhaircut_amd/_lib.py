@@ -86,6 +86,17 @@ class ModelArgs(ctypes.Structure):
                [("debug", ctypes.c_int32)]
 
 
+class LossArgs(ctypes.Structure):
+    """``ghr_loss_args`` (include/ghr.h)."""
+    _fields_ = [("W", ctypes.c_int32), ("H", ctypes.c_int32)] + \
+               [(n, ctypes.c_void_p) for n in ("image", "mask", "dir2d", "orient_conf", "gt_image", "gt_mask",
+                                               "gt_orient_angle", "gt_orient_conf")] + \
+               [(n, ctypes.c_float) for n in ("w_l1", "w_ssim", "w_mask", "w_orient")]
+
+
+LOSS_SUMS = 1288  # GHR_LOSS_SUMS
+
+
 class WsView(ctypes.Structure):
     """``ghr_ws_view`` (include/ghr.h) -- test introspection."""
     _fields_ = [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "cov3D", "final_T", "n_contrib",
@@ -121,8 +132,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
-    L.ghr_loss_forward.argtypes = [vp, i32, i32, vp, vp, vp, vp, f32, f32, f32, vp, vp, vp]
-    L.ghr_loss_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, f32, vp, vp]
+    L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]
+    L.ghr_loss_backward.argtypes = [vp, ctypes.POINTER(LossArgs)] + [vp] * 9
     L.ghr_adam_step.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, i32, ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, i32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15

@@ -344,46 +344,64 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
 }
 
 namespace ghr {
-__global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, float w_mask, float n_pix, float* out)
+__global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, float w_mask, float w_orient, float n_pix,
+                                float* aux, float* out)
 {
     // one wave: lane l folds slots l, l+64, ... in double, then a butterfly over the 64 lanes
-    double s0 = 0, s1 = 0, s2 = 0;
-    for (int i = threadIdx.x; i < GHR_LOSS_SLOTS; i += 64) {
-        s0 += sums[3 * i]; s1 += sums[3 * i + 1]; s2 += sums[3 * i + 2];
+    double s[GHR_LOSS_TERMS] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < GHR_LOSS_SLOTS; i += 64)
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += sums[GHR_LOSS_TERMS * i + k];
+    for (int off = 32; off >= 1; off >>= 1)
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += __shfl_xor(s[k], off);
+    if (threadIdx.x == 0) {
+        float lo = 0.f, bad = 0.f;
+        if (w_orient != 0.f) {
+            lo = (float)(s[3] / s[4]);
+            if (lo != lo) { lo = 0.f; bad = 1.f; }  // train_gaussians.py:134: a NaN orientation loss is dropped
+        }
+        aux[0] = (float)s[4];
+        aux[1] = bad;
+        out[0] = (float)(w_l1 * (s[0] / (3.0 * n_pix)) + w_ssim * (1.0 - s[1] / (3.0 * n_pix)) + w_mask * (s[2] / (2.0 * n_pix))) +
+                 w_orient * lo;
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-        s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
-    }
-    if (threadIdx.x == 0)
-        out[0] = (float)(w_l1 * (s0 / (3.0 * n_pix)) + w_ssim * (1.0 - s1 / (3.0 * n_pix)) + w_mask * (s2 / (2.0 * n_pix)));
 }
 }  // namespace ghr
 
-int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, const float* mask, const float* gt_image,
-                     const float* gt_mask, float w_l1, float w_ssim, float w_mask, float* maps, float* sums,
-                     float* loss_out)
+int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* sums, float* loss_out)
 {
-    if (W <= 0 || H <= 0 || !image || !mask || !gt_image || !gt_mask || !maps || !sums || !loss_out)
+    if (!l || l->W <= 0 || l->H <= 0 || !l->image || !l->mask || !l->gt_image || !l->gt_mask || !maps || !sums || !loss_out)
         return fail(GHR_E_INVALID, "ghr_loss_forward: bad args");
+    const bool orient = l->w_orient != 0.f;
+    if (orient && (!l->dir2d || !l->orient_conf || !l->gt_orient_angle || !l->gt_orient_conf))
+        return fail(GHR_E_INVALID, "ghr_loss_forward: w_orient != 0 needs dir2d / orient_conf / gt_orient_angle / gt_orient_conf");
     hipStream_t s = (hipStream_t)stream;
-    GHR_HIP(hipMemsetAsync(sums, 0, 3 * GHR_LOSS_SLOTS * sizeof(float), s));
-    ghr::LossArgs a{W, H, image, mask, gt_image, gt_mask, maps, sums};
-    const dim3 grid((W + GHR_SSIM_T - 1) / GHR_SSIM_T, (H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
+    GHR_HIP(hipMemsetAsync(sums, 0, GHR_LOSS_SUMS * sizeof(float), s));
+    ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
+                    l->gt_orient_angle, l->gt_orient_conf, maps, sums};
+    const dim3 grid((l->W + GHR_SSIM_T - 1) / GHR_SSIM_T, (l->H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
     hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(GHR_SSIM_T, GHR_SSIM_T), 0, s, a);
-    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, w_l1, w_ssim, w_mask, (float)W * (float)H,
+    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, l->w_l1, l->w_ssim, l->w_mask,
+                       orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
                        loss_out);
     return finish(s, 0);
 }
 
-int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, const float* mask,
-                      const float* gt_image, const float* gt_mask, const float* maps, const float* grad_loss,
-                      float w_l1, float w_ssim, float w_mask, float* d_image, float* d_mask)
+int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, const float* sums,
+                      const float* grad_loss, float* d_image, float* d_mask, float* d_dir2d, float* d_orient_conf,
+                      float* zero_plane_a, float* zero_plane_b)
 {
-    if (W <= 0 || H <= 0 || !image || !mask || !gt_image || !gt_mask || !maps || !d_image || !d_mask)
+    if (!l || l->W <= 0 || l->H <= 0 || !l->image || !l->mask || !l->gt_image || !l->gt_mask || !maps || !sums ||
+        !d_image || !d_mask || ((d_dir2d == nullptr) != (d_orient_conf == nullptr)))
         return fail(GHR_E_INVALID, "ghr_loss_backward: bad args");
+    const bool orient = l->w_orient != 0.f;
+    if (orient && (!l->dir2d || !l->orient_conf || !l->gt_orient_angle || !l->gt_orient_conf || !d_dir2d))
+        return fail(GHR_E_INVALID, "ghr_loss_backward: w_orient != 0 needs the orientation inputs and d_dir2d / d_orient_conf");
     hipStream_t s = (hipStream_t)stream;
-    ghr::LossBwdArgs a{W, H, image, mask, gt_image, gt_mask, maps, grad_loss, w_l1, w_ssim, w_mask, d_image, d_mask};
-    const dim3 grid((W + GHR_SSIM_T - 1) / GHR_SSIM_T, (H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
+    ghr::LossBwdArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image,
+                       l->gt_mask, l->gt_orient_angle, l->gt_orient_conf, maps, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
+                       grad_loss, l->w_l1, l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, d_image, d_mask, d_dir2d,
+                       d_orient_conf, zero_plane_a, zero_plane_b};
+    const dim3 grid((l->W + GHR_SSIM_T - 1) / GHR_SSIM_T, (l->H + GHR_SSIM_T - 1) / GHR_SSIM_T, 3);
     hipLaunchKernelGGL(ghr::k_loss_bwd, grid, dim3(GHR_SSIM_T, GHR_SSIM_T), 0, s, a);
     return finish(s, 0);
 }

@@ -1,11 +1,15 @@
-// ghr_loss.h -- fused photometric loss of the stage-1 step: masked L1 + (1 - SSIM) + mask L1, forward and backward.
+// ghr_loss.h -- fused loss of the stage-1 step: masked L1 + (1 - SSIM) + mask L1 + orientation, forward and backward.
 //
 // Reference: src/train_gaussians.py:126-140 with src/utils/loss_utils.py:19-26 (l1_loss) and :91-121 (ssim: 11x11
 // Gaussian window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over the map):
 //     Ll1   = mean(|image - gt| * m)                       m = gt_mask[1:] (foreground), broadcast over RGB
 //     Lssim = 1 - mean(ssim_map(image * m, gt * m))
 //     Lmask = mean(|mask - gt_mask|)
-//     loss  = w_l1 * Ll1 + w_ssim * Lssim + w_mask * Lmask
+//     Lorient = or_loss(orient_angle, gt_angle, orient_conf, weight = gt_orient_conf, mask = gt_mask[:1])
+//               (loss_utils.py:31-47) with orient_angle derived from the rendered 2D strand direction exactly as
+//               src/gaussian_renderer/__init__.py:100-105 (normalize, mirror, clamp, acos / pi); NaN -> 0
+//               (train_gaussians.py:134)
+//     loss  = w_l1 * Ll1 + w_ssim * Lssim + w_mask * Lmask + w_orient * Lorient      (run.sh:112-115: w_orient = 0.1)
 // PyTorch runs this as 10 MIOpen depthwise convolutions + ~40 elementwise kernels per step (measured 10.2 ms at
 // 1080p on MI355X = 69 % of the step once projection was fused).  Here: one forward kernel (separable 11-tap window
 // staged through LDS, 16x16 pixel tiles with a 5-pixel halo) that also emits the three per-pixel partial derivatives
@@ -20,6 +24,7 @@ namespace ghr {
 #define GHR_SSIM_T 16
 #define GHR_SSIM_E (GHR_SSIM_T + 2 * GHR_SSIM_R)  // 26
 #define GHR_LOSS_SLOTS 256
+#define GHR_LOSS_TERMS 5  // partial sums per slot: |image-gt|*m, ssim_map, |mask-gt_mask|, orient num, orient den
 
 __device__ __constant__ float c_ssim_w[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
                                              2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
@@ -47,12 +52,53 @@ struct LossArgs {
     int W, H;
     const float* image;     // [3,H,W] rendered
     const float* mask;      // [2,H,W] rendered (hair label, foreground)
+    const float* dir2d;     // [2,H,W] rendered 2D strand direction (x, y), or NULL (no orientation term)
+    const float* oconf;     // [1,H,W] rendered orientation confidence
     const float* gt_image;  // [3,H,W]
-    const float* gt_mask;   // [2,H,W]; channel 1 masks the colour terms
+    const float* gt_mask;   // [2,H,W]; channel 1 masks the colour terms, channel 0 the orientation term
+    const float* gt_angle;  // [1,H,W] orientation angle / pi in [0,1)
+    const float* gt_oconf;  // [1,H,W] per-pixel weight of the orientation term
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
-    float* sums;            // [GHR_LOSS_SLOTS][3] partial sums {|image-gt|*m, ssim_map, |mask-gt_mask|}, zeroed by the caller;
-                            // block b adds into slot b % SLOTS (one hot address would serialise ~73k atomics)
+    float* sums;            // [GHR_LOSS_SLOTS][GHR_LOSS_TERMS] partial sums, zeroed by the caller; block b adds into
+                            // slot b % SLOTS (one hot address would serialise ~73k atomics)
 };
+
+// Orientation term of ONE pixel (gaussian_renderer/__init__.py:100-105 + loss_utils.py:31-47), value and the partial
+// derivatives w.r.t. the rendered direction (d0, d1) and confidence.  `l` excludes the weight gt_oconf.
+struct OrientPix { float l, dl_dd0, dl_dd1, dl_dconf; };
+GHR_HD OrientPix orient_pixel(float d0, float d1, float conf, float gt_angle, float m)
+{
+    const float PI = 3.14159265358979323846f;
+    const float nrm = sqrtf(d0 * d0 + d1 * d1);
+    const float den = fmaxf(nrm, 1e-12f);                 // F.normalize(dim=0), eps = 1e-12
+    const float u0 = d0 / den, u1 = d1 / den;
+    const float mirror = u0 < 0.f ? -1.f : 1.f;
+    const float lo = -1.f + 1e-3f, hi = 1.f - 1e-3f;
+    const float uc = fminf(hi, fmaxf(lo, u1));
+    const float c = uc * mirror;
+    const float angle = acosf(c) / PI;
+    const float diff = angle - gt_angle;
+    const float a0 = fabsf(diff), a1 = fabsf(diff - 1.f), a2 = fabsf(diff + 1.f);
+    float lmin = a0, arg = diff;
+    if (a1 < lmin) { lmin = a1; arg = diff - 1.f; }
+    if (a2 < lmin) { lmin = a2; arg = diff + 1.f; }
+    OrientPix o;
+    o.l = (lmin * PI * conf - logf(conf + 1e-7f)) * m;
+    o.dl_dconf = (lmin * PI - 1.0f / (conf + 1e-7f)) * m;
+    const float sgn = arg > 0.f ? 1.f : (arg < 0.f ? -1.f : 0.f);
+    const float dl_dangle = PI * conf * m * sgn;
+    const float dl_dc = dl_dangle * (-1.0f / (PI * sqrtf(1.f - c * c)));
+    const float dl_du1 = (u1 >= lo && u1 <= hi) ? dl_dc * mirror : 0.f;   // clamp passes gradient inside the range
+    if (nrm > 1e-12f) {  // u = d / |d|:  du1/dd0 = -d0 d1 / |d|^3,  du1/dd1 = d0^2 / |d|^3
+        const float i3 = 1.0f / (nrm * nrm * nrm);
+        o.dl_dd0 = dl_du1 * (-d0 * d1 * i3);
+        o.dl_dd1 = dl_du1 * (d0 * d0 * i3);
+    } else {             // clamped denominator: u = d / eps
+        o.dl_dd0 = 0.f;
+        o.dl_dd1 = dl_du1 / 1e-12f;
+    }
+    return o;
+}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ float block_sum_256(float v, float* s_red)
@@ -135,11 +181,27 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
     const float s0 = block_sum_256(l1_v, s_red);
     const float s1 = block_sum_256(ssim_v, s_red);
     const float s2 = block_sum_256(ml1_v, s_red);
+    const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
     if (tid == 0) {
-        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
-        atomicAdd(&a.sums[3 * slot + 0], s0);
-        atomicAdd(&a.sums[3 * slot + 1], s1);
-        atomicAdd(&a.sums[3 * slot + 2], s2);
+        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 0], s0);
+        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 1], s1);
+        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 2], s2);
+    }
+    if (ch == 2 && a.dir2d != nullptr) {  // the blocks of the third colour channel also carry the orientation term
+        float num = 0.f, den = 0.f;
+        if (inside) {
+            const size_t p = (size_t)gy * W + gx;
+            const float w = a.gt_oconf[p];
+            const OrientPix o = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
+            num = o.l * w;
+            den = w;
+        }
+        const float s3 = block_sum_256(num, s_red);
+        const float s4 = block_sum_256(den, s_red);
+        if (tid == 0) {
+            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 3], s3);
+            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 4], s4);
+        }
     }
 #endif
 }
@@ -148,13 +210,22 @@ struct LossBwdArgs {
     int W, H;
     const float* image;
     const float* mask;
+    const float* dir2d;      // may be NULL
+    const float* oconf;
     const float* gt_image;
     const float* gt_mask;
+    const float* gt_angle;
+    const float* gt_oconf;
     const float* maps;
+    const float* aux;        // {sum of orientation weights, orientation-term-is-NaN flag} from k_loss_finalize
     const float* grad_loss;  // device scalar dL/dloss (may be null => 1)
-    float w_l1, w_ssim, w_mask;
+    float w_l1, w_ssim, w_mask, w_orient;
     float* d_image;  // [3,H,W]
     float* d_mask;   // [2,H,W]
+    float* d_dir2d;  // [2,H,W] or NULL
+    float* d_oconf;  // [1,H,W] or NULL
+    float* zero_a;   // optional planes to zero-fill (channels of a packed [10,H,W] gradient no loss term touches)
+    float* zero_b;
 };
 
 __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
@@ -210,6 +281,18 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
             const float dm = a.mask[ch * N + p] - a.gt_mask[ch * N + p];
             const float sm = dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f);
             a.d_mask[ch * N + p] = up * a.w_mask * sm / (2.0f * (float)N);
+            float* z = ch == 0 ? a.zero_a : a.zero_b;
+            if (z) z[p] = 0.f;
+        } else if (a.d_dir2d != nullptr) {
+            float g0 = 0.f, g1 = 0.f, gc = 0.f;
+            if (a.dir2d != nullptr && a.w_orient != 0.f && a.aux[1] == 0.f) {
+                const OrientPix o = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
+                const float s = up * a.w_orient * a.gt_oconf[p] / a.aux[0];
+                g0 = s * o.dl_dd0; g1 = s * o.dl_dd1; gc = s * o.dl_dconf;
+            }
+            a.d_dir2d[p] = g0;
+            a.d_dir2d[N + p] = g1;
+            a.d_oconf[p] = gc;
         }
     }
 #endif

@@ -38,13 +38,61 @@ def _sh_to_rgb(deg, shs_view, xyz, campos):
     return torch.clamp_min(eval_sh(deg, shs_view, d) + 0.5, 0.0)
 
 
-def _package(renders, screenspace_points, radii):
-    image, mask, cov2d, orient_conf, _ = renders.split([3, 2, 3, 1, 1], dim=0)
+def orient_angle_from(cov2d):
+    """Reference :102-105: rendered 2D strand direction -> orientation angle / pi in [0,1)."""
     dir2d = F.normalize(cov2d[:2], dim=0)
     mirror = torch.where(dir2d[[0]] < 0, -torch.ones_like(dir2d[[0]]), torch.ones_like(dir2d[[0]]))
-    orient_angle = torch.acos(dir2d[[1]].clamp(-1 + 1e-3, 1 - 1e-3) * mirror) / math.pi
-    return {"render": image, "mask": mask, "orient_angle": orient_angle, "orient_conf": orient_conf,
-            "viewspace_points": screenspace_points, "visibility_filter": radii > 0, "radii": radii}
+    return torch.acos(dir2d[[1]].clamp(-1 + 1e-3, 1 - 1e-3) * mirror) / math.pi
+
+
+class RenderPackage(dict):
+    """The reference's return dict.  ``orient_angle`` (10 small PyTorch kernels at full resolution) is computed on first
+    access: the fused stage-1 loss derives it inside its own kernel from ``renders_packed`` (the packed [10,H,W]
+    rasterizer output, kept as an attribute) and never reads it."""
+
+    def __init__(self, renders, cov2d, **kw):
+        super().__init__(**kw)
+        self._cov2d = cov2d
+        self.renders_packed = renders
+
+    def _materialise(self):
+        if not dict.__contains__(self, "orient_angle"):
+            dict.__setitem__(self, "orient_angle", orient_angle_from(self._cov2d))
+
+    def __getitem__(self, k):
+        if k == "orient_angle":
+            self._materialise()
+        return dict.__getitem__(self, k)
+
+    def get(self, k, default=None):
+        if k == "orient_angle":
+            self._materialise()
+        return dict.get(self, k, default)
+
+    def __contains__(self, k):
+        return k == "orient_angle" or dict.__contains__(self, k)
+
+    def keys(self):
+        self._materialise()
+        return dict.keys(self)
+
+    def items(self):
+        self._materialise()
+        return dict.items(self)
+
+    def values(self):
+        self._materialise()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._materialise()
+        return dict.__iter__(self)
+
+
+def _package(renders, screenspace_points, radii):
+    image, mask, cov2d, orient_conf, _ = renders.split([3, 2, 3, 1, 1], dim=0)
+    return RenderPackage(renders, cov2d, render=image, mask=mask, orient_conf=orient_conf,
+                         viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
 
 
 def _use_fused(pc, pipe) -> bool:

@@ -15,11 +15,18 @@ PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, deb
 
 
 def view_loss(render_pkg, cam, opt, fused=None):
-    """train_gaussians.py:113-140.  On a ROCm device the L1 / SSIM / mask terms run as one fused HIP op."""
+    """train_gaussians.py:113-140.  On a ROCm device all four terms run as one fused HIP op."""
     image, mask = render_pkg["render"], render_pkg["mask"]
     gt_image, gt_mask = cam.original_image, cam.original_mask
     if fused is None:
         fused = image.is_cuda
+    if fused and getattr(render_pkg, "renders_packed", None) is not None:
+        # one HIP op on the rasterizer's packed [10,H,W] output, orientation term included (orient_weight =
+        # ones_like(gt_mask[:1]) * gt_orient_conf, train_gaussians.py:130)
+        from .fused_loss import stage1_loss
+        return stage1_loss(render_pkg.renders_packed, gt_image, gt_mask, cam.original_orient_angle,
+                           cam.original_orient_conf, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask,
+                           opt.lambda_dorient)
     if fused and opt.lambda_dorient == 0.0:
         from .fused_loss import photometric_loss
         return photometric_loss(image, mask, gt_image, gt_mask, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 2
+#define GHR_ABI_VERSION 3
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -144,18 +144,35 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
                        float* d_features_rest);
 
-/* ---- fused photometric loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-26,91-121) -------------
- * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|),
- * m = gt_mask[1].  image/gt_image [3,H,W], mask/gt_mask [2,H,W].  maps: 9*H*W floats of scratch kept for backward.
- * loss_out: device scalar.  sums: GHR_LOSS_SUMS (768) device floats of scratch. */
-#define GHR_LOSS_SUMS 768
-int ghr_loss_forward(void* stream, int32_t W, int32_t H, const float* image, const float* mask, const float* gt_image,
-                     const float* gt_mask, float w_l1, float w_ssim, float w_mask, float* maps, float* sums,
-                     float* loss_out);
-/* grad_loss: device scalar dL/dloss (NULL = 1).  d_image [3,H,W], d_mask [2,H,W] fully written. */
-int ghr_loss_backward(void* stream, int32_t W, int32_t H, const float* image, const float* mask,
-                      const float* gt_image, const float* gt_mask, const float* maps, const float* grad_loss,
-                      float w_l1, float w_ssim, float w_mask, float* d_image, float* d_mask);
+/* ---- fused stage-1 loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-47,91-121) ----------------
+ * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|)
+ *        + w_orient * or_loss(orient_angle(dir2d), gt_orient_angle, orient_conf, weight = gt_orient_conf, mask = gt_mask[0]),
+ * m = gt_mask[1]; orient_angle as in src/gaussian_renderer/__init__.py:100-105; a NaN orientation term is dropped
+ * (train_gaussians.py:134).  All planes are H*W floats: image/gt_image 3, mask/gt_mask 2, dir2d 2 (x, y), the rest 1.
+ * The rendered planes may point into one packed [10,H,W] rasterizer output (channels 0-2, 3-4, 5-6, 8).
+ * w_orient == 0 disables the orientation term (its pointers may then be NULL). */
+typedef struct ghr_loss_args {
+    int32_t W, H;
+    const float* image;
+    const float* mask;
+    const float* dir2d;
+    const float* orient_conf;
+    const float* gt_image;
+    const float* gt_mask;
+    const float* gt_orient_angle;
+    const float* gt_orient_conf;
+    float w_l1, w_ssim, w_mask, w_orient;
+} ghr_loss_args;
+/* maps: 9*H*W floats of scratch kept for backward.  sums: GHR_LOSS_SUMS device floats of scratch kept for backward.
+ * loss_out: device scalar. */
+#define GHR_LOSS_SUMS 1288 /* 256 slots x 5 partial sums + {sum of orientation weights, NaN flag} + pad */
+int ghr_loss_forward(void* stream, const ghr_loss_args* a, float* maps, float* sums, float* loss_out);
+/* grad_loss: device scalar dL/dloss (NULL = 1).  d_image [3,H,W], d_mask [2,H,W] fully written; d_dir2d [2,H,W] and
+ * d_orient_conf [1,H,W] (both or neither; zeros when the orientation term is off or was NaN); zero_plane_a/b: optional
+ * H*W planes to zero-fill (the channels of a packed [10,H,W] gradient that no loss term touches). */
+int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, const float* sums,
+                      const float* grad_loss, float* d_image, float* d_mask, float* d_dir2d, float* d_orient_conf,
+                      float* zero_plane_a, float* zero_plane_b);
 
 /* ---- fused Adam (src/scene/gaussian_model.py:431-444; src/train_gaussians.py:174-181) ---------------------------
  * One pass over flat buffers p/g/m/v of n floats split into n_groups contiguous groups (group_end[i] = exclusive end

@@ -72,3 +72,71 @@ def test_fused_adam_matches_torch_adam_and_nan_guard():
     for p, q in zip(pa, before):
         assert torch.equal(p.detach(), q)
     assert float(fa.flat_grad.abs().sum()) == 0.0
+
+
+def _torch_stage1(renders, gt_image, gt_mask, gt_angle, gt_oconf, w):
+    """The reference's loss code path on the packed output (gaussian_renderer/__init__.py:100-105 +
+    train_gaussians.py:126-140), PyTorch autograd."""
+    from gaussianhaircut_amd.gaussian_renderer import orient_angle_from
+    image, mask, cov2d, oconf, _ = renders.split([3, 2, 3, 1, 1], dim=0)
+    angle = orient_angle_from(cov2d)
+    base = _torch_loss(image, mask, gt_image, gt_mask, w[:3])
+    weight = torch.ones_like(gt_mask[:1]) * gt_oconf
+    lo = lu.or_loss(angle, gt_angle, oconf, weight=weight, mask=gt_mask[:1])
+    lo = torch.where(torch.isnan(lo), torch.zeros_like(lo), lo)
+    return base + w[3] * lo
+
+
+@pytest.mark.parametrize("H,W,w_orient", [(48, 64, 0.1), (37, 70, 0.1), (270, 480, 0.1), (48, 64, 0.0)])
+def test_fused_stage1_loss_with_orientation_matches_torch(H, W, w_orient):
+    from gaussianhaircut_amd.fused_loss import stage1_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7 * H + W)
+    base = torch.rand(3, H // 4 + 2, W // 4 + 2, generator=g)
+    gt = torch.nn.functional.interpolate(base[None], size=(H, W), mode="bilinear")[0]
+    r = torch.zeros(10, H, W)
+    r[0:3] = (gt + 0.15 * torch.randn(3, H, W, generator=g)).clamp(-0.2, 1.3)
+    r[3:5] = torch.rand(2, H, W, generator=g)
+    r[5:8] = torch.randn(3, H, W, generator=g) * 0.3          # 2D direction (+ unused z)
+    r[8] = torch.rand(H, W, generator=g) * 2 + 0.05           # orientation confidence > 0
+    r[9] = torch.rand(H, W, generator=g) * 5
+    r[5:7, : H // 6] = 0.0                                     # empty pixels: zero direction (normalize's eps branch)
+    r[8, : H // 6] = 0.0
+    gt_mask = (torch.rand(2, H, W, generator=g) > 0.35).float()
+    gt_angle = torch.rand(1, H, W, generator=g)
+    gt_oconf = torch.rand(1, H, W, generator=g)
+    w = (0.8, 0.2, 0.2, w_orient)
+    a = r.to(dev).requires_grad_(True)
+    b = r.to(dev).requires_grad_(True)
+    consts = [t.to(dev) for t in (gt, gt_mask, gt_angle, gt_oconf)]
+    lf = stage1_loss(a, *consts, *w)
+    lt = _torch_stage1(b, *consts, w)
+    assert abs(float(lf.detach()) - float(lt.detach())) < 5e-6 * max(1.0, abs(float(lt.detach())))
+    (lf * 0.37).backward()
+    (lt * 0.37).backward()
+    x, y = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    assert np.isfinite(x).all()
+    for lo_, hi_, name in ((0, 3, "image"), (3, 5, "mask"), (5, 7, "dir2d"), (7, 8, "dir z"), (8, 9, "conf"), (9, 10, "depth")):
+        scale = max(np.abs(y[lo_:hi_]).max(), 1e-30)
+        # orientation gradients are discontinuous where the wrapped-difference branch or the mirror flips: allow a
+        # handful of pixels sitting exactly on a branch boundary to pick the other side
+        bad = np.abs(x[lo_:hi_] - y[lo_:hi_]) > 2e-4 * scale
+        assert bad.sum() <= (3 if name in ("dir2d", "conf") else 0), (name, int(bad.sum()), scale)
+
+
+def test_fused_stage1_loss_nan_orientation_is_dropped():
+    from gaussianhaircut_amd.fused_loss import stage1_loss
+    dev = torch.device("cuda:0")
+    H, W = 32, 48
+    g = torch.Generator().manual_seed(5)
+    r = torch.rand(10, H, W, generator=g)
+    gt, gt_mask = torch.rand(3, H, W, generator=g), (torch.rand(2, H, W, generator=g) > 0.5).float()
+    gt_angle, gt_oconf = torch.rand(1, H, W, generator=g), torch.zeros(1, H, W)   # weight.sum() == 0 -> 0/0 = NaN
+    a = r.to(dev).requires_grad_(True)
+    b = r.to(dev).requires_grad_(True)
+    consts = [t.to(dev) for t in (gt, gt_mask, gt_angle, gt_oconf)]
+    lf = stage1_loss(a, *consts, 0.8, 0.2, 0.2, 0.1)
+    lt = _torch_stage1(b, *consts, (0.8, 0.2, 0.2, 0.1))
+    assert torch.isfinite(lf) and abs(float(lf.detach()) - float(lt.detach())) < 5e-6
+    lf.backward()
+    assert torch.isfinite(a.grad).all() and float(a.grad[5:].abs().max()) == 0.0
