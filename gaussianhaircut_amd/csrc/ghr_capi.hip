@@ -312,7 +312,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
-                       float* d_features_rest)
+                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag)
 {
     ghr::ModelArgs a;
     if (int rc = fill_model(m, &a)) return rc;
@@ -339,6 +339,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
     mg.ginst = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
+    mg.accumulate = accumulate; mg.nan_flag = nan_flag;
     hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a, mg);
     return finish(s, m->debug);
 }
@@ -420,7 +421,7 @@ int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* 
     for (int i = 0; i < n_groups; i++) { a.end[i] = group_end_host[i]; a.lr[i] = lr_host[i]; }
     a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    if (nan_guard) hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
+    if (nan_guard == 1) hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
     hipLaunchKernelGGL(ghr::k_adam, dim3(blocks), dim3(256), 0, s, a);
     hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state);
     return finish(s, 0);

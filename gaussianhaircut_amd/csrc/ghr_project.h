@@ -59,7 +59,17 @@ struct ModelGrads {
     float* d_orient_conf_log; // [P]
     float* d_features_dc;     // [P,1,3]
     float* d_features_rest;   // [P,K-1,3]
+    int accumulate;           // != 0: parameter gradients are ADDED to the output buffers (d_means2D is always assigned)
+    int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN
 };
+
+// Writes (or accumulates) one parameter-gradient element; returns whether the stored value is NaN.
+GHR_HD bool grad_out(float* p, float v, int accumulate)
+{
+    if (accumulate) v += *p;
+    *p = v;
+    return v != v;
+}
 
 GHR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -287,11 +297,14 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
 }
 
 // Backward for one Gaussian: packed rasterizer gradients `ga[16]` (already summed over the Gaussian's tile instances)
-// -> raw-parameter gradients.  Writes every output element.
+// -> raw-parameter gradients.  Writes (or accumulates into) every output element except d_rest, which is handed back in
+// the caller's staging block.  Returns whether any value stored was NaN.
 // `rest` / `d_rest`: this Gaussian's (K-1) x 3 blocks of features_rest and of its gradient (LDS in the kernel).
-GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
+GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
                             float* d_rest)
 {
+    bool bad = false;
+    const int acc = g.accumulate;
     const int K = a.sh_coeffs;
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
@@ -439,16 +452,17 @@ GHR_HD void project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        g.d_xyz[3 * idx + i] = dxyz[i];
-        g.d_log_scales[3 * idx + i] = dls[i];
+        bad |= grad_out(g.d_xyz + 3 * idx + i, dxyz[i], acc);
+        bad |= grad_out(g.d_log_scales + 3 * idx + i, dls[i], acc);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) g.d_rotations[4 * idx + i] = dq[i];
-    g.d_opacity_logit[idx] = dlo;
-    g.d_label_logit[idx] = dll;
-    g.d_orient_conf_log[idx] = dlc;
+    for (int i = 0; i < 4; i++) bad |= grad_out(g.d_rotations + 4 * idx + i, dq[i], acc);
+    bad |= grad_out(g.d_opacity_logit + idx, dlo, acc);
+    bad |= grad_out(g.d_label_logit + idx, dll, acc);
+    bad |= grad_out(g.d_orient_conf_log + idx, dlc, acc);
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) g.d_features_dc[3 * (size_t)idx + ch] = ddc[ch];
+    for (int ch = 0; ch < 3; ch++) bad |= grad_out(g.d_features_dc + 3 * (size_t)idx + ch, ddc[ch], acc);
+    return bad;
 }
 
 // features_rest is [P, K-1, 3]: one thread's 3(K-1) floats are contiguous but 180 B apart from its neighbour's, so
@@ -466,6 +480,27 @@ __device__ __forceinline__ void slab_copy(float* dst, const float* src, size_t n
     f4* d4 = reinterpret_cast<f4*>(dst);
     for (size_t i = tid; i < n4; i += GHR_BLOCK) d4[i] = s4[i];
     for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
+}
+// LDS gradient slab -> global, assigning or accumulating; returns whether a stored value was NaN
+__device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_floats, int tid, int accumulate)
+{
+    const size_t n4 = n_floats / 4;
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    f4* d4 = reinterpret_cast<f4*>(dst);
+    bool bad = false;
+    for (size_t i = tid; i < n4; i += GHR_BLOCK) {
+        f4 v = s4[i];
+        if (accumulate) v += d4[i];
+        d4[i] = v;
+        bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    }
+    for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) {
+        float v = src[i];
+        if (accumulate) v += dst[i];
+        dst[i] = v;
+        bad |= v != v;
+    }
+    return bad;
 }
 #endif
 
@@ -499,13 +534,15 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     const int idx = base + threadIdx.x;
+    bool bad = false;
     if (idx < a.P) {
         float ga[16];
         gather_inst_grads(g.ginst, a.rects[idx], ga);
-        project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+        bad = project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
     }
     __syncthreads();
-    if (row > 0) slab_copy(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x);
+    if (row > 0) bad |= slab_out(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
+    if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
 #endif
 }
 

@@ -62,6 +62,9 @@ class _RenderModelFused(torch.autograd.Function):
                                             _ptr(color)))
         LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
         ctx.cfg, ctx.R, ctx.K = cfg, R, K
+        # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
+        # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
+        ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
         ctx.mark_non_differentiable(radii)
         ctx.save_for_backward(*params, view, proj, campos, bg, radii, geom, img, binb)
         return color, radii
@@ -74,16 +77,24 @@ class _RenderModelFused(torch.autograd.Function):
         xyz = params[0]
         dev, P = xyz.device, xyz.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
+        sink = cfg.get("grad_sink")
+        direct = sink is not None and P > 0 and all(
+            isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous()
+            and t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.leaves)
         with torch.cuda.device(dev):
             d_m2d = torch.empty((P, 3), **f32)
-            d_xyz = torch.empty((P, 3), **f32)
-            d_ls = torch.empty((P, 3), **f32)
-            d_rot = torch.empty((P, 4), **f32)
-            d_op = torch.empty((P, 1), **f32)
-            d_label = torch.empty((P, 1), **f32)
-            d_conf = torch.empty((P, 1), **f32)
-            d_fdc = torch.empty((P, 1, 3), **f32)
-            d_frest = torch.empty((P, K - 1, 3), **f32)
+            if direct:
+                # accumulate into the optimizer's flat gradient buffer: no per-parameter AccumulateGrad kernels
+                d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest = [t.grad for t in ctx.leaves]
+            else:
+                d_xyz = torch.empty((P, 3), **f32)
+                d_ls = torch.empty((P, 3), **f32)
+                d_rot = torch.empty((P, 4), **f32)
+                d_op = torch.empty((P, 1), **f32)
+                d_label = torch.empty((P, 1), **f32)
+                d_conf = torch.empty((P, 1), **f32)
+                d_fdc = torch.empty((P, 1, 3), **f32)
+                d_frest = torch.empty((P, K - 1, 3), **f32)
             scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)  # one line per instance
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
@@ -92,7 +103,11 @@ class _RenderModelFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), R, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
-                                                _ptr(d_fdc), _ptr(d_frest)))
+                                                _ptr(d_fdc), _ptr(d_frest), int(direct),
+                                                sink.nan_flag_ptr() if direct else None))
+        if direct:
+            sink.note_direct_backward()
+            return None, None, None, None, None, None, None, None, d_m2d, None
         return d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d, None
 
 
@@ -109,6 +124,10 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
                tanfovx=math.tan(float(cam.FoVx) * 0.5), tanfovy=math.tan(float(cam.FoVy) * 0.5),
                conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug))
+    from ..optim import FusedAdam
+    opt = getattr(pc, "optimizer", None)
+    if isinstance(opt, FusedAdam) and opt.direct_grads:
+        cfg["grad_sink"] = opt
     renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
                                              pc._features_dc, pc._features_rest, screenspace_points, cfg)
     return renders, radii, screenspace_points

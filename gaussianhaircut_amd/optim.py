@@ -19,9 +19,14 @@ from .diff_gaussian_rasterization import _ptr, _stream
 
 
 class FusedAdam:
-    def __init__(self, param_groups: List[Dict], betas=(0.9, 0.999), eps: float = 1e-15, nan_guard: bool = True):
+    def __init__(self, param_groups: List[Dict], betas=(0.9, 0.999), eps: float = 1e-15, nan_guard: bool = True,
+                 direct_grads: bool = True):
         self.param_groups = [dict(g) for g in param_groups]
         self.betas, self.eps, self.nan_guard = betas, eps, nan_guard
+        # direct_grads: the fused renderer's backward adds its parameter gradients straight into ``flat_grad`` and keeps
+        # the NaN flag up to date, instead of returning 8 tensors for autograd to accumulate (8 kernels, 3x the traffic)
+        self.direct_grads = direct_grads
+        self._direct_backwards = 0
         params = [p for g in self.param_groups for p in g["params"]]
         assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
             "FusedAdam needs fp32 parameters on a ROCm device (use torch.optim.Adam elsewhere)"
@@ -66,15 +71,26 @@ class FusedAdam:
     def has_nan(self):
         return torch.isnan(self.flat_grad).any()
 
+    # ---- direct-gradient sink used by gaussian_renderer.fused
+    def nan_flag_ptr(self):
+        return ctypes.c_void_p(self.state_dev.data_ptr() + 4)
+
+    def note_direct_backward(self):
+        self._direct_backwards += 1
+
     # ---- optimizer interface
-    def step(self, zero_grad: bool = True):
+    def step(self, zero_grad: bool = True, nan_scan: bool = True):
+        """``nan_scan=False``: every gradient of this step was produced by the fused renderer's backward on THIS rank
+        (which maintains the NaN flag), so the guard needs no pass over the gradients.  Must stay True after an
+        all-reduce (another rank's NaN arrives through the sum) or when other losses touched ``.grad``."""
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        guard = 0 if not self.nan_guard else (1 if nan_scan or self._direct_backwards == 0 else 2)
+        self._direct_backwards = 0
         with torch.cuda.device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                                                self.betas[0], self.betas[1], self.eps, int(self.nan_guard),
-                                                int(zero_grad)))
+                                                self.betas[0], self.betas[1], self.eps, guard, int(zero_grad)))
 
     def state_dict(self):
         return {"flat_param": self.flat_param, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,

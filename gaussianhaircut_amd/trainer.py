@@ -57,8 +57,11 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     from .optim import FusedAdam
     if isinstance(gaussians.optimizer, FusedAdam):
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
+        # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no
+        # other rank contributes: the guard needs no scan over the gradients
+        direct_all = gaussians.optimizer._direct_backwards == len(cams) and _world_size() == 1
         gaussians.optimizer.all_reduce()
-        gaussians.optimizer.step(zero_grad=True)
+        gaussians.optimizer.step(zero_grad=True, nan_scan=not direct_all)
         return total
     if bucket is not None:
         bucket.all_reduce()
@@ -78,6 +81,11 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return total
+
+
+def _world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
 @torch.no_grad()

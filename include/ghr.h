@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 3
+#define GHR_ABI_VERSION 4
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -135,14 +135,17 @@ typedef struct ghr_model_args {
 int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_ws, void* img_ws, int32_t* radii,
                              float* means2D_out, uint32_t* R_host);
 
-/* Backward of the fused path.  Outputs are fully written: d_means2D [P,3], d_xyz [P,3], d_log_scales [P,3],
+/* Backward of the fused path.  Outputs: d_means2D [P,3] (always assigned), d_xyz [P,3], d_log_scales [P,3],
  * d_rotations [P,4], d_opacity_logit [P], d_label_logit [P], d_orient_conf_log [P], d_features_dc [P,1,3],
- * d_features_rest [P,K-1,3]. */
+ * d_features_rest [P,K-1,3].  accumulate == 0: every parameter-gradient element is assigned; != 0: added to what the
+ * buffers hold (they may be the optimizer's own flat gradient buffer: no separate accumulation pass).
+ * nan_flag (nullable, device int): set to 1 when any stored parameter-gradient value is NaN (the stage-1 loop's NaN
+ * guard, src/train_gaussians.py:174-181, without a scan over the gradients). */
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
-                       float* d_features_rest);
+                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag);
 
 /* ---- fused stage-1 loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-47,91-121) ----------------
  * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|)
@@ -177,7 +180,9 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, c
 /* ---- fused Adam (src/scene/gaussian_model.py:431-444; src/train_gaussians.py:174-181) ---------------------------
  * One pass over flat buffers p/g/m/v of n floats split into n_groups contiguous groups (group_end[i] = exclusive end
  * offset, lr[i] = its learning rate; host arrays).  state: 2 device ints {step, nan_flag}, zero-initialised once.
- * nan_guard != 0: skip the whole update (and do not advance step) when any gradient is NaN, on-device.
+ * nan_guard != 0: skip the whole update (and do not advance step) when any gradient is NaN, on-device;
+ * nan_guard == 1 scans the gradients first, nan_guard == 2 trusts state[1] as maintained by the gradient producer
+ * (ghr_model_backward's nan_flag).
  * zero_grad != 0: the gradient buffer is zeroed for the next step. */
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,

@@ -237,6 +237,7 @@ void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const
     g.ginst = nullptr; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
     g.d_features_rest = d_frest;
+    g.accumulate = 0; g.nan_flag = nullptr;
     const int row = 3 * (a.sh_coeffs - 1);
     for (int i = 0; i < a.P; i++)
         ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row);

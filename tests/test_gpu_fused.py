@@ -69,3 +69,43 @@ def test_fused_training_step_runs_and_learns():
     model.training_setup(opt)  # FusedAdam owns the flat gradient buffer: no separate FlatGradBucket
     losses = [float(training_step(model, [cam], bg, opt, i + 1)) for i in range(8)]
     assert losses[-1] < losses[0] and np.isfinite(losses).all()
+
+
+def test_direct_gradient_sink_equals_autograd_accumulation_and_raises_nan_flag():
+    """FusedAdam(direct_grads=True): the renderer's backward adds into the flat gradient buffer itself (two views ->
+    accumulation) and maintains the NaN flag; must equal the autograd-accumulated gradients of direct_grads=False."""
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    cams = ring_cameras(2, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    g = torch.Generator().manual_seed(11)
+    weights = torch.randn(6, spec.H, spec.W, generator=g).to(dev)
+    flats = []
+    for direct in (True, False):
+        model = syn.make_model(spec, dev)
+        model.training_setup(OptimizationParams())
+        model.optimizer.direct_grads = direct
+        for cam in cams:
+            pkg = render(cam, model, FUSED, bg)
+            full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
+            (full * weights).sum().backward()
+        assert model.optimizer._direct_backwards == (2 if direct else 0)
+        assert int(model.optimizer.state_dev[1]) == 0
+        flats.append(model.optimizer.flat_grad.detach().cpu().numpy().copy())
+    scale = np.abs(flats[1]).max()
+    assert scale > 0 and np.abs(flats[0] - flats[1]).max() <= 1e-5 * scale
+    # a NaN parameter poisons its gradients: the producer-side flag must go up and the step must be skipped
+    model = syn.make_model(spec, dev)
+    model.training_setup(OptimizationParams())
+    with torch.no_grad():
+        model._opacity[3] = float("nan")
+    before = model.optimizer.flat_param.detach().clone()
+    pkg = render(cams[0], model, FUSED, bg)
+    torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0).sum().backward()
+    assert int(model.optimizer.state_dev[1]) == 1
+    model.optimizer.step(zero_grad=True, nan_scan=False)
+    after = model.optimizer.flat_param
+    same = (after == before) | (torch.isnan(after) & torch.isnan(before))
+    assert bool(same.all()) and int(model.optimizer.state_dev[0]) == 0 and int(model.optimizer.state_dev[1]) == 0
