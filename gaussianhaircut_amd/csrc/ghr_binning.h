@@ -58,18 +58,25 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect
                                                        const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
                                                        uint64_t* keys)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
-    if (idx >= P) return;
-    const rect4 r = rects[idx];
+    rect4 r = rect4{0u, 0u, 0u, 0u};
+    if (idx < P) r = rects[idx];
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
-    if (x1 <= x0 || y1 <= y0) return;
-    const uint64_t key = ((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx;
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const int t = y * gx + x;
-            const uint32_t pos = atomicAdd(&tile_cursor[t], 1u);
-            keys[tile_start[t] + pos] = key;
-        }
+    const int w = x1 - x0, area = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
+    const uint64_t key = area ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;
+    // lanes walk their k-th tile in lockstep; equal tiles share one returning atomic (wave_inc)
+    int max_area = area;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
+    int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
+    for (int k = 0; k < max_area; k++) {
+        const bool on = k < area;
+        const uint32_t pos = wave_inc(tile_cursor, (uint32_t)t, on);
+        if (on) keys[tile_start[t] + pos] = key;
+        if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+    }
+#endif
 }
 
 // Bitonic network in its "flip" form: every compare-exchange moves the smaller key to the lower index, so virtual

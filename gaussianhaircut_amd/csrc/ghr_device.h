@@ -122,6 +122,28 @@ __device__ __forceinline__ uint32_t wave_alloc(uint32_t n, uint32_t* counter)
     base = (uint32_t)__shfl((int)base, 63);
     return base + incl - n;
 }
+
+// Run-aggregated atomicAdd(&counter[t], 1) for every lane with `active`: a run of ADJACENT lanes that target the same
+// counter issues ONE atomic (strand Gaussians that are neighbours in memory are neighbours on screen: a wave's 64
+// increments collapse to a handful; incoherent inputs degrade to one atomic per lane plus ~15 VALU).  Returns the value
+// the counter had before THIS lane's increment (as a per-lane atomicAdd would).  Every lane of the wave must call it.
+__device__ __forceinline__ uint32_t wave_inc(uint32_t* counter, uint32_t t, bool active, bool want_result = true)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = active ? t : 0xffffffffu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool leader = lane == 0 || prev != key;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(leader);
+    const unsigned long long upto = (2ull << lane) - 1ull;             // bits 0..lane (lane 63: all ones)
+    const int lead = 63 - __builtin_clzll(lm & upto);                   // this lane's run leader (bit 0 is always set)
+    const unsigned long long after = lm & ~((2ull << lead) - 1ull);     // leaders above the run
+    const int end = after ? __builtin_ctzll(after) : 64;
+    uint32_t base = 0;
+    if (leader && active) base = atomicAdd(&counter[t], (uint32_t)(end - lead));
+    if (!want_result) return 0u;
+    base = (uint32_t)__shfl((int)base, lead);
+    return base + (uint32_t)(lane - lead);
+}
 #endif
 
 // ---- chip mapping ----------------------------------------------------------------------------------------------------

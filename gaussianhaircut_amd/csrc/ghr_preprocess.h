@@ -159,6 +159,23 @@ GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1,
     return true;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// tile_count[t] += 1 for every tile of every lane's rect (empty rect: x1 == x0), run-aggregated (wave_inc).  Lanes walk
+// their k-th tile in lockstep, so neighbouring Gaussians with equal rects merge perfectly.  All lanes of the wave call it.
+__device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1)
+{
+    const int w = x1 - x0, area = w * (y1 - y0);
+    int max_area = area;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
+    int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
+    for (int k = 0; k < max_area; k++) {
+        wave_inc(tile_count, (uint32_t)t, k < area, false);
+        if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+    }
+}
+#endif
+
 __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -166,12 +183,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     const bool ok = idx < a.P && preprocess_one(a, idx, x0, y0, x1, y1);
     const uint32_t base = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
-    if (!ok) return;
-    a.rects[idx].z = base;
+    if (ok) a.rects[idx].z = base;
     // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
     // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
 #endif
 }
 

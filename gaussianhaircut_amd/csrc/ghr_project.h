@@ -517,10 +517,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     const bool ok = idx < a.P && project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1);
     const uint32_t slot0 = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
-    if (!ok) return;
-    a.rects[idx].z = slot0;
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) atomicAdd(&a.tile_count[y * a.gx + x], 1u);
+    if (ok) a.rects[idx].z = slot0;
+    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
 #endif
 }
 
