@@ -59,22 +59,29 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect
                                                        uint64_t* keys)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
+    // A wavefront serves 16 Gaussians: lane = 16*q + i handles the rect ordinals q, q+4, q+8, ... of Gaussian i
+    // (4x shorter chains of returning atomics and 4x more waves in flight than one thread per Gaussian), while lanes
+    // that are neighbours within a 16-lane row still hold neighbouring Gaussians at the SAME ordinal, so equal tiles
+    // of strand neighbours share one atomic (wave_inc).
+    const int lane = threadIdx.x & 63, q = lane >> 4;
+    const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 16) + (lane & 15);
     rect4 r = rect4{0u, 0u, 0u, 0u};
     if (idx < P) r = rects[idx];
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
     const int w = x1 - x0, area = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
     const uint64_t key = area ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;
-    // lanes walk their k-th tile in lockstep; equal tiles share one returning atomic (wave_inc)
     int max_area = area;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
-    int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
-    for (int k = 0; k < max_area; k++) {
+    for (int off = 8; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));  // same in all 4 rows
+    // first ordinal q -> (kx, ky); afterwards advance by 4 without a division per step (w >= 1 when area > 0)
+    int ky = area ? q / w : 0, kx = area ? q - ky * w : 0;
+    for (int k = q; k - q < max_area; k += 4) {
         const bool on = k < area;
+        const int t = (y0 + ky) * gx + x0 + kx;
         const uint32_t pos = wave_inc(tile_cursor, (uint32_t)t, on);
         if (on) keys[tile_start[t] + pos] = key;
-        if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+        kx += 4;
+        while (on && kx >= w) { kx -= w; ky++; }
     }
 #endif
 }

@@ -203,7 +203,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     if (R > 0) {
         // append cursors start at 0 (k_tile_scan left them there; re-zeroed so that stage 2 may be replayed)
         GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
-        hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a->P, gx,
+        hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.depths, im.tile_start, im.tile_count, b.keys);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
                            b.point_list);

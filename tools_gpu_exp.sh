@@ -7,7 +7,13 @@ for so in $R/gaussianhaircut_amd/csrc/variants/*.so; do
 done | tee gpurun_out/kbench.log
 if [ -n "$KT" ]; then
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/tools_kbench.py ${CFG:-cfg3} 10 ) > gpurun_out/kt.log 2>&1
-  grep -E "k_render|k_scatter|k_tile|k_preprocess|k_geom" /tmp/kt/*/kt_kernel_stats.csv /tmp/kt/kt_kernel_stats.csv 2>/dev/null | cut -c1-200 | tee gpurun_out/kt_stats.log
+  python - <<PY | tee gpurun_out/kt_stats.log
+import csv,glob
+for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'ghr::' in r['Name']:
+            print('KT %-18s calls %3s avg %9.1f us min %9.1f us' % (r['Name'].split('(')[0].replace('ghr::',''), r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3))
+PY
 fi
 if [ -n "$PMC" ]; then
 i=0
