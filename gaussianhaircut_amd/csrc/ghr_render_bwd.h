@@ -8,12 +8,14 @@
 //   1. reduced across the 16 lanes of the cell with a register "halving butterfly" of DPP row operations
 //      (row_ror:8, row_half_mirror, quad_perm): 16 -> 8 -> 4 -> 2 -> 1 values per lane, lane l ends up holding the
 //      cell's total of component l (45 VALU, no LDS, no cross-row traffic),
-//   2. accumulated across the tile's 16 cells with one ds_add_f32 per lane into a per-batch LDS table,
-//   3. written once per (tile, Gaussian) INSTANCE as one 64-byte line (4 plain b128 stores) into the instance's own
-//      gradient slot (rect4_slot); the per-Gaussian backward sums a Gaussian's slots in a fixed order.
-// => no global float atomics at all: the 16 dword-granular device-scope atomics per instance (measured: 40 % of this
-//    kernel's time on MI355X, every one a fabric transaction) are gone, and the cross-tile sum has a fixed order (the
-//    only order-dependent float sums left are the ds_add_f32 accumulations inside one tile).
+//   2. accumulated across the tile's 16 cells straight into the (tile, Gaussian) INSTANCE's own 64-byte gradient slot
+//      (rect4_slot) with ONE workgroup-scope global_atomic_add_f32 per lane: the 16 lanes of a cell hit one cache line,
+//      and because only this workgroup ever touches the slot the atomic is resolved in the XCD's L2 (no sc1 / fabric
+//      round trip).  The slot line is zero-filled by the staging thread of the entry before the barrier that precedes
+//      the walk.  Measured on MI355X (cfg3): an LDS table with ds_add_f32 cost 24 % of the kernel (LDS float atomics
+//      retire ~1.8 cycles per lane), device-scope atomics on a per-Gaussian line 40 %, this form is free.
+//   3. summed per Gaussian over its instance slots in a fixed order by the per-Gaussian backward (k_geom_bwd /
+//      k_project_bwd) -- no cross-tile float atomics.
 //
 // The per-channel recurrences of the reference (accum_rec[ch], last_color[ch], backward.cu:519-523) are linear in the
 // channel index and only ever used through sum_ch(. * dL_dpixel[ch]); they are carried as ONE scalar
@@ -136,7 +138,6 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
     __shared__ uint32_t s_slot[GHR_BLOCK];
-    __shared__ float s_acc[GHR_BLOCK * 16];
     __shared__ uint32_t s_max[4];
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
@@ -181,22 +182,21 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
 
     for (uint32_t base = 0; base < n_eff; base += GHR_BLOCK) {
         const uint32_t cnt = min((uint32_t)GHR_BLOCK, n_eff - base);
-        __syncthreads();  // previous batch fully consumed (LDS planes + accumulators)
+        __syncthreads();  // previous batch fully consumed (LDS planes)
         if ((uint32_t)tid < cnt) {
             // walk back to front: batch entry j is list position n_eff-1-(base+j)
             const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)id;
             const f4 a0 = r[0], a1 = r[1];
-            s_slot[tid] = rect4_slot(rects[id], tx, ty);
+            const uint32_t slot = rect4_slot(rects[id], tx, ty);
+            f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)slot;  // zero the instance's gradient line
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
+            dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
+            s_slot[tid] = slot;
             s_r0[tid] = a0; s_r1[tid] = a1; s_r2[tid] = r[2]; s_r3[tid] = r[3];
             s_bb[tid] = alpha_bbox(a0, a1);
         }
-        {
-            f4* z = reinterpret_cast<f4*>(s_acc) + 4 * tid;
-            const f4 zero = {0.f, 0.f, 0.f, 0.f};
-            z[0] = zero; z[1] = zero; z[2] = zero; z[3] = zero;
-        }
-        __syncthreads();
+        __syncthreads();  // also orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
 
         for (uint32_t sub = 0; sub < cnt; sub += 64) {
             // per-GROUP ordered list (64-bit mask) of the entries whose alpha >= 1/255 box touches the group's cell
@@ -213,15 +213,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                 bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy,
                          g);
                 const float v = row_reduce16(g, l);
-                atomicAdd(&s_acc[j * 16 + l], v);  // ds_add_f32: lane l adds component l of the cell's total
+                // lane l adds component l of the cell's total: 16 lanes -> one 64-B line, resolved in this XCD's L2
+                __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + l, v, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
             }
-        }
-        __syncthreads();
-
-        if ((uint32_t)tid < cnt) {  // every staged instance writes its line (zeros when nothing contributed)
-            const f4* a4 = reinterpret_cast<const f4*>(s_acc) + 4 * tid;
-            f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)s_slot[tid];
-            dst[0] = a4[0]; dst[1] = a4[1]; dst[2] = a4[2]; dst[3] = a4[3];
         }
     }
     // list entries no pixel of the tile ever reached (positions >= n_eff): their slots must read as zero
