@@ -273,6 +273,21 @@ class GaussianModel:
                                                              keepdim=True)
         self.denom[update_filter] += 1
 
+    @torch.no_grad()
+    def precompute_head(self):
+        """Freeze the non-hair ("head", label < 0.5) Gaussians for the strand stage: the ``*_precomp`` attributes
+        ``render_hair()`` reads (reference: src/train_strands.py:65-73)."""
+        self.mask_precomp = self.get_label[..., 0] < 0.5
+        m = self.mask_precomp
+        self.xyz_precomp = self.get_xyz[m].detach()
+        self.opacity_precomp = self.get_opacity[m].detach()
+        self.scaling_precomp = self.get_scaling[m].detach()
+        self.rotation_precomp = self.get_rotation[m].detach()
+        self.cov3D_precomp = self.get_covariance(1.0)[m].detach()
+        n_coef = (self.max_sh_degree + 1) ** 2
+        self.shs_view = self.get_features[m].detach().transpose(1, 2).reshape(-1, 3, n_coef)
+        return self
+
     def leaf_parameters(self):
         ps = [self._xyz, self._features_dc, self._features_rest, self._opacity, self._label, self._scaling,
               self._rotation, self._orient_conf]

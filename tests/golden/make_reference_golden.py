@@ -8,7 +8,8 @@ What is pinned: ``GaussianModel.get_covariance / get_conic / get_mean_2d / get_d
 filter_points`` (src/scene/gaussian_model.py:143-393), ``eval_sh`` (src/utils/sh_utils.py:57-112), ``build_rotation``,
 ``strip_symmetric``, ``get_expon_lr_func``, ``parallel_transport`` (src/utils/general_utils.py),
 ``getProjectionMatrix`` / ``getWorld2View2`` (src/utils/graphics_utils.py), ``l1_loss`` / ``ssim`` / ``or_loss``
-(src/utils/loss_utils.py).  The reference modules hard-code device="cuda" and import plyfile / simple_knn, which do
+(src/utils/loss_utils.py), and the strand model's ``initialize_gaussians_hair`` / ``get_conic`` (eps 1e-7) /
+``get_direction_2d`` / ``filter_points`` (src/scene/gaussian_model_strands.py:143-452).  The reference modules hard-code device="cuda" and import plyfile / simple_knn, which do
 not exist here: the script stubs those two modules and redirects "cuda" tensor factories to the CPU.  Nothing from
 the reference is copied into the repository -- only numeric outputs.
 """
@@ -94,6 +95,46 @@ def main():
             out[cfg + "/sh%d" % deg] = ref_sh.eval_sh(deg, shs_view, d).numpy()
         out[cfg + "/view"] = cam.world_view_transform.numpy()
         out[cfg + "/proj"] = cam.full_proj_transform.numpy()
+
+    # ---- the strand-parametrised model (src/scene/gaussian_model_strands.py): its module imports trimesh / pysdf /
+    # NeuralHaircut networks at import time and builds them in __init__; stub the imports, bypass __init__ and drive
+    # the projection helpers (:143-452) directly on explicit strand tensors.
+    for name in ("trimesh", "pysdf", "src", "src.hair_networks", "src.hair_networks.optimizable_textured_strands",
+                 "src.hair_networks.strand_prior"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["pysdf"].SDF = None
+    sys.modules["src.hair_networks.optimizable_textured_strands"].OptimizableTexturedStrands = None
+    sys.modules["src.hair_networks.strand_prior"].Decoder = None
+    sys.modules["src.hair_networks.strand_prior"].Encoder = None
+    ref_gms = _load("ref_gaussian_model_strands", os.path.join(REF, "scene", "gaussian_model_strands.py"))
+    spec = syn.CONFIGS["tiny_strands"]
+    cam = syn.make_view(spec)
+    gs = torch.Generator().manual_seed(77)
+    S, n_seg = 24, 12
+    origins = torch.nn.functional.normalize(torch.randn(S, 1, 3, generator=gs), dim=-1) * 0.8
+    dirs = torch.randn(S, n_seg, 3, generator=gs) * 0.02 + torch.randn(S, 1, 3, generator=gs) * 0.03
+    feats = torch.randn(S * n_seg, 16, 3, generator=gs) * 0.1
+    m = object.__new__(ref_gms.GaussianModelCurves)
+    m.setup_functions()
+    m.active_sh_degree = m.max_sh_degree = 3
+    m.pts_origins, m._dirs = origins, dirs
+    m._features_dc, m._features_rest = feats[:, :1], feats[:, 1:]
+    m._orient_conf = torch.zeros(S * n_seg, 1)
+    m.scale, m.use_sds = 1e-3, False
+    m.initialize_gaussians_hair()
+    out["strands/origins"], out["strands/dirs"], out["strands/features"] = origins.numpy(), dirs.numpy(), feats.numpy()
+    out["strands/xyz"], out["strands/rotation"] = m._xyz.numpy(), m._rotation.numpy()
+    out["strands/scaling"] = m._scaling.numpy()
+    conic = m.get_conic(cam)
+    out["strands/conic"] = conic.numpy()
+    out["strands/cov2d"] = m.cov.numpy()  # this class caches the 2D covariance in .cov (gaussian_model_strands.py:300)
+    out["strands/cov3D"] = m.get_covariance().numpy()
+    out["strands/mean2d"] = m.get_mean_2d(cam).numpy()
+    out["strands/depths"] = m.get_depths(cam).numpy()
+    out["strands/dir2d"] = m.get_direction_2d(cam).numpy()
+    out["strands/mask"] = m.filter_points(cam).numpy()
+    out["strands/opacity"], out["strands/label"] = m.get_opacity.numpy(), m.get_label.numpy()
+    out["strands/orient_conf"] = m.get_orient_conf.numpy()
 
     g = torch.Generator().manual_seed(123)
     q = torch.randn(64, 4, generator=g)

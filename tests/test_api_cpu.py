@@ -135,3 +135,73 @@ def test_training_step_decreases_loss_with_oracle_backend():
         model.training_setup(opt)
         losses = [float(training_step(model, [cam], syn.background(), opt, it + 1)) for it in range(6)]
     assert losses[-1] < losses[0]
+
+
+def _hair_scene(dev="cpu"):
+    """A frozen head (free Gaussians, half of them labelled head) + explicit strands, as src/train_strands.py sets up."""
+    from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
+    spec = syn.CONFIGS["tiny"]
+    head = syn.make_model(spec, dev)
+    with torch.no_grad():
+        head._label[: spec.P // 2] = -4.0   # sigmoid < 0.5 -> head
+        head._label[spec.P // 2:] = 4.0     # hair-labelled free Gaussians are dropped in the strand stage
+    head.precompute_head()
+    g = torch.Generator().manual_seed(9)
+    S, n_seg = 40, 10
+    origins = torch.nn.functional.normalize(torch.randn(S, 1, 3, generator=g), dim=-1) * 0.9
+    dirs = torch.randn(S, n_seg, 3, generator=g) * 0.015 + torch.randn(S, 1, 3, generator=g) * 0.03
+    feats = torch.randn(S * n_seg, 16, 3, generator=g) * 0.2
+    hair = GaussianModelStrands(3).create_from_strands(origins.to(dev), dirs.to(dev), feats.to(dev))
+    return spec, head, hair, syn.make_view(spec, dev)
+
+
+def test_render_hair_dict_gradients_and_plumbing_with_oracle_backend():
+    """render_hair() (reference gaussian_renderer/__init__.py:116-214): head + hair concatenation, keep mask, radii
+    scatter, gradients reach the strand parameters only."""
+    import oracle
+    from gaussianhaircut_amd.gaussian_renderer import render_hair
+    from tests import helpers as hp
+    spec, head, hair, cam = _hair_scene()
+    n_head, n_hair = int(head.mask_precomp.sum()), hair.get_xyz.shape[0]
+    with oracle_rasterizer():
+        pkg = render_hair(cam, head, hair, PIPE, syn.background())
+        assert set(pkg) == {"render", "mask", "orient_angle", "orient_conf", "viewspace_points", "visibility_filter",
+                            "radii"}
+        assert pkg["render"].shape == (3, spec.H, spec.W) and pkg["radii"].shape == (n_head + n_hair,)
+        assert (pkg["visibility_filter"] == (pkg["radii"] > 0)).all() and pkg["radii"].max() > 0
+        (pkg["render"].sum() + pkg["mask"].sum() * 0.5 + pkg["orient_conf"].sum() + pkg["orient_angle"].sum()).backward()
+    assert hair._dirs.grad is not None and torch.isfinite(hair._dirs.grad).all() and hair._dirs.grad.abs().sum() > 0
+    assert hair._features_dc.grad.abs().sum() > 0 and hair._orient_conf.grad.abs().sum() > 0
+    # (as in the reference, the head's conic / depth are not detached; the head is frozen by not being optimised)
+    assert not head.xyz_precomp.requires_grad and not head.shs_view.requires_grad
+    # hair label channel: head Gaussians splat label 0, strands label 1 -> mask[0] <= mask[1] (foreground) everywhere
+    m = pkg["mask"].detach()
+    assert (m[0] <= m[1] + 1e-5).all() and m[0].max() > 0.1
+    # plumbing: the same inputs straight through the oracle (mode A_sr: scales/rotations AND conic given)
+    with torch.no_grad():
+        xyz = torch.cat([head.xyz_precomp, hair.get_xyz])
+        keep = torch.cat([head.filter_points(cam)[head.mask_precomp], hair.filter_points(cam)])
+        conic = torch.cat([head.get_conic(cam)[head.mask_precomp], hair.get_conic(cam)])
+        out, radii, _ = oracle.rasterize_forward(
+            hp.np32(syn.background()), hp.np32(xyz[keep]), hp.np32(_hair_colors(head, hair, cam)[keep]),
+            hp.np32(torch.cat([head.opacity_precomp, hair.get_opacity])[keep]), hp.np32(cam.world_view_transform),
+            hp.np32(cam.full_proj_transform), math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5), spec.H, spec.W,
+            scales=hp.np32(torch.cat([head.scaling_precomp, hair.get_scaling])[keep]),
+            rotations=hp.np32(torch.cat([head.rotation_precomp, hair.get_rotation])[keep]), conic_precomp=hp.np32(conic[keep]))
+    assert np.abs(out[:3] - pkg["render"].detach().numpy()).max() < 1e-6
+    assert (pkg["radii"][keep].numpy() == radii).all() and (pkg["radii"][~keep] == 0).all()
+
+
+def _hair_colors(head, hair, cam):
+    """The 10 features render_hair() assembles (reference :160-186), restated for the plumbing check."""
+    from gaussianhaircut_amd.gaussian_renderer import _sh_to_rgb
+    m = head.mask_precomp
+    xyz = torch.cat([head.xyz_precomp, hair.get_xyz])
+    shs = torch.cat([head.shs_view, hair.get_features.transpose(1, 2).reshape(-1, 3, 16)])
+    rgb = _sh_to_rgb(hair.active_sh_degree, shs, xyz, cam.camera_center)
+    z1 = torch.zeros_like(head.xyz_precomp[:, :1])
+    label = torch.cat([z1, hair.get_label])
+    dir2d = torch.cat([torch.zeros_like(head.xyz_precomp), hair.get_direction_2d(cam)])
+    conf = torch.cat([z1, hair.get_orient_conf])
+    depth = torch.cat([head.get_depths(cam)[m], hair.get_depths(cam)])
+    return torch.cat([rgb, label, torch.ones_like(label), dir2d, conf, depth], dim=-1)

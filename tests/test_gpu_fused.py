@@ -109,3 +109,41 @@ def test_direct_gradient_sink_equals_autograd_accumulation_and_raises_nan_flag()
     after = model.optimizer.flat_param
     same = (after == before) | (torch.isnan(after) & torch.isnan(before))
     assert bool(same.all()) and int(model.optimizer.state_dev[0]) == 0 and int(model.optimizer.state_dev[1]) == 0
+
+
+def test_render_hair_gpu_matches_cpu_oracle_path():
+    """render_hair() on the HIP rasterizer (mode A_sr) vs the same host code driving the CPU oracle: image, radii and
+    the gradients that reach the strand parameters."""
+    from gaussianhaircut_amd.gaussian_renderer import render_hair
+    from tests.oracle_backend import oracle_rasterizer
+    from tests.test_api_cpu import _hair_scene
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    res = {}
+    for where in ("cpu", dev):
+        spec, head, hair, cam = _hair_scene(where)
+        w = torch.randn(7, spec.H, spec.W, generator=torch.Generator().manual_seed(3)).to(where)
+        bg = syn.background(where)
+        if where == "cpu":
+            with oracle_rasterizer():
+                pkg = render_hair(cam, head, hair, GENERIC, bg)
+                full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
+                (full * w).sum().backward()
+        else:
+            pkg = render_hair(cam, head, hair, GENERIC, bg)
+            full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
+            (full * w).sum().backward()
+        res[str(where)] = (full.detach().cpu().numpy(), pkg["radii"].cpu().numpy(),
+                           {n: getattr(hair, n).grad.detach().cpu().numpy() for n in
+                            ("_dirs", "_features_dc", "_features_rest", "_orient_conf")})
+    (img_c, rad_c, g_c), (img_g, rad_g, g_g) = res["cpu"], res[str(dev)]
+    assert (rad_c != rad_g).mean() < 1e-3
+    err = np.abs(img_c[:6] - img_g[:6]) / np.maximum(1.0, np.abs(img_c[:6]))
+    assert np.quantile(err, 0.999) < 1e-4
+    for k in g_c:
+        a, b = g_g[k].reshape(len(g_g[k]), -1), g_c[k].reshape(len(g_c[k]), -1)
+        assert np.isfinite(a).all()
+        scale = np.abs(b).max() + 1e-30
+        rows = np.abs(b).max(axis=1, keepdims=True)
+        e = np.abs(a - b) / (rows + 1e-3 * scale)
+        assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())
