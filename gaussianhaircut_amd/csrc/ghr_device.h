@@ -202,18 +202,64 @@ GHR_HD bool bbox_hits(const f4& bb, float x0, float x1, float y0, float y1)
     return !(bb.y < x0 || bb.x > x1 || bb.w < y0 || bb.z > y1);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// Per-lane 64-bit list of the batch entries sub..sub+63 whose alpha box touches this lane's cell: lane L tests entry
-// sub+L against the wave's four cells (x ranges cx0[g]..cx0[g]+3, shared y range), four ballots, and every lane
-// keeps the ballot of its own group.
-__device__ __forceinline__ unsigned long long cell_masks(const f4& bb, bool valid, float wx0, float cy0, float cy1,
-                                                         int grp)
+// Second, tighter stage of the cull: the alpha >= 1/255 region is the ELLIPSE q(d) = cx dx^2 + 2 cy dx dy + cz dy^2
+// <= thr = 2 ln(255 o) (d = mean - pixel), and its bounding box over-covers badly for diagonal needles and for blobs
+// (corners).  A 4x4 cell spans the full height of its wave's 4-row band, so a cell can hold a contributing pixel only
+// if the x-extent of (ellipse ∩ band) overlaps the cell's columns.  That extent is exact and cheap: for a fixed dy the
+// ellipse covers dx in (-cy dy -+ sqrt(cx thr - det dy^2)) / cx, and the right / left-most points over the band are
+// reached at dy = clamp(-+k, band) with k = cy hx / cz the dy of the ellipse's own extreme points.
+// ellipse_params returns {cx*thr, det, 1/cx, k}; thr carries a 2 % + 0.05 margin (fp32 evaluation order differs from
+// the per-pixel `power`), the interval another 0.02 px.  Conics that are not comfortably positive definite or extremely
+// anisotropic (cancellation in det) get det = -1 (box test only).
+GHR_HD f4 ellipse_params(const f4& r0, const f4& r1)
 {
-    const bool yhit = valid && !(bb.w < cy0 || bb.z > cy1);
-    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 || bb.x > wx0 + 3.0f));
-    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 4.0f || bb.x > wx0 + 7.0f));
-    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 8.0f || bb.x > wx0 + 11.0f));
-    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(yhit && !(bb.y < wx0 + 12.0f || bb.x > wx0 + 15.0f));
+    const float o = r1.y, cx = r0.z, cy = r0.w, cz = r1.x;
+    const float det = cx * cz - cy * cy;
+    const float L = logf(255.0f * fmaxf(o, 1.0e-30f));
+    if (!(L >= 1.0e-3f) || !(cx > 0.0f) || !(cz > 0.0f) || !(det > 1.0e-4f * cx * cz) || !(L < 100.0f))
+        return f4{0.f, -1.f, 0.f, 0.f};
+    const float thr = 2.04f * L + 0.05f;
+    const float hx = sqrtf(thr * cz / det);
+    const float k = cy * hx / cz;
+    if (!(hx < 3.0e38f) || !(fabsf(k) < 3.0e38f)) return f4{0.f, -1.f, 0.f, 0.f};
+    return f4{cx * thr, det, 1.0f / cx, k};
+}
+// x-extent [lo, hi] (in d = mean - pixel) of the ellipse restricted to the band dy in [ay, by]; the band must
+// intersect the ellipse's y-extent (the box test guarantees it).  Degenerate conics: the whole axis.
+GHR_HD void ellipse_band_extent(float cy, const f4& ep, float ay, float by, float& lo, float& hi)
+{
+    if (!(ep.y > 0.0f)) { lo = -3.0e38f; hi = 3.0e38f; return; }
+    const float dyr = fminf(by, fmaxf(ay, -ep.w)), dyl = fminf(by, fmaxf(ay, ep.w));
+    const float Dr = fmaxf(ep.x - ep.y * dyr * dyr, 0.0f), Dl = fmaxf(ep.x - ep.y * dyl * dyl, 0.0f);
+    hi = (-cy * dyr + sqrtf(Dr)) * ep.z + 0.02f;
+    lo = (-cy * dyl - sqrtf(Dl)) * ep.z - 0.02f;
+}
+// Full per-cell test used by the render kernels (and, pixel by pixel, by tests/hostsim): box, then ellipse extent.
+// (X0, Y0) = pixel coordinates of the cell's first pixel; the cell spans X0..X0+3, Y0..Y0+3.
+GHR_HD bool cell_hit(const f4& bb, const f4& ep, const f4& r0, float X0, float Y0)
+{
+    if (!bbox_hits(bb, X0, X0 + 3.0f, Y0, Y0 + 3.0f)) return false;
+    float lo, hi;
+    ellipse_band_extent(r0.w, ep, r0.y - (Y0 + 3.0f), r0.y - Y0, lo, hi);
+    return !(hi < r0.x - (X0 + 3.0f) || lo > r0.x - X0);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Per-lane 64-bit list of the batch entries sub..sub+63 whose alpha >= 1/255 region can touch this lane's cell: lane L
+// tests entry sub+L against the wave's four cells (X0 = wx0 + 4g, shared band Y0 = cy0 .. cy0+3): one band extent,
+// four interval overlaps, four ballots; every lane keeps the ballot of its own group.
+__device__ __forceinline__ unsigned long long cell_masks(const f4& bb, const f4& ep, const f4& r0, bool valid, float wx0,
+                                                         float cy0, int grp)
+{
+    const bool yhit = valid && !(bb.w < cy0 || bb.z > cy0 + 3.0f);
+    float lo, hi;
+    ellipse_band_extent(r0.w, ep, r0.y - (cy0 + 3.0f), r0.y - cy0, lo, hi);
+    // pixel-space x-interval of the band-restricted ellipse, intersected with the box
+    const float xl = fmaxf(bb.x, r0.x - hi), xr = fminf(bb.y, r0.x - lo);
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(yhit && !(xr < wx0 || xl > wx0 + 3.0f));
+    const unsigned long long m1 = __builtin_amdgcn_ballot_w64(yhit && !(xr < wx0 + 4.0f || xl > wx0 + 7.0f));
+    const unsigned long long m2 = __builtin_amdgcn_ballot_w64(yhit && !(xr < wx0 + 8.0f || xl > wx0 + 11.0f));
+    const unsigned long long m3 = __builtin_amdgcn_ballot_w64(yhit && !(xr < wx0 + 12.0f || xl > wx0 + 15.0f));
     return grp == 0 ? m0 : (grp == 1 ? m1 : (grp == 2 ? m2 : m3));
 }
 #endif

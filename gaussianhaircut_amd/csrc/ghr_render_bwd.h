@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                                                           const rect4* __restrict__ rects, float* ginst)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
+    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
     __shared__ uint32_t s_slot[GHR_BLOCK];
     __shared__ uint32_t s_max[4];
 
@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     const float pxf = (float)px, pyf = (float)py;
     const size_t pix = (size_t)W * py + px, plane = (size_t)W * H;
     const float wx0 = (float)(tx * GHR_TILE_X);
-    const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave), cy1 = cy0 + 3.0f;
+    const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave);
 
     const uint32_t beg = tile_start[tile];
     const uint32_t n = tile_start[tile + 1] - beg;
@@ -195,13 +195,15 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             s_slot[tid] = slot;
             s_r0[tid] = a0; s_r1[tid] = a1; s_r2[tid] = r[2]; s_r3[tid] = r[3];
             s_bb[tid] = alpha_bbox(a0, a1);
+            s_ep[tid] = ellipse_params(a0, a1);
         }
         __syncthreads();  // also orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
 
         for (uint32_t sub = 0; sub < cnt; sub += 64) {
             // per-GROUP ordered list (64-bit mask) of the entries whose alpha >= 1/255 box touches the group's cell
             const uint32_t e = sub + lane;
-            unsigned long long todo = cell_masks(s_bb[e < cnt ? e : 0], e < cnt, wx0, cy0, cy1, grp);
+            const uint32_t ec = e < cnt ? e : 0;
+            unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
             // entry j sits at list position n_eff-1-(base+j); positions >= gmax are dead for this cell
             const long long jmin = (long long)n_eff - (long long)gmax - (long long)(base + sub);
             if (jmin > 0) todo = jmin >= 64 ? 0ull : (todo & (~0ull << jmin));

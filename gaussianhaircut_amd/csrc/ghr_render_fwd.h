@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           uint32_t* __restrict__ n_contrib)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK];
+    __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
     const int tx = tile % gx, ty = tile / gx;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const float wx0 = (float)(tx * GHR_TILE_X);
-    const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave), cy1 = cy0 + 3.0f;
+    const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave);
 
     const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
     const uint32_t n = end - beg;
@@ -101,6 +101,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
         if (__syncthreads_count(done) == GHR_BLOCK) break;
         s_r0[tid] = g0; s_r1[tid] = g1; s_r2[tid] = g2; s_r3[tid] = g3;
         s_bb[tid] = alpha_bbox(g0, g1);
+        s_ep[tid] = ellipse_params(g0, g1);
         __syncthreads();
         if (base + GHR_BLOCK < n) GHR_GATHER(base + GHR_BLOCK);
 
@@ -109,7 +110,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             const unsigned long long alive = __builtin_amdgcn_ballot_w64(!done);
             if (alive == 0) break;  // wave-uniform: all 64 pixels finished
             const uint32_t e = sub + lane;
-            unsigned long long todo = cell_masks(s_bb[e < cnt ? e : 0], e < cnt, wx0, cy0, cy1, grp);
+            const uint32_t ec = e < cnt ? e : 0;
+            unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);

@@ -110,10 +110,10 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
             for (int c = 0; c < GHR_C; c++) st.C[c] = 0.f;
             bool done = false;
             // k_render_fwd's cull: the 4x4-pixel cell this pixel belongs to
-            const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sx1 = sx0 + 3.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
+            const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sy0 = (float)(ty * 16 + 4 * (tid >> 6));
             for (uint32_t j = 0; j < n && !done; j++) {
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)s->point_list[beg + j];
-                if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_fwd's cell cull
+                if (!ghr::cell_hit(ghr::alpha_bbox(r[0], r[1]), ghr::ellipse_params(r[0], r[1]), r[0], sx0, sy0)) continue;  // k_render_fwd's cell cull
                 done = ghr::fwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
             }
             const size_t pix = (size_t)a->W * py + px;
@@ -174,8 +174,8 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                 const uint32_t id = s->point_list[beg + pos];
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)id;
                 {
-                    const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sx1 = sx0 + 3.f, sy0 = (float)(ty * 16 + 4 * (tid >> 6)), sy1 = sy0 + 3.f;
-                    if (!ghr::bbox_hits(ghr::alpha_bbox(r[0], r[1]), sx0, sx1, sy0, sy1)) continue;  // k_render_bwd's cell cull
+                    const float sx0 = (float)(tx * 16 + 4 * ((tid & 15) >> 2)), sy0 = (float)(ty * 16 + 4 * (tid >> 6));
+                    if (!ghr::cell_hit(ghr::alpha_bbox(r[0], r[1]), ghr::ellipse_params(r[0], r[1]), r[0], sx0, sy0)) continue;  // k_render_bwd's cell cull
                 }
                 float g[16];
                 // branch-free step: non-contributing visits (pos >= n_contrib of THIS pixel included) run with alpha = 0
@@ -261,6 +261,9 @@ int ghrsim_bbox_violations(const float* rec16, int n, int W, int H)
                 const float alpha = fminf(0.99f, r[1].y * ghr::fast_exp(power));
                 if (alpha < 1.0f / 255.0f) continue;
                 if (!ghr::bbox_hits(bb, (float)x, (float)x, (float)y, (float)y)) bad++;
+                // ... and the 4x4 cell that holds the pixel must pass the box + ellipse test of the render kernels
+                const float X0 = (float)(x & ~3), Y0 = (float)(y & ~3);
+                if (!ghr::cell_hit(bb, ghr::ellipse_params(r[0], r[1]), r[0], X0, Y0)) bad++;
             }
     }
     return bad;

@@ -85,7 +85,7 @@ def test_bitonic_network_any_length(hostsim):
 
 
 def test_alpha_bbox_is_conservative(hostsim):
-    """The strip-culling box of k_render_fwd / k_render_bwd must contain every pixel the per-pixel alpha test accepts,
+    """The culling box AND the per-cell box+ellipse test of k_render_fwd / k_render_bwd must keep every pixel the per-pixel alpha test accepts,
     including needle-like conics, opacities at the 1/255 threshold, huge and degenerate splats."""
     import ctypes
     rng = np.random.default_rng(5)
