@@ -31,9 +31,11 @@
 
 namespace ghr {
 
+typedef float f2 __attribute__((ext_vector_type(2)));  // pairs of channels: v_pk_mul_f32 / v_pk_fma_f32 (2 flops/lane/issue)
+
 struct PixBwd {
     float T, T_final, S, last_alpha, last_cdot, bgdot;
-    float dL[GHR_C];
+    f2 dL[GHR_C / 2];  // dL/dpixel of the 10 channels, channel pairs (0,1) (2,3) ...
 };
 
 // One list entry applied to one pixel (backward.cu:494-558).  `live` = the entry lies below the pixel's n_contrib
@@ -55,16 +57,13 @@ GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, c
     s.T = s.T * inv1ma;  // backward.cu:507
     const float w = alpha * s.T;
 
-    float cdot = r1.z * s.dL[0];
-    cdot = fma_(r1.w, s.dL[1], cdot);
-    cdot = fma_(r2.x, s.dL[2], cdot);
-    cdot = fma_(r2.y, s.dL[3], cdot);
-    cdot = fma_(r2.z, s.dL[4], cdot);
-    cdot = fma_(r2.w, s.dL[5], cdot);
-    cdot = fma_(r3.x, s.dL[6], cdot);
-    cdot = fma_(r3.y, s.dL[7], cdot);
-    cdot = fma_(r3.z, s.dL[8], cdot);
-    cdot = fma_(r3.w, s.dL[9], cdot);
+    // colour . dL/dpixel over the 10 channels, two channels per packed FMA
+    f2 cd = f2{r1.z, r1.w} * s.dL[0];
+    cd = __builtin_elementwise_fma(f2{r2.x, r2.y}, s.dL[1], cd);
+    cd = __builtin_elementwise_fma(f2{r2.z, r2.w}, s.dL[2], cd);
+    cd = __builtin_elementwise_fma(f2{r3.x, r3.y}, s.dL[3], cd);
+    cd = __builtin_elementwise_fma(f2{r3.z, r3.w}, s.dL[4], cd);
+    const float cdot = cd.x + cd.y;
     // backward.cu:519-523 collapsed to scalars (see header)
     s.S = fma_(s.last_alpha, s.last_cdot, (1.f - s.last_alpha) * s.S);
     s.last_cdot = cdot;
@@ -83,7 +82,11 @@ GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, c
     g[4] = -0.5f * gdy * dy * dL_dG;     // :555
     g[5] = G * dL_dalpha;                // :558
 #pragma unroll
-    for (int i = 0; i < GHR_C; i++) g[6 + i] = w * s.dL[i];  // :508,:527
+    for (int i = 0; i < GHR_C / 2; i++) {  // :508,:527
+        const f2 gc = s.dL[i] * w;
+        g[6 + 2 * i] = gc.x;
+        g[7 + 2 * i] = gc.y;
+    }
     return c;
 }
 
@@ -100,28 +103,45 @@ __device__ __forceinline__ float dpp_get(float v)
 // Sum 16 per-lane values over the 16 lanes of a DPP row.  On return lane l (0..15 within its row) holds the row's
 // total of component l.  Each stage pairs a lane with a partner that differs in one more bit of l, keeps half of its
 // values and receives the partner's copy of the same half: 8 + 4 + 2 + 1 exchanges.
+// The first two stages (partners l ^ 8 and l ^ 7) split the lanes along whole 4-lane banks, so "keep mine / take the
+// partner's" is expressed with the DPP bank write mask instead of v_cndmask: two v_add_f32_dpp per output
+//     h = g_lo + partner(g_lo)   written by the banks that keep the low half
+//     h = g_hi + partner(g_hi)   written by the other banks
+// (hand-written: the compiler cannot derive the masked form).  s_nop 1 covers the "VALU write -> DPP read" hazard at
+// the block boundaries, which the hazard recogniser does not see through inline asm.  33 VALU in total.
 __device__ __forceinline__ float row_reduce16(const float* g, int l)
 {
-    const bool b3 = (l & 8) != 0, b2 = (l & 4) != 0, b1 = (l & 2) != 0, b0 = (l & 1) != 0;
-    float h[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) {  // partner l ^ 8; lanes with b3 keep components 8..15
-        const float keep = b3 ? g[8 + i] : g[i], send = b3 ? g[i] : g[8 + i];
-        h[i] = keep + dpp_get<0>(send);
-    }
-    float q[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // partner l ^ 7 (flips b2); lanes with b2 keep the upper 4 of their 8
-        const float keep = b2 ? h[4 + i] : h[i], send = b2 ? h[i] : h[4 + i];
-        q[i] = keep + dpp_get<1>(send);
-    }
-    float e[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {  // partner l ^ 2
-        const float keep = b1 ? q[2 + i] : q[i], send = b1 ? q[i] : q[2 + i];
-        e[i] = keep + dpp_get<2>(send);
-    }
-    const float keep = b0 ? e[1] : e[0], send = b0 ? e[0] : e[1];  // partner l ^ 1
+    float h0, h1, h2, h3, h4, h5, h6, h7;
+#define GHR_PAIR(d, lo, hi, ctrl, mlo, mhi)                                                   \
+    "v_add_f32_dpp " d ", " lo ", " lo " " ctrl " row_mask:0xf bank_mask:" mlo "\n\t"          \
+    "v_add_f32_dpp " d ", " hi ", " hi " " ctrl " row_mask:0xf bank_mask:" mhi "\n\t"
+    asm volatile("s_nop 1\n\t"  // partner l ^ 8: banks 0,1 keep components 0..7, banks 2,3 keep 8..15
+                 GHR_PAIR("%0", "%8", "%16", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%1", "%9", "%17", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%2", "%10", "%18", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%3", "%11", "%19", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%4", "%12", "%20", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%5", "%13", "%21", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%6", "%14", "%22", "row_ror:8", "0x3", "0xc")
+                 GHR_PAIR("%7", "%15", "%23", "row_ror:8", "0x3", "0xc")
+                 : "=&v"(h0), "=&v"(h1), "=&v"(h2), "=&v"(h3), "=&v"(h4), "=&v"(h5), "=&v"(h6), "=&v"(h7)
+                 : "v"(g[0]), "v"(g[1]), "v"(g[2]), "v"(g[3]), "v"(g[4]), "v"(g[5]), "v"(g[6]), "v"(g[7]),
+                   "v"(g[8]), "v"(g[9]), "v"(g[10]), "v"(g[11]), "v"(g[12]), "v"(g[13]), "v"(g[14]), "v"(g[15]));
+    float q0, q1, q2, q3;
+    asm volatile(  // partner l ^ 7 (flips bit 2): banks 0,2 keep the lower four of their eight, banks 1,3 the upper
+                 GHR_PAIR("%0", "%4", "%8", "row_half_mirror", "0x5", "0xa")
+                 GHR_PAIR("%1", "%5", "%9", "row_half_mirror", "0x5", "0xa")
+                 GHR_PAIR("%2", "%6", "%10", "row_half_mirror", "0x5", "0xa")
+                 GHR_PAIR("%3", "%7", "%11", "row_half_mirror", "0x5", "0xa")
+                 "s_nop 1"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2), "=&v"(q3)
+                 : "v"(h0), "v"(h1), "v"(h2), "v"(h3), "v"(h4), "v"(h5), "v"(h6), "v"(h7));
+#undef GHR_PAIR
+    // the last two stages pair lanes inside a quad (no bank granularity): select + add
+    const bool b1 = (l & 2) != 0, b0 = (l & 1) != 0;
+    const float k0 = b1 ? q2 : q0, s0 = b1 ? q0 : q2, k1 = b1 ? q3 : q1, s1 = b1 ? q1 : q3;
+    const float e0 = k0 + dpp_get<2>(s0), e1 = k1 + dpp_get<2>(s1);  // partner l ^ 2
+    const float keep = b0 ? e1 : e0, send = b0 ? e0 : e1;            // partner l ^ 1
     return keep + dpp_get<3>(send);
 }
 #endif
@@ -164,8 +184,9 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
 #pragma unroll
     for (int c = 0; c < GHR_C; c++) {
-        st.dL[c] = inside ? dL_dpix[c * plane + pix] : 0.f;
-        st.bgdot = fma_(bg[c], st.dL[c], st.bgdot);
+        const float d = inside ? dL_dpix[c * plane + pix] : 0.f;
+        if (c & 1) st.dL[c / 2].y = d; else st.dL[c / 2].x = d;
+        st.bgdot = fma_(bg[c], d, st.bgdot);
     }
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // backward.cu:464-465
 

@@ -158,8 +158,9 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
             st.T_final = s->final_T[pix]; st.T = st.T_final; st.S = 0.f; st.last_alpha = 0.f; st.last_cdot = 0.f;
             st.bgdot = 0.f;
             for (int c = 0; c < GHR_C; c++) {
-                st.dL[c] = dL_dpix[c * N + pix];
-                st.bgdot = ghr::fma_(a->background[c], st.dL[c], st.bgdot);
+                const float d = dL_dpix[c * N + pix];
+                if (c & 1) st.dL[c / 2].y = d; else st.dL[c / 2].x = d;
+                st.bgdot = ghr::fma_(a->background[c], d, st.bgdot);
             }
             const uint32_t last = s->n_contrib[pix];
             // the kernel drops entries above the CELL's max n_contrib; emulate with the cell of this pixel
