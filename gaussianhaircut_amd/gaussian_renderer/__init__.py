@@ -46,31 +46,36 @@ def orient_angle_from(cov2d):
 
 
 class RenderPackage(dict):
-    """The reference's return dict.  ``orient_angle`` (10 small PyTorch kernels at full resolution) is computed on first
-    access: the fused stage-1 loss derives it inside its own kernel from ``renders_packed`` (the packed [10,H,W]
-    rasterizer output, kept as an attribute) and never reads it."""
+    """The reference's return dict.  ``orient_angle`` (10 small PyTorch kernels at full resolution) and
+    ``visibility_filter`` (``radii > 0``) are computed on first access: the fused stage-1 loss derives the angle inside
+    its own kernel from ``renders_packed`` (the packed [10,H,W] rasterizer output, kept as an attribute) and the
+    measured step reads neither."""
+
+    _LAZY = ("orient_angle", "visibility_filter")
 
     def __init__(self, renders, cov2d, **kw):
         super().__init__(**kw)
         self._cov2d = cov2d
         self.renders_packed = renders
 
-    def _materialise(self):
-        if not dict.__contains__(self, "orient_angle"):
+    def _materialise(self, k=None):
+        if k in (None, "orient_angle") and not dict.__contains__(self, "orient_angle"):
             dict.__setitem__(self, "orient_angle", orient_angle_from(self._cov2d))
+        if k in (None, "visibility_filter") and not dict.__contains__(self, "visibility_filter"):
+            dict.__setitem__(self, "visibility_filter", dict.__getitem__(self, "radii") > 0)
 
     def __getitem__(self, k):
-        if k == "orient_angle":
-            self._materialise()
+        if k in self._LAZY:
+            self._materialise(k)
         return dict.__getitem__(self, k)
 
     def get(self, k, default=None):
-        if k == "orient_angle":
-            self._materialise()
+        if k in self._LAZY:
+            self._materialise(k)
         return dict.get(self, k, default)
 
     def __contains__(self, k):
-        return k == "orient_angle" or dict.__contains__(self, k)
+        return k in self._LAZY or dict.__contains__(self, k)
 
     def keys(self):
         self._materialise()
@@ -92,7 +97,7 @@ class RenderPackage(dict):
 def _package(renders, screenspace_points, radii):
     image, mask, cov2d, orient_conf, _ = renders.split([3, 2, 3, 1, 1], dim=0)
     return RenderPackage(renders, cov2d, render=image, mask=mask, orient_conf=orient_conf,
-                         viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
+                         viewspace_points=screenspace_points, radii=radii)
 
 
 def _use_fused(pc, pipe) -> bool:

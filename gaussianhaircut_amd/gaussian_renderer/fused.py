@@ -118,7 +118,8 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
     P = xyz.shape[0]
     # "zero tensor used to make pytorch return gradients of the 2D (screen-space) means" of the original 3DGS;
     # here it also carries the NDC means as values, like the reference's get_mean_2d() output.
-    screenspace_points = torch.zeros((P, 3), dtype=torch.float32, device=xyz.device, requires_grad=True)
+    # k_project writes all P rows (culled Gaussians included), so no zero-fill is needed
+    screenspace_points = torch.empty((P, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
     cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
                proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),

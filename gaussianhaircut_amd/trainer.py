@@ -51,7 +51,9 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     total = None
     for cam in cams:
         pkg = render(cam, gaussians, pipe, background)
-        loss = view_loss(pkg, cam, opt) / V
+        loss = view_loss(pkg, cam, opt)
+        if V != 1:
+            loss = loss / V
         loss.backward()
         total = loss.detach() if total is None else total + loss.detach()
     from .optim import FusedAdam
