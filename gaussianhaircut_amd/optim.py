@@ -71,6 +71,71 @@ class FusedAdam:
     def has_nan(self):
         return torch.isnan(self.flat_grad).any()
 
+    # ---- optimizer-state surgery for densification (reference: gaussian_model.py:581-658 on torch.optim.Adam state)
+    def _rebuild(self, new_params: List[torch.Tensor], new_m: List[torch.Tensor], new_v: List[torch.Tensor]):
+        """Re-lay the flat buffers for a new set of per-group tensors (one parameter per group, the reference's layout).
+        Returns {group name: new nn.Parameter}.  The step counter is kept (Adam's ``step`` is per optimizer here, as it
+        effectively is in the reference where every group is stepped every iteration)."""
+        dev = self.flat_param.device
+        n = sum(t.numel() for t in new_params)
+        flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_m = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_v = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off, ends, out, params = 0, [], {}, []
+        for g, t, m, v in zip(self.param_groups, new_params, new_m, new_v):
+            k = t.numel()
+            flat_p[off:off + k].copy_(t.reshape(-1))
+            flat_m[off:off + k].copy_(m.reshape(-1))
+            flat_v[off:off + k].copy_(v.reshape(-1))
+            p = torch.nn.Parameter(flat_p[off:off + k].view(t.shape), requires_grad=True)
+            p.grad = self.flat_grad[off:off + k].view(t.shape)
+            g["params"] = [p]
+            out[g["name"]] = p
+            params.append(p)
+            off += k
+            ends.append(off)
+        self.flat_param, self.exp_avg, self.exp_avg_sq = flat_p, flat_m, flat_v
+        self._ends = (ctypes.c_int64 * len(ends))(*ends)
+        self.params = params
+        self._direct_backwards = 0
+        return out
+
+    def _group_views(self):
+        off = 0
+        for g in self.param_groups:
+            p = g["params"][0]
+            k = p.numel()
+            yield g, p, self.exp_avg[off:off + k].view(p.shape), self.exp_avg_sq[off:off + k].view(p.shape)
+            off += k
+
+    def prune(self, keep_mask: torch.Tensor):
+        """``_prune_optimizer`` (gaussian_model.py:596-612): keep the rows where ``keep_mask`` is True, moments included."""
+        ps, ms, vs = [], [], []
+        for _, p, m, v in self._group_views():
+            ps.append(p.data[keep_mask]); ms.append(m[keep_mask]); vs.append(v[keep_mask])
+        return self._rebuild(ps, ms, vs)
+
+    def extend(self, tensors_dict: Dict[str, torch.Tensor]):
+        """``cat_tensors_to_optimizer`` (gaussian_model.py:634-654): append rows with zero moments."""
+        ps, ms, vs = [], [], []
+        for g, p, m, v in self._group_views():
+            ext = tensors_dict[g["name"]].detach().to(p.dtype)
+            ps.append(torch.cat((p.data, ext), dim=0))
+            ms.append(torch.cat((m, torch.zeros_like(ext)), dim=0))
+            vs.append(torch.cat((v, torch.zeros_like(ext)), dim=0))
+        return self._rebuild(ps, ms, vs)
+
+    def replace(self, tensor: torch.Tensor, name: str):
+        """``replace_tensor_to_optimizer`` (gaussian_model.py:581-594): new values, zeroed moments, for one group."""
+        out = {}
+        for g, p, m, v in self._group_views():
+            if g["name"] == name:
+                p.data.copy_(tensor.detach().reshape(p.shape))
+                m.zero_(); v.zero_()
+                out[name] = p
+        return out
+
     # ---- direct-gradient sink used by gaussian_renderer.fused
     def nan_flag_ptr(self):
         return ctypes.c_void_p(self.state_dev.data_ptr() + 4)

@@ -10,9 +10,12 @@ contract so ``render()`` and a reference-shaped training loop work unchanged):
 * ``get_mean_2d`` / ``get_depths`` / ``get_direction_2d``  :317-393
 * ``training_setup`` / ``update_learning_rate``           :426-456
 
-Device-agnostic (the reference hard-codes ``device="cuda"``, :235,:384).  Out of scope here (SURVEY.md 8(f) "next"):
-``create_from_pcd`` (needs simple_knn), densify/prune, PLY I/O.  ``capture``/``restore`` are symmetric (the
-reference's restore() unpacks 14 of capture()'s 15 fields, :65-100).
+* densify / clone / split / prune / reset_opacity           :560-741   (``scene/densification.py``)
+* ``save_ply`` / ``load_ply``                                :458-579   (``scene/ply_io.py``)
+
+Device-agnostic (the reference hard-codes ``device="cuda"``, :235,:384).  Out of scope: ``create_from_pcd`` (needs
+simple_knn).  ``capture``/``restore`` are symmetric (the reference's restore() unpacks 14 of capture()'s 15 fields,
+:65-100).
 """
 from __future__ import annotations
 
@@ -21,11 +24,13 @@ import torch.nn.functional as F
 from torch import nn
 
 from ..utils.general_utils import build_rotation, get_expon_lr_func, inverse_sigmoid, strip_symmetric
+from .densification import DensificationMixin
+from .ply_io import PlyMixin
 
 BLOCK_X = BLOCK_Y = 16
 
 
-class GaussianModel:
+class GaussianModel(DensificationMixin, PlyMixin):
     conic_eps = 1e-12  # gaussian_model.py:312 (strand models use 1e-7, gaussian_model_strands.py:355)
 
     def setup_functions(self):
@@ -312,4 +317,13 @@ class OptimizationParams:
     lambda_dssim = 0.2
     lambda_dmask = 0.2
     lambda_dorient = 0.0
+    lambda_dsds = 0.0
+    densification_interval = 100
+    opacity_reset_interval = 3000
+    densify_from_iter = 500
+    densify_until_iter = 15_000
+    densify_grad_threshold = 0.0002
+    opacity_reg_from_iter = 30_000
+    gaussian_pruning_threshold = 0.5
     train_orient_conf = True
+    use_gt_orient_conf = True

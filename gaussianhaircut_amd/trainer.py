@@ -85,6 +85,30 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     return total
 
 
+@torch.no_grad()
+def densification_step(gaussians, render_pkg, opt, iteration: int, cameras_extent: float,
+                       white_background: bool = False, generator=None):
+    """The densification block of the stage-1 loop (src/train_gaussians.py:158-171), to be called between
+    ``loss.backward()`` and the optimizer step of an iteration: image-space radius tracking, gradient statistics,
+    densify_and_prune every ``densification_interval`` and the periodic opacity reset.  Under data parallelism every
+    rank must call it with identical statistics (``parallel.all_reduce_densification_stats``) and the same
+    ``generator`` seed so the replicas stay bit-identical."""
+    if iteration >= opt.densify_until_iter:
+        return False
+    vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+    gaussians.update_max_radii(radii, vis)
+    gaussians.add_densification_stats(render_pkg["viewspace_points"], vis)
+    changed = False
+    if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
+        size_threshold = 20 if iteration > opt.opacity_reset_interval else None
+        gaussians.densify_and_prune(opt.densify_grad_threshold, 0.005, cameras_extent, size_threshold,
+                                    generator=generator)
+        changed = True
+    if iteration % opt.opacity_reset_interval == 0 or (white_background and iteration == opt.densify_from_iter):
+        gaussians.reset_opacity()
+    return changed
+
+
 def _world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

@@ -9,7 +9,8 @@ filter_points`` (src/scene/gaussian_model.py:143-393), ``eval_sh`` (src/utils/sh
 ``strip_symmetric``, ``get_expon_lr_func``, ``parallel_transport`` (src/utils/general_utils.py),
 ``getProjectionMatrix`` / ``getWorld2View2`` (src/utils/graphics_utils.py), ``l1_loss`` / ``ssim`` / ``or_loss``
 (src/utils/loss_utils.py), and the strand model's ``initialize_gaussians_hair`` / ``get_conic`` (eps 1e-7) /
-``get_direction_2d`` / ``filter_points`` (src/scene/gaussian_model_strands.py:143-452).  The reference modules hard-code device="cuda" and import plyfile / simple_knn, which do
+``get_direction_2d`` / ``filter_points`` (src/scene/gaussian_model_strands.py:143-452), and ``densify_and_prune`` /
+``reset_opacity`` with their ``torch.optim.Adam`` state surgery (src/scene/gaussian_model.py:560-741).  The reference modules hard-code device="cuda" and import plyfile / simple_knn, which do
 not exist here: the script stubs those two modules and redirects "cuda" tensor factories to the CPU.  Nothing from
 the reference is copied into the repository -- only numeric outputs.
 """
@@ -135,6 +136,57 @@ def main():
     out["strands/mask"] = m.filter_points(cam).numpy()
     out["strands/opacity"], out["strands/label"] = m.get_opacity.numpy(), m.get_label.numpy()
     out["strands/orient_conf"] = m.get_orient_conf.numpy()
+
+    # ---- densification with optimizer-state surgery (src/scene/gaussian_model.py:560-741) on the reference's own
+    # GaussianModel + torch.optim.Adam: two Adam steps on seeded gradients to populate the moments, seeded
+    # densification statistics, then densify_and_prune (clone + split with torch.normal + prune) and reset_opacity.
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    spec = syn.CONFIGS["tiny"]
+    p = syn.random_gaussian_params(spec.P, spec.seed, spec.log_scale_mean)
+    m = ref_gm.GaussianModel(3)
+    par = lambda t: torch.nn.Parameter(t.detach().clone().float().contiguous().requires_grad_(True))
+    m._xyz, m._scaling, m._rotation = par(p["xyz"]), par(p["log_scales"]), par(p["rotations"])
+    m._opacity, m._label = par(p["opacity_logit"].reshape(-1, 1)), par(p["label_logit"].reshape(-1, 1))
+    m._orient_conf = par(p["orient_conf_log"].reshape(-1, 1))
+    m._features_dc, m._features_rest = par(p["features"][:, :1]), par(p["features"][:, 1:])
+    m.max_radii2D = torch.zeros(spec.P)
+    m.spatial_lr_scale = 1.0
+    opt = OptimizationParams()
+    m.training_setup(opt)
+    gd = torch.Generator().manual_seed(4242)
+    for it in range(2):
+        for grp in m.optimizer.param_groups:
+            prm = grp["params"][0]
+            prm.grad = torch.randn(prm.shape, generator=gd) * 1e-3
+        m.update_learning_rate(it + 1)
+        m.optimizer.step()
+    out["densify/pre_xyz"], out["densify/pre_label"] = m._xyz.detach().numpy().copy(), m._label.detach().numpy().copy()
+    m.xyz_gradient_accum = torch.rand(spec.P, 1, generator=gd) * 1.2e-3
+    m.denom = torch.randint(0, 4, (spec.P, 1), generator=gd).float()
+    m.max_radii2D = torch.rand(spec.P, generator=gd) * 30
+    out["densify/accum"], out["densify/denom"] = m.xyz_gradient_accum.numpy(), m.denom.numpy()
+    out["densify/max_radii"] = m.max_radii2D.numpy()
+    torch.manual_seed(991)
+    with torch.no_grad():
+        m.densify_and_prune(opt.densify_grad_threshold, 0.005, 2.5, 20)
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_label", "_scaling", "_rotation", "_orient_conf")
+    for nme in names:
+        out["densify/after" + nme] = getattr(m, nme).detach().numpy().copy()
+    for grp in m.optimizer.param_groups:
+        st = m.optimizer.state[grp["params"][0]]
+        out["densify/m_" + grp["name"]] = st["exp_avg"].numpy().copy()
+        out["densify/v_" + grp["name"]] = st["exp_avg_sq"].numpy().copy()
+    out["densify/n_after"] = np.int64(m.get_xyz.shape[0])
+    with torch.no_grad():
+        m.reset_opacity()
+    out["densify/opacity_reset"] = m._opacity.detach().numpy().copy()
+    out["densify/m_opacity_reset"] = m.optimizer.state[m._opacity]["exp_avg"].numpy().copy()
+    # one more Adam step on the resized state (the surgery must leave a steppable optimizer)
+    for grp in m.optimizer.param_groups:
+        prm = grp["params"][0]
+        prm.grad = torch.randn(prm.shape, generator=gd) * 1e-3
+    m.optimizer.step()
+    out["densify/xyz_after_step"] = m._xyz.detach().numpy()
 
     g = torch.Generator().manual_seed(123)
     q = torch.randn(64, 4, generator=g)

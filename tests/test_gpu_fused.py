@@ -147,3 +147,77 @@ def test_render_hair_gpu_matches_cpu_oracle_path():
         rows = np.abs(b).max(axis=1, keepdims=True)
         e = np.abs(a - b) / (rows + 1e-3 * scale)
         assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())
+
+
+def test_densification_with_fused_adam_matches_torch_adam_surgery():
+    """SURVEY N3 on the GPU: densify_and_prune + reset_opacity re-lay FusedAdam's flat buffers exactly like the
+    reference's per-parameter torch.optim.Adam surgery (same seeds), and the fused step keeps training afterwards."""
+    from gaussianhaircut_amd.optim import FusedAdam
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    from tests.test_reference_golden import _densify_sequence
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    opt = OptimizationParams()
+    res = []
+    for fused in (True, False):
+        m = syn.make_model(spec, dev)
+        m.training_setup(opt, fused=fused)
+        assert isinstance(m.optimizer, FusedAdam) == fused
+        _densify_sequence(m, opt, dev)
+        torch.manual_seed(991)
+        m.densify_and_prune(opt.densify_grad_threshold, 0.005, 2.5, 20)
+        m.reset_opacity()
+        state = {}
+        if fused:
+            for g, p, mm, vv in m.optimizer._group_views():
+                state[g["name"]] = (p.detach().clone(), mm.clone(), vv.clone())
+                assert p.grad is not None and p.grad.data_ptr() >= m.optimizer.flat_grad.data_ptr()
+        else:
+            for g in m.optimizer.param_groups:
+                st = m.optimizer.state[g["params"][0]]
+                state[g["name"]] = (g["params"][0].detach().clone(), st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+        res.append((m, state))
+    (mf, sf), (mt, stt) = res
+    assert mf.get_xyz.shape[0] == mt.get_xyz.shape[0] != spec.P
+    for k in stt:
+        for a, b, what in zip(sf[k], stt[k], ("param", "exp_avg", "exp_avg_sq")):
+            assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-9), (k, what, (a - b).abs().max())
+    # the resized model keeps training through the fused render / loss / Adam path
+    cam, bg = syn.make_view(spec, dev), syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, [cam], bg)
+    losses = [float(training_step(mf, [cam], bg, opt, i + 3)) for i in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    assert mf._xyz.data_ptr() == mf.optimizer.flat_param.data_ptr()
+
+
+def test_densification_step_loop_on_gpu():
+    """trainer.densification_step inside a short stage-1 loop (train_gaussians.py:158-171): statistics accumulate from
+    viewspace_points.grad, the model is resized at the interval, training goes on."""
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import PIPE, densification_step, make_ground_truth, view_loss
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    opt = OptimizationParams()
+    opt.densify_from_iter, opt.densification_interval, opt.lambda_dorient = 2, 4, 0.1
+    opt.densify_grad_threshold = 1e-7
+    m, cam, bg = syn.make_model(spec, dev), syn.make_view(spec, dev), syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, [cam], bg)
+    m.training_setup(opt)
+    sizes = []
+    for it in range(1, 10):
+        m.update_learning_rate(it)
+        pkg = render(cam, m, PIPE, bg)
+        view_loss(pkg, cam, opt).backward()
+        assert pkg["viewspace_points"].grad is not None
+        densification_step(m, pkg, opt, it, cameras_extent=2.5)
+        m.optimizer.step(zero_grad=True)
+        sizes.append(m.get_xyz.shape[0])
+    assert sizes[2] == spec.P and sizes[3] != spec.P and sizes[7] != sizes[3]
+    assert torch.isfinite(m.optimizer.flat_param).all()

@@ -108,3 +108,79 @@ def test_strand_model_matches_reference_strands_module():
         close(m.get_opacity.numpy(), G["strands/opacity"])
         close(m.get_label.numpy(), G["strands/label"])
         close(m.get_orient_conf.numpy(), G["strands/orient_conf"])
+
+
+def _densify_sequence(model, opt, dev="cpu"):
+    """The exact sequence tests/golden/make_reference_golden.py ran on the reference's GaussianModel."""
+    gd = torch.Generator().manual_seed(4242)
+    for it in range(2):
+        for grp in model.optimizer.param_groups:
+            prm = grp["params"][0]
+            g = (torch.randn(prm.shape, generator=gd) * 1e-3).to(dev)
+            if prm.grad is None:
+                prm.grad = g
+            else:
+                prm.grad.copy_(g)
+        model.update_learning_rate(it + 1)
+        model.optimizer.step()
+    model.xyz_gradient_accum = (torch.rand(model.get_xyz.shape[0], 1, generator=gd) * 1.2e-3).to(dev)
+    model.denom = torch.randint(0, 4, (model.get_xyz.shape[0], 1), generator=gd).float().to(dev)
+    model.max_radii2D = (torch.rand(model.get_xyz.shape[0], generator=gd) * 30).to(dev)
+    return gd
+
+
+def test_densify_prune_and_optimizer_surgery_match_reference():
+    """densify_and_prune (clone + split + prune) and reset_opacity with torch.optim.Adam state surgery vs the
+    reference's own implementation (gaussian_model.py:560-741), same seeds -> same tensors."""
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    spec = syn.CONFIGS["tiny"]
+    m = syn.make_model(spec)
+    opt = OptimizationParams()
+    m.training_setup(opt, fused=False)
+    gd = _densify_sequence(m, opt)
+    close(m.xyz_gradient_accum.numpy(), G["densify/accum"])
+    torch.manual_seed(991)
+    m.densify_and_prune(opt.densify_grad_threshold, 0.005, 2.5, 20)
+    assert m.get_xyz.shape[0] == int(G["densify/n_after"]) != spec.P
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_label", "_scaling", "_rotation", "_orient_conf"):
+        close(getattr(m, n).detach().numpy(), G["densify/after" + n], rtol=1e-6, atol=1e-7)
+    for grp in m.optimizer.param_groups:
+        st = m.optimizer.state[grp["params"][0]]
+        close(st["exp_avg"].numpy(), G["densify/m_" + grp["name"]], rtol=1e-6, atol=1e-12)
+        close(st["exp_avg_sq"].numpy(), G["densify/v_" + grp["name"]], rtol=1e-6, atol=1e-15)
+    assert m.xyz_gradient_accum.shape == (m.get_xyz.shape[0], 1) and m.max_radii2D.shape == (m.get_xyz.shape[0],)
+    with torch.no_grad():
+        m.reset_opacity()
+    close(m._opacity.detach().numpy(), G["densify/opacity_reset"], rtol=1e-6, atol=1e-7)
+    close(m.optimizer.state[m._opacity]["exp_avg"].numpy(), G["densify/m_opacity_reset"])
+    for grp in m.optimizer.param_groups:
+        prm = grp["params"][0]
+        prm.grad = torch.randn(prm.shape, generator=gd) * 1e-3
+    m.optimizer.step()
+    close(m._xyz.detach().numpy(), G["densify/xyz_after_step"], rtol=1e-6, atol=1e-7)
+
+
+def test_ply_round_trip_and_reference_layout(tmp_path):
+    """save_ply / load_ply (gaussian_model.py:458-579): attribute order, the two files, float32 payload, round trip."""
+    from gaussianhaircut_amd.scene.ply_io import read_ply_vertices
+    spec = syn.CONFIGS["tiny"]
+    m = syn.make_model(spec)
+    path = str(tmp_path / "point_cloud" / "iteration_7" / "point_cloud.ply")
+    m.save_ply(path)
+    raw = os.path.join(os.path.dirname(path), "raw_point_cloud.ply")
+    names_raw, v_raw = read_ply_vertices(raw)
+    names_vis, v_vis = read_ply_vertices(path)
+    exp = (["x", "y", "z", "nx", "ny", "nz"] + ["f_dc_%d" % i for i in range(3)] + ["f_rest_%d" % i for i in range(45)] +
+           ["opacity", "orient_conf", "label_0"] + ["scale_%d" % i for i in range(3)] + ["rot_%d" % i for i in range(4)])
+    assert names_raw == exp and names_vis == [n for n in exp if n != "label_0"]
+    assert v_raw.shape == (spec.P,) and all(v_raw.dtype[n] == np.dtype("<f4") for n in names_raw)
+    header = open(raw, "rb").read(64)
+    assert header.startswith(b"ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % spec.P)
+    # f_dc / f_rest are stored channel-major: transpose(1, 2).flatten(1) (gaussian_model.py:486-487)
+    fr = m._features_rest.detach().transpose(1, 2).flatten(start_dim=1).numpy()
+    assert np.array_equal(v_raw["f_rest_17"], fr[:, 17]) and np.array_equal(v_raw["nx"], np.zeros(spec.P, np.float32))
+    m2 = GaussianModel(3)
+    m2.load_ply(raw)
+    for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_label", "_orient_conf", "_scaling", "_rotation"):
+        assert torch.equal(getattr(m, n).detach(), getattr(m2, n).detach()), n
+    assert m2.active_sh_degree == 3 and m2._xyz.requires_grad
