@@ -6,10 +6,13 @@
            bench.py --gpus N --steps K --warmup W
 
 A *step* is one global gradient step of the reference's stage-1 loop shape (src/train_gaussians.py:96-181, no
-densification): per rank ``views_per_gpu`` views of the 500k strand-aligned model at 1920x1080 -- render() (fused HIP
+densification) over the whole view batch: per rank ``views_per_gpu`` views (default 4 = the per-GPU shard
+of BASELINE.json configs[3], "32 views sharded 4-per-GPU on 8 GPUs"; the same 4 views per GPU at every N, so the series
+is weak scaling) of the 500k strand-aligned model at 1920x1080 -- render() (fused HIP
 projection + rasterizer forward), the four stage-1 losses incl. the orientation term (lambda_dorient = 0.1 as in
 run.sh:112-115), backward (HIP loss / rasterizer / projection backward), one flat all-reduce of the
-Gaussian gradients when N > 1 (RCCL), Adam.  Weak scaling: per-GPU work is fixed as N grows.
+Gaussian gradients when N > 1 (RCCL), Adam.  Weak scaling: per-GPU work is fixed as N grows.  At N = 1 the line also
+carries ``single_view_step``: the same loop with ONE view per step (BASELINE.json configs[2]).
 
 One JSON line on rank 0:  value = Gaussians rasterized per second over the whole job = N * views_per_gpu * P / t_step
 (inputs resident in HBM; P = Gaussians of the model, every one of them goes through projection, cull and -- if
@@ -44,7 +47,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "tiny"])
-    ap.add_argument("--views-per-gpu", type=int, default=1)
+    ap.add_argument("--views-per-gpu", type=int, default=4,
+                    help="views per GPU per global step; 4 = the per-GPU shard of BASELINE.json configs[3] (32 views on 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-only", action="store_true")
     args = ap.parse_args()
@@ -178,6 +182,19 @@ def main():
     }
 
     if rank == 0 and world == 1:
+        # BASELINE.json configs[2]: the same stage-1 step with ONE view per gradient step
+        K1 = max(10, K)
+        for i in range(3):
+            training_step(model, cams[:1], bg, opt, Wm + K + i + 1, global_views=1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K1):
+            training_step(model, cams[:1], bg, opt, Wm + K + 3 + i + 1, global_views=1)
+        torch.cuda.synchronize()
+        dt1 = (time.perf_counter() - t1) / K1
+        out["single_view_step"] = {"workload": "BASELINE configs[2]: 1 view per gradient step", "steps": K1,
+                                   "ms_per_step": round(1e3 * dt1, 4), "gaussians_per_sec": round(P_model / dt1, 1),
+                                   "grad_steps_per_sec": round(1.0 / dt1, 2)}
         if not args.no_op_only:
             out["op_only"] = op_only_bench(dev)
         if not args.no_cpu_baseline:

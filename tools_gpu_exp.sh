@@ -3,7 +3,7 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for so in $R/gaussianhaircut_amd/csrc/variants/*.so; do
-  GHR_LIB_PATH=$so timeout 120 python tools_kbench.py ${CFG:-cfg3} 20 2>&1 | grep -E "KBENCH|Error|error"
+  GHR_LIB_PATH=$so timeout 90 python tools_kbench.py ${CFG:-cfg3} 20 2>&1 | grep -E "KBENCH|Error|error"
 done | tee gpurun_out/kbench.log
 if [ -n "$KT" ]; then
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/tools_kbench.py ${CFG:-cfg3} 10 ) > gpurun_out/kt.log 2>&1
