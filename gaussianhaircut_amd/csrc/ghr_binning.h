@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
 __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect4* __restrict__ rects,
                                                        const float* __restrict__ depths,
                                                        const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
-                                                       uint64_t* keys)
+                                                       uint64_t* keys, uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     // A wavefront serves 16 Gaussians: lane = 16*q + i handles the rect ordinals q, q+4, q+8, ... of Gaussian i
@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect
         const bool on = k < area;
         const int t = (y0 + ky) * gx + x0 + kx;
         const uint32_t pos = wave_inc(tile_cursor, (uint32_t)t, on);
-        if (on) keys[tile_start[t] + pos] = key;
+        if (on && tile_start[t] + pos < cap) keys[tile_start[t] + pos] = key;  // cap: see ghr_forward_stage2
         kx += 4;
         while (on && kx >= w) { kx -= w; ky++; }
     }
@@ -124,12 +124,12 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
 }
 
 __global__ void __launch_bounds__(GHR_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
-                                                         uint64_t* keys, uint32_t* point_list)
+                                                         uint64_t* keys, uint32_t* point_list, uint32_t cap)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
     const uint32_t tile = xcd_tile(blockIdx.x, T);
-    const uint32_t s = tile_start[tile];
-    const uint32_t n = tile_start[tile + 1] - s;
+    const uint32_t s = min(tile_start[tile], cap);
+    const uint32_t n = min(tile_start[tile + 1], cap) - s;
     if (n == 0) return;
     const int tid = threadIdx.x;
     uint64_t* g = keys + s;

@@ -204,13 +204,13 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // append cursors start at 0 (k_tile_scan left them there; re-zeroed so that stage 2 may be replayed)
         GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
-                           g.rects, g.depths, im.tile_start, im.tile_count, b.keys);
+                           g.rects, g.depths, im.tile_start, im.tile_count, b.keys, R);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
-                           b.point_list);
+                           b.point_list, R);
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T, im.tile_start,
-                       b.point_list, g.rec, a->background, out_color, im.final_T, im.n_contrib);
+                       b.point_list, g.rec, a->background, out_color, im.final_T, im.n_contrib, R);
     if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }

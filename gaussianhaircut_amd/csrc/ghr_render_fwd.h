@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           const uint32_t* __restrict__ point_list,
                                                           const f4* __restrict__ rec, const float* __restrict__ bg,
                                                           float* __restrict__ out_color, float* __restrict__ final_T,
-                                                          uint32_t* __restrict__ n_contrib)
+                                                          uint32_t* __restrict__ n_contrib, uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
     const float wx0 = (float)(tx * GHR_TILE_X);
     const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave);
 
-    const uint32_t beg = tile_start[tile], end = tile_start[tile + 1];
+    const uint32_t beg = min(tile_start[tile], cap), end = min(tile_start[tile + 1], cap);  // cap: ghr_forward_stage2
     const uint32_t n = end - beg;
 
     PixFwd st;

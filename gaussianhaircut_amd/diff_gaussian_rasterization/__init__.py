@@ -92,6 +92,33 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_R_HINT = {}  # device index -> binning capacity guess (1.25 x the previous frame's instance count)
+
+
+def run_stage2(dev, P, pinned, launch):
+    """Reads stage 1's instance count and runs stage 2 (``launch(capacity) -> binning buffer``).  After the first
+    frame stage 2 is launched SPECULATIVELY with a capacity guessed from the previous frame before the 4-byte count is
+    read back, so the GPU already works on scatter / sort / compositing while the host waits; it is relaunched only if
+    the true count exceeds the guess (include/ghr.h, ghr_forward_stage2).  Returns (num_rendered, capacity, buffer)."""
+    stream = torch.cuda.current_stream()
+    hint = _R_HINT.get(dev.index) if P > 0 else None
+    if hint:
+        ev = torch.cuda.Event()
+        ev.record(stream)      # completes when stage 1's count has landed in pinned memory ...
+        binb = launch(hint)    # ... while stage 2 is already queued behind it
+        ev.synchronize()
+        R, cap = int(pinned[0].item()), hint
+        if R > hint:
+            binb, cap = launch(R), R
+    else:
+        stream.synchronize()  # the reference blocks on the same 4 bytes (rasterizer_impl.cu:284-285)
+        R = int(pinned[0].item()) if P > 0 else 0
+        binb, cap = launch(R), R
+    if P > 0:
+        _R_HINT[dev.index] = R + R // 4 + 4096
+    return R, cap, binb
+
+
 def rasterize_gaussians(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         conics_precomp, raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations,
@@ -148,15 +175,16 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 rs.prefiltered, rs.debug))
             try:
                 pinned = _pinned(dev)
-                stream = torch.cuda.current_stream()
                 _lib.check(L.ghr_forward_stage1(_stream(), ctypes.byref(args), _ptr(geomBuffer), _ptr(imgBuffer),
                                                 _ptr(radii), ctypes.c_void_p(pinned.data_ptr())))
-                stream.synchronize()  # the reference blocks on the same 4 bytes (rasterizer_impl.cu:284-285)
-                num_rendered = int(pinned[0].item()) if P > 0 else 0
-                bbytes = _lib.binning_size(num_rendered)
-                binningBuffer = torch.empty((bbytes,), dtype=torch.uint8, device=dev)
-                _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), num_rendered, _ptr(geomBuffer),
-                                                _ptr(imgBuffer), _ptr(binningBuffer), _ptr(color)))
+
+                def launch(cap):
+                    b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                    _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), cap, _ptr(geomBuffer),
+                                                    _ptr(imgBuffer), _ptr(b), _ptr(color)))
+                    return b
+
+                num_rendered, bin_cap, binningBuffer = run_stage2(dev, P, pinned, launch)
             except Exception as ex:
                 if cpu_args is not None:
                     torch.save(cpu_args, "snapshot_fw.dump")
@@ -166,6 +194,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         LAST_STATS["num_rendered"], LAST_STATS["P"] = num_rendered, P
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.bin_cap = bin_cap  # layout of binningBuffer
         ctx.mark_non_differentiable(radii)
         # same tuple as the reference (__init__.py:102); tensors are the contiguous fp32 versions the kernels read
         ctx.save_for_backward(colors_c if colors_c is not None else torch.empty(0), means3D_c,
@@ -212,7 +241,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 imgBuffer, rs.debug))
             try:
                 if P > 0:
-                    _lib.check(L.ghr_backward(_stream(), ctypes.byref(args), num_rendered, _ptr(radii),
+                    _lib.check(L.ghr_backward(_stream(), ctypes.byref(args), ctx.bin_cap, _ptr(radii),
                                               _ptr(geomBuffer), _ptr(imgBuffer), _ptr(binningBuffer), _ptr(dL),
                                               _ptr(scratch), _ptr(grad_means2D), _ptr(grad_conic),
                                               _ptr(grad_opacities), _ptr(grad_colors_precomp), _ptr(grad_means3D),

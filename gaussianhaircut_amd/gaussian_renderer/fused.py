@@ -12,7 +12,7 @@ import ctypes
 import torch
 
 from .. import _lib
-from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream
+from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
 
 
 def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug):
@@ -51,17 +51,20 @@ class _RenderModelFused(torch.autograd.Function):
             pinned = _pinned(dev)
             _lib.check(L.ghr_model_forward_stage1(_stream(), ctypes.byref(m), _ptr(geom), _ptr(img), _ptr(radii),
                                                   _ptr(screenspace_points.detach()), ctypes.c_void_p(pinned.data_ptr())))
-            torch.cuda.current_stream().synchronize()  # num_rendered sizes the binning workspace (cf. rasterizer_impl.cu:284)
-            R = int(pinned[0].item()) if P > 0 else 0
-            binb = torch.empty((_lib.binning_size(R),), dtype=torch.uint8, device=dev)
             va = _lib.ViewArgs()
             va.P, va.W, va.H, va.C = P, W, H, NUM_CHANNELS
             va.background = _ptr(bg)
             va.debug = int(bool(cfg["debug"]))
-            _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), R, _ptr(geom), _ptr(img), _ptr(binb),
-                                            _ptr(color)))
+
+            def launch(cap):
+                b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
+                                                _ptr(color)))
+                return b
+
+            R, cap, binb = run_stage2(dev, P, pinned, launch)  # speculative: see diff_gaussian_rasterization.run_stage2
         LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
-        ctx.cfg, ctx.R, ctx.K = cfg, R, K
+        ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
         # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
         # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
@@ -100,7 +103,7 @@ class _RenderModelFused(torch.autograd.Function):
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
             if P > 0:
-                _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), R, _ptr(radii), _ptr(geom), _ptr(img),
+                _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
                                                 _ptr(d_fdc), _ptr(d_frest), int(direct),

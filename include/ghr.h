@@ -86,13 +86,19 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
                        uint32_t* R_host);
 
 /* Stage 2 = instance scatter + per-tile depth sort (== the reference's global (tile|depth) stable radix sort,
- * rasterizer_impl.cu:293-321) + front-to-back compositing (K7).  out_color is [C,H,W]. */
+ * rasterizer_impl.cu:293-321) + front-to-back compositing (K7).  out_color is [C,H,W].
+ * R is the CAPACITY (in instances) of bin_ws (ghr_binning_size(R)) and fixes its layout: it must be >= the instance
+ * count stage 1 reported for the result to be valid, and the same value must be passed to the backward call.  A caller
+ * may therefore launch stage 2 speculatively with a capacity guessed from the previous frame BEFORE reading *R_host
+ * (no GPU bubble behind the host round trip) and relaunch it only if the true count turned out larger: instances
+ * beyond the capacity are dropped without touching memory outside bin_ws.  Stage 2 may be replayed. */
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
                        float* out_color);
 
-/* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  grad_scratch: GHR_GRAD_STRIDE*R floats (one 64-B gradient line per
- * Gaussian-tile instance, R as returned by stage 1; may be NULL when R == 0), uninitialised on entry: every line is
- * written by K8 with plain stores and summed per Gaussian in a fixed order -- no global float atomics.
+/* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  R: the capacity stage 2 was run with (layout of bin_ws).
+ * grad_scratch: GHR_GRAD_STRIDE floats (one 64-B gradient line) per Gaussian-tile instance actually reported by stage 1
+ * (may be NULL when that count is 0), uninitialised on entry: every line is zero-filled and accumulated by K8 and the
+ * lines of a Gaussian are summed in a fixed order -- no cross-tile float atomics.
  * Outputs (all fully written, no pre-zeroing needed), shapes of rasterize_points.cu:160-168:
  *   dL_dmeans2D [P,3] (z = 0), dL_dconic [P,2,2] ([0][0], [0][1] = HALF of d/db as in backward.cu:554, [1][1]),
  *   dL_dopacity [P], dL_dcolors [P,C], dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dscales [P,3], dL_drotations [P,4]. */

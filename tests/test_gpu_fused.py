@@ -221,3 +221,31 @@ def test_densification_step_loop_on_gpu():
         sizes.append(m.get_xyz.shape[0])
     assert sizes[2] == spec.P and sizes[3] != spec.P and sizes[7] != sizes[3]
     assert torch.isfinite(m.optimizer.flat_param).all()
+
+
+@pytest.mark.parametrize("pipe", [FUSED, GENERIC])
+def test_speculative_stage2_capacity_guess_never_changes_the_result(pipe):
+    """run_stage2: stage 2 is launched with a capacity guessed from the previous frame before num_rendered is read;
+    too small a guess drops instances inside the workspace bounds and triggers a relaunch.  Image, radii and gradients
+    must be identical for no guess / a far too small guess / a generous guess."""
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    cam, bg = syn.make_view(spec, dev), syn.background(dev)
+    w = torch.randn(6, spec.H, spec.W, generator=torch.Generator().manual_seed(2)).to(dev)
+    outs = []
+    for hint in (None, 64, 10_000_000):
+        dgr._R_HINT.pop(dev.index, None)
+        if hint:
+            dgr._R_HINT[dev.index] = hint
+        model = syn.make_model(spec, dev)
+        pkg = render(cam, model, pipe, bg)
+        full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
+        (full * w).sum().backward()
+        R = dgr.LAST_STATS["num_rendered"]
+        assert 64 < R < 10_000_000 and dgr._R_HINT[dev.index] == R + R // 4 + 4096
+        outs.append((full.detach().clone(), pkg["radii"].clone(), model._xyz.grad.clone(), model._features_dc.grad.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        for a, b in zip(o[2:], outs[0][2:]):   # float atomics inside a tile: order-dependent rounding only
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()))
