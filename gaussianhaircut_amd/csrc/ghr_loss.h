@@ -12,7 +12,7 @@
 //     loss  = w_l1 * Ll1 + w_ssim * Lssim + w_mask * Lmask + w_orient * Lorient      (run.sh:112-115: w_orient = 0.1)
 // PyTorch runs this as 10 MIOpen depthwise convolutions + ~40 elementwise kernels per step (measured 10.2 ms at
 // 1080p on MI355X = 69 % of the step once projection was fused).  Here: one forward kernel (separable 11-tap window
-// staged through LDS, 16x16 pixel tiles with a 5-pixel halo) that also emits the three per-pixel partial derivatives
+// staged through LDS, 32x16 pixel tiles with a 5-pixel halo) that also emits the three per-pixel partial derivatives
 // of the SSIM map, and one backward kernel that convolves those maps back (same window, adjoint of a symmetric
 // zero-padded convolution) and adds the L1 terms.  HBM-bound: ~25 B/pixel/channel forward, ~30 B backward.
 #pragma once
@@ -100,41 +100,58 @@ GHR_HD OrientPix orient_pixel(float d0, float d1, float conf, float gt_angle, fl
     return o;
 }
 
+// Tile geometry of both kernels: a 256-thread block produces a 32 x 16 pixel tile of one colour channel from a
+// (32 + 10) x (16 + 10) input window.  Horizontal pass: one thread = 4 adjacent outputs of one row from 16 inputs read
+// as four ds_read_b128 (rows are 16-B aligned); vertical pass: one thread = 2 vertically adjacent outputs of one
+// column (12 rows x maps of conflict-free ds_read_b32).  One barrier per phase and ONE for all partial sums.
+#define GHR_L_TW 32
+#define GHR_L_TH 16
+#define GHR_L_EW (GHR_L_TW + 2 * GHR_SSIM_R)  // 42
+#define GHR_L_EH (GHR_L_TH + 2 * GHR_SSIM_R)  // 26
+#define GHR_L_XS 44  // row stride (floats) of the input window: 16-B aligned rows, columns 42, 43 are zero padding
+#define GHR_L_HS 36  // row stride of the horizontally filtered maps: 16-B aligned, (4 r + c) mod 32 banks
+
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ float block_sum_256(float v, float* s_red)
+// Sums NV per-thread values over the 256 threads of the block with one barrier; valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum_n(float* v, float (*s_red)[8])
 {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    const int tid = threadIdx.y * GHR_SSIM_T + threadIdx.x;
-    if ((tid & 63) == 0) s_red[tid >> 6] = v;
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) s_red[tid >> 6][k] = v[k];
     __syncthreads();
-    const float r = s_red[0] + s_red[1] + s_red[2] + s_red[3];
-    __syncthreads();
-    return r;
+    if (tid == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = s_red[0][k] + s_red[1][k] + s_red[2][k] + s_red[3][k];
 }
 #endif
 
-// grid (ceil(W/16), ceil(H/16), 3 colour channels), block (16,16)
+// grid (ceil(W/32), ceil(H/16), 3 colour channels), block 256
 __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ float s_x[GHR_SSIM_E][GHR_SSIM_E + 1], s_y[GHR_SSIM_E][GHR_SSIM_E + 1];
-    __shared__ float s_h[5][GHR_SSIM_E][GHR_SSIM_T + 1];
-    __shared__ float s_red[4];
+    __shared__ __attribute__((aligned(16))) float s_x[GHR_L_EH][GHR_L_XS], s_y[GHR_L_EH][GHR_L_XS];
+    __shared__ __attribute__((aligned(16))) float s_h[5][GHR_L_EH][GHR_L_HS];
+    __shared__ float s_red[4][8];
     const int ch = blockIdx.z;
     const int W = a.W, H = a.H;
     const size_t N = (size_t)W * H;
-    const int bx = blockIdx.x * GHR_SSIM_T, by = blockIdx.y * GHR_SSIM_T;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * GHR_SSIM_T + tx;
+    const int bx = blockIdx.x * GHR_L_TW, by = blockIdx.y * GHR_L_TH;
+    const int tid = threadIdx.x;
     const float* img = a.image + ch * N;
     const float* gt = a.gt_image + ch * N;
     const float* m = a.gt_mask + N;  // gt_mask[1]
 
-    for (int i = tid; i < GHR_SSIM_E * GHR_SSIM_E; i += 256) {
-        const int ly = i / GHR_SSIM_E, lx = i - ly * GHR_SSIM_E;
+    for (int i = tid; i < GHR_L_EH * GHR_L_XS; i += 256) {
+        const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
         const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
         float x = 0.f, y = 0.f;
-        if (gx >= 0 && gx < W && gy >= 0 && gy < H) {
+        if (lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H) {
             const size_t p = (size_t)gy * W + gx;
             const float mm = m[p];
             x = img[p] * mm;
@@ -144,63 +161,91 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
         s_y[ly][lx] = y;
     }
     __syncthreads();
-    // horizontal 11-tap pass over 26 rows x 16 columns for the 5 moments
-    for (int i = tid; i < GHR_SSIM_E * GHR_SSIM_T; i += 256) {
-        const int ly = i / GHR_SSIM_T, lx = i - ly * GHR_SSIM_T;
-        float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+    // horizontal 11-tap pass: 26 rows x 8 groups of 4 columns, the 5 moments
+    if (tid < GHR_L_EH * (GHR_L_TW / 4)) {
+        const int ly = tid >> 3, c0 = (tid & 7) * 4;
+        float xs[16], ys[16];
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = c_ssim_w[k], x = s_x[ly][lx + k], y = s_y[ly][lx + k];
-            h0 = fma_(w, x, h0); h1 = fma_(w, y, h1); h2 = fma_(w, x * x, h2); h3 = fma_(w, y * y, h3);
-            h4 = fma_(w, x * y, h4);
+        for (int q = 0; q < 4; q++) {
+            const f4 vx = *reinterpret_cast<const f4*>(&s_x[ly][c0 + 4 * q]);
+            const f4 vy = *reinterpret_cast<const f4*>(&s_y[ly][c0 + 4 * q]);
+            xs[4 * q] = vx.x; xs[4 * q + 1] = vx.y; xs[4 * q + 2] = vx.z; xs[4 * q + 3] = vx.w;
+            ys[4 * q] = vy.x; ys[4 * q + 1] = vy.y; ys[4 * q + 2] = vy.z; ys[4 * q + 3] = vy.w;
         }
-        s_h[0][ly][lx] = h0; s_h[1][ly][lx] = h1; s_h[2][ly][lx] = h2; s_h[3][ly][lx] = h3; s_h[4][ly][lx] = h4;
+        float xx[14], yy[14], xy[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) { xx[k] = xs[k] * xs[k]; yy[k] = ys[k] * ys[k]; xy[k] = xs[k] * ys[k]; }
+        float h[5][4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float h0 = 0, h1 = 0, h2 = 0, h3 = 0, h4 = 0;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = c_ssim_w[k];
+                h0 = fma_(w, xs[o + k], h0); h1 = fma_(w, ys[o + k], h1); h2 = fma_(w, xx[o + k], h2);
+                h3 = fma_(w, yy[o + k], h3); h4 = fma_(w, xy[o + k], h4);
+            }
+            h[0][o] = h0; h[1][o] = h1; h[2][o] = h2; h[3][o] = h3; h[4][o] = h4;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) *reinterpret_cast<f4*>(&s_h[k][ly][c0]) = f4{h[k][0], h[k][1], h[k][2], h[k][3]};
     }
     __syncthreads();
-    float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+    // vertical pass: column tx, rows 2*tr and 2*tr + 1
+    const int tx = tid & 31, tr = tid >> 5;
+    float acc[2][5];
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = c_ssim_w[k];
-        mu1 = fma_(w, s_h[0][ty + k][tx], mu1); mu2 = fma_(w, s_h[1][ty + k][tx], mu2);
-        e11 = fma_(w, s_h[2][ty + k][tx], e11); e22 = fma_(w, s_h[3][ty + k][tx], e22);
-        e12 = fma_(w, s_h[4][ty + k][tx], e12);
-    }
-    const int gx = bx + tx, gy = by + ty;
-    const bool inside = gx < W && gy < H;
-    float ssim_v = 0.f, l1_v = 0.f, ml1_v = 0.f;
-    if (inside) {
-        const size_t p = (size_t)gy * W + gx;
-        float d0, d1, d2;
-        ssim_v = ssim_point(mu1, mu2, e11, e22, e12, d0, d1, d2);
-        a.maps[(0 * 3 + ch) * N + p] = d0;
-        a.maps[(1 * 3 + ch) * N + p] = d1;
-        a.maps[(2 * 3 + ch) * N + p] = d2;
-        l1_v = fabsf(img[p] - gt[p]) * m[p];
-        if (ch < 2) ml1_v = fabsf(a.mask[ch * N + p] - a.gt_mask[ch * N + p]);
-    }
-    const float s0 = block_sum_256(l1_v, s_red);
-    const float s1 = block_sum_256(ssim_v, s_red);
-    const float s2 = block_sum_256(ml1_v, s_red);
-    const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
-    if (tid == 0) {
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 0], s0);
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 1], s1);
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 2], s2);
-    }
-    if (ch == 2 && a.dir2d != nullptr) {  // the blocks of the third colour channel also carry the orientation term
-        float num = 0.f, den = 0.f;
-        if (inside) {
-            const size_t p = (size_t)gy * W + gx;
-            const float w = a.gt_oconf[p];
-            const OrientPix o = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
-            num = o.l * w;
-            den = w;
+    for (int o = 0; o < 2; o++)
+#pragma unroll
+        for (int k = 0; k < 5; k++) acc[o][k] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 12; r++) {
+        float v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] = s_h[k][2 * tr + r][tx];
+        if (r < 11) {
+            const float w = c_ssim_w[r];
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[0][k] = fma_(w, v[k], acc[0][k]);
         }
-        const float s3 = block_sum_256(num, s_red);
-        const float s4 = block_sum_256(den, s_red);
-        if (tid == 0) {
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 3], s3);
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 4], s4);
+        if (r >= 1) {
+            const float w = c_ssim_w[r - 1];
+#pragma unroll
+            for (int k = 0; k < 5; k++) acc[1][k] = fma_(w, v[k], acc[1][k]);
+        }
+    }
+    const bool orient = ch == 2 && a.dir2d != nullptr;
+    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // |image-gt|*m, ssim, |mask-gt_mask|, orientation num, den
+    const int gx = bx + tx;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const int gy = by + 2 * tr + o;
+        if (gx < W && gy < H) {
+            const size_t p = (size_t)gy * W + gx;
+            float d0, d1, d2;
+            sums[1] += ssim_point(acc[o][0], acc[o][1], acc[o][2], acc[o][3], acc[o][4], d0, d1, d2);
+            a.maps[(0 * 3 + ch) * N + p] = d0;
+            a.maps[(1 * 3 + ch) * N + p] = d1;
+            a.maps[(2 * 3 + ch) * N + p] = d2;
+            sums[0] += fabsf(img[p] - gt[p]) * m[p];
+            if (ch < 2) sums[2] += fabsf(a.mask[ch * N + p] - a.gt_mask[ch * N + p]);
+            if (orient) {  // the blocks of the third colour channel also carry the orientation term
+                const float w = a.gt_oconf[p];
+                const OrientPix op = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
+                sums[3] += op.l * w;
+                sums[4] += w;
+            }
+        }
+    }
+    block_sum_n<5>(sums, s_red);
+    if (tid == 0) {
+        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
+        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 0], sums[0]);
+        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 1], sums[1]);
+        if (ch < 2) atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 2], sums[2]);
+        if (orient) {
+            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 3], sums[3]);
+            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 4], sums[4]);
         }
     }
 #endif
@@ -231,49 +276,67 @@ struct LossBwdArgs {
 __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ float s_m[3][GHR_SSIM_E][GHR_SSIM_E + 1];
-    __shared__ float s_h[3][GHR_SSIM_E][GHR_SSIM_T + 1];
+    __shared__ __attribute__((aligned(16))) float s_m[3][GHR_L_EH][GHR_L_XS];
+    __shared__ __attribute__((aligned(16))) float s_h[3][GHR_L_EH][GHR_L_HS];
     const int ch = blockIdx.z;
     const int W = a.W, H = a.H;
     const size_t N = (size_t)W * H;
-    const int bx = blockIdx.x * GHR_SSIM_T, by = blockIdx.y * GHR_SSIM_T;
-    const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * GHR_SSIM_T + tx;
-    for (int i = tid; i < GHR_SSIM_E * GHR_SSIM_E; i += 256) {
-        const int ly = i / GHR_SSIM_E, lx = i - ly * GHR_SSIM_E;
+    const int bx = blockIdx.x * GHR_L_TW, by = blockIdx.y * GHR_L_TH;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < GHR_L_EH * GHR_L_XS; i += 256) {
+        const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
         const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
-        const bool in = gx >= 0 && gx < W && gy >= 0 && gy < H;
+        const bool in = lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
         const size_t p = in ? (size_t)gy * W + gx : 0;
 #pragma unroll
         for (int k = 0; k < 3; k++) s_m[k][ly][lx] = in ? a.maps[(k * 3 + ch) * N + p] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < GHR_SSIM_E * GHR_SSIM_T; i += 256) {
-        const int ly = i / GHR_SSIM_T, lx = i - ly * GHR_SSIM_T;
-        float h0 = 0, h1 = 0, h2 = 0;
+    if (tid < GHR_L_EH * (GHR_L_TW / 4)) {  // horizontal pass, 4 outputs per thread
+        const int ly = tid >> 3, c0 = (tid & 7) * 4;
 #pragma unroll
-        for (int k = 0; k < 11; k++) {
-            const float w = c_ssim_w[k];
-            h0 = fma_(w, s_m[0][ly][lx + k], h0); h1 = fma_(w, s_m[1][ly][lx + k], h1);
-            h2 = fma_(w, s_m[2][ly][lx + k], h2);
+        for (int k = 0; k < 3; k++) {
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const f4 t = *reinterpret_cast<const f4*>(&s_m[k][ly][c0 + 4 * q]);
+                v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            }
+            float h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+#pragma unroll
+                for (int t = 0; t < 11; t++) h[o] = fma_(c_ssim_w[t], v[o + t], h[o]);
+            *reinterpret_cast<f4*>(&s_h[k][ly][c0]) = f4{h[0], h[1], h[2], h[3]};
         }
-        s_h[0][ly][lx] = h0; s_h[1][ly][lx] = h1; s_h[2][ly][lx] = h2;
     }
     __syncthreads();
-    float c0 = 0, c1 = 0, c2 = 0;
+    const int tx = tid & 31, tr = tid >> 5;
+    float c[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int k = 0; k < 11; k++) {
-        const float w = c_ssim_w[k];
-        c0 = fma_(w, s_h[0][ty + k][tx], c0); c1 = fma_(w, s_h[1][ty + k][tx], c1); c2 = fma_(w, s_h[2][ty + k][tx], c2);
+    for (int r = 0; r < 12; r++) {
+        const float v0 = s_h[0][2 * tr + r][tx], v1 = s_h[1][2 * tr + r][tx], v2 = s_h[2][2 * tr + r][tx];
+        if (r < 11) {
+            const float w = c_ssim_w[r];
+            c[0][0] = fma_(w, v0, c[0][0]); c[0][1] = fma_(w, v1, c[0][1]); c[0][2] = fma_(w, v2, c[0][2]);
+        }
+        if (r >= 1) {
+            const float w = c_ssim_w[r - 1];
+            c[1][0] = fma_(w, v0, c[1][0]); c[1][1] = fma_(w, v1, c[1][1]); c[1][2] = fma_(w, v2, c[1][2]);
+        }
     }
-    const int gx = bx + tx, gy = by + ty;
-    if (gx < W && gy < H) {
+    const int gx = bx + tx;
+    const float up = a.grad_loss ? a.grad_loss[0] : 1.0f;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+        const int gy = by + 2 * tr + o;
+        if (!(gx < W && gy < H)) continue;
         const size_t p = (size_t)gy * W + gx;
-        const float up = a.grad_loss ? a.grad_loss[0] : 1.0f;
         const float mm = a.gt_mask[N + p];
         const float im = a.image[ch * N + p], g = a.gt_image[ch * N + p];
         const float x = im * mm, y = g * mm;
         // d(mean ssim)/dx(p), then Lssim = 1 - mean  and x = image * m
-        const float dssim_dx = (c0 + 2.f * x * c1 + y * c2) / (3.0f * (float)N);
+        const float dssim_dx = (c[o][0] + 2.f * x * c[o][1] + y * c[o][2]) / (3.0f * (float)N);
         const float diff = im - g;
         const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
         a.d_image[ch * N + p] = up * (a.w_l1 * sgn * mm / (3.0f * (float)N) - a.w_ssim * dssim_dx * mm);
@@ -286,9 +349,9 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
         } else if (a.d_dir2d != nullptr) {
             float g0 = 0.f, g1 = 0.f, gc = 0.f;
             if (a.dir2d != nullptr && a.w_orient != 0.f && a.aux[1] == 0.f) {
-                const OrientPix o = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
-                const float s = up * a.w_orient * a.gt_oconf[p] / a.aux[0];
-                g0 = s * o.dl_dd0; g1 = s * o.dl_dd1; gc = s * o.dl_dconf;
+                const OrientPix op = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
+                const float sc = up * a.w_orient * a.gt_oconf[p] / a.aux[0];
+                g0 = sc * op.dl_dd0; g1 = sc * op.dl_dd1; gc = sc * op.dl_dconf;
             }
             a.d_dir2d[p] = g0;
             a.d_dir2d[N + p] = g1;
