@@ -17,7 +17,10 @@
 namespace ghr {
 
 #define GHR_SCAN_BLOCK 1024
-#define GHR_SORT_CAP 4096  // keys sorted in LDS (32 KiB); longer lists use the in-place global path
+#define GHR_SORT_CAP 2048  // keys sorted in LDS (16 KiB); longer lists use the in-place global path
+#define GHR_SORT_BLOCK 256  // the sort is latency-bound (about one compare-exchange per thread and step at typical
+                            // list lengths): 16 KiB of LDS instead of 32 keeps 8 tiles in flight per CU (measured 72 -> 49 us;
+                            // 128-thread workgroups: 56 us)
 
 // Exclusive scan of tile_count[T] into tile_start[T+1]; resets tile_count to 0 so k_scatter can reuse it as the
 // per-tile append cursor; publishes R = tile_start[T].
@@ -88,12 +91,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect
 
 // Bitonic network in its "flip" form: every compare-exchange moves the smaller key to the lower index, so virtual
 // +inf padding beyond n never moves and exchanges whose upper index is >= n are simply skipped (any n, no padding).
+// Steps whose partner distance is < 64 only touch one aligned 64-key block per 32 pair indices, and thread t always
+// handles the pair indices t, t + nthreads, ... (nthreads a multiple of 64) -- so with WAVE_LOCAL a wavefront owns its blocks for all those steps and
+// they are separated by a wave-level fence instead of a workgroup barrier (45 of the 55 steps of a 1024-key sort).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GHR_SYNC() __syncthreads()
+#define GHR_SYNC_WAVE()                                           \
+    do {                                                          \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    \
+        __builtin_amdgcn_wave_barrier();                          \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
+    } while (0)
 #else
 #define GHR_SYNC() ((void)0)  // tests/hostsim runs the network with one "thread": steps are already ordered
+#define GHR_SYNC_WAVE() ((void)0)
 #endif
-template <typename KeyPtr>
+template <bool WAVE_LOCAL, typename KeyPtr>
 GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
 {
     uint32_t np2 = 1;
@@ -101,6 +114,8 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
     const uint32_t half = np2 >> 1;
     for (uint32_t size = 2; size <= np2; size <<= 1) {
         const uint32_t hs = size >> 1;
+        const bool flip_local = WAVE_LOCAL && size <= 64;
+        if (!flip_local) GHR_SYNC();  // keys written by other waves in the previous (local) steps
         for (uint32_t i = tid; i < half; i += nthreads) {  // flip: l <-> block_end - offset
             const uint32_t blk = i / hs, off = i - blk * hs;
             const uint32_t l = blk * size + off, u = blk * size + (size - 1 - off);
@@ -109,7 +124,7 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
                 if (b < a) { k[l] = b; k[u] = a; }
             }
         }
-        GHR_SYNC();
+        if (flip_local) GHR_SYNC_WAVE(); else GHR_SYNC();
         for (uint32_t j = hs >> 1; j >= 1; j >>= 1) {  // disperse: l <-> l + j
             for (uint32_t i = tid; i < half; i += nthreads) {
                 const uint32_t l = 2 * j * (i / j) + (i % j), u = l + j;
@@ -118,12 +133,13 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
                     if (b < a) { k[l] = b; k[u] = a; }
                 }
             }
-            GHR_SYNC();
+            if (WAVE_LOCAL && j <= 32) GHR_SYNC_WAVE(); else GHR_SYNC();  // j <= 32: this and the next step stay in-block
         }
     }
+    GHR_SYNC();
 }
 
-__global__ void __launch_bounds__(GHR_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
@@ -134,10 +150,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_tile_sort(uint32_t T, const uint3
     const int tid = threadIdx.x;
     uint64_t* g = keys + s;
     if (n <= GHR_SORT_CAP) {
-        for (uint32_t i = tid; i < n; i += GHR_BLOCK) s_keys[i] = g[i];
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) s_keys[i] = g[i];
         __syncthreads();
-        if (n > 1) bitonic_any_n(s_keys, n, tid, GHR_BLOCK);
-        for (uint32_t i = tid; i < n; i += GHR_BLOCK) {
+        if (n > 1) bitonic_any_n<true>(s_keys, n, tid, GHR_SORT_BLOCK); else __syncthreads();
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) {
             const uint64_t k = s_keys[i];
             g[i] = k;
             point_list[s + i] = (uint32_t)k;
@@ -146,8 +162,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_tile_sort(uint32_t T, const uint3
         // Rare: a single tile with more instances than fit in LDS.  Same network, in place in global memory
         // (one workgroup => same CU/L1, __syncthreads orders the accesses).
         __syncthreads();
-        bitonic_any_n(g, n, tid, GHR_BLOCK);
-        for (uint32_t i = tid; i < n; i += GHR_BLOCK) point_list[s + i] = (uint32_t)g[i];
+        bitonic_any_n<false>(g, n, tid, GHR_SORT_BLOCK);
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) point_list[s + i] = (uint32_t)g[i];
     }
 }
 

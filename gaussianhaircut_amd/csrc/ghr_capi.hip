@@ -205,7 +205,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.depths, im.tile_start, im.tile_count, b.keys, R);
-        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
+        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
                            b.point_list, R);
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));

@@ -92,7 +92,7 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
     // k_tile_sort
     for (int t = 0; t < T; t++) {
         const uint32_t b = s->tile_start[t], n = s->tile_start[t + 1] - b;
-        if (n > 1) ghr::bitonic_any_n(s->keys.data() + b, n, 0, 1);
+        if (n > 1) ghr::bitonic_any_n<false>(s->keys.data() + b, n, 0, 1);
         for (uint32_t i = 0; i < n; i++) s->point_list[b + i] = (uint32_t)s->keys[b + i];
     }
     // k_render_fwd
@@ -285,7 +285,7 @@ int ghrsim_xcd_bijective(uint32_t n)
 // sorts `n` keys with the product's network; returns 1 if the result is ascending
 int ghrsim_bitonic(uint64_t* keys, uint32_t n)
 {
-    if (n > 1) ghr::bitonic_any_n(keys, n, 0, 1);
+    if (n > 1) ghr::bitonic_any_n<false>(keys, n, 0, 1);
     for (uint32_t i = 1; i < n; i++)
         if (keys[i - 1] > keys[i]) return 0;
     return 1;
