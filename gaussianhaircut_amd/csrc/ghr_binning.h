@@ -22,17 +22,17 @@ namespace ghr {
                             // list lengths): 16 KiB of LDS instead of 32 keeps 8 tiles in flight per CU (measured 72 -> 49 us;
                             // 128-thread workgroups: 56 us)
 
-// Exclusive scan of tile_count[T] into tile_start[T+1]; resets tile_count to 0 so k_scatter can reuse it as the
-// per-tile append cursor; publishes R = tile_start[T].
-__global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
-                                                              uint32_t* R_out)
+#if defined(__HIP_DEVICE_COMPILE__)
+// Exclusive scan of src[n] into dst[n] (may alias) by one 1024-thread workgroup; returns the total in every thread.
+// `zero_src`: reset src[i] to 0 after reading it.
+__device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* dst, bool zero_src, uint32_t* s_part)
 {
-    __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
     const int tid = threadIdx.x;
-    const int per = (T + GHR_SCAN_BLOCK - 1) / GHR_SCAN_BLOCK;
-    const int b = tid * per, e = min(T, b + per);
+    const int per = (n + GHR_SCAN_BLOCK - 1) / GHR_SCAN_BLOCK;
+    const int b = tid * per, e = min(n, b + per);
     uint32_t sum = 0;
-    for (int i = b; i < e; i++) sum += tile_count[i];
+    for (int i = b; i < e; i++) sum += src[i];
+    __syncthreads();  // s_part may still be read by a previous call
     s_part[tid] = sum;
     __syncthreads();
     // Hillis-Steele inclusive scan over the 1024 partials
@@ -44,19 +44,34 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
     }
     uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
     for (int i = b; i < e; i++) {
-        const uint32_t c = tile_count[i];
-        tile_start[i] = run;
-        tile_count[i] = 0u;
+        const uint32_t c = src[i];
+        if (zero_src) src[i] = 0u;
+        dst[i] = run;
         run += c;
     }
-    if (tid == GHR_SCAN_BLOCK - 1) {
-        const uint32_t total = s_part[GHR_SCAN_BLOCK - 1];
+    return s_part[GHR_SCAN_BLOCK - 1];
+}
+#endif
+
+// tile_count[T] -> tile_start[T+1] (exclusive scan; tile_count is reset to 0 so k_scatter can reuse it as the per-tile
+// append cursor; publishes R = tile_start[T]) and, in place, slot_blk[nblk] -> exclusive prefix of the gradient slots
+// used by the K1 workgroups.
+__global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
+                                                              uint32_t* R_out, uint32_t* slot_blk, int nblk)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
+    const uint32_t total = scan_1024(T, tile_count, tile_start, true, s_part);
+    if (threadIdx.x == 0) {
         tile_start[T] = total;
         *R_out = total;
     }
+    scan_1024(nblk, slot_blk, slot_blk, false, s_part);
+#endif
 }
 
-__global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect4* __restrict__ rects,
+__global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rects,
+                                                       const uint32_t* __restrict__ slot_blk,
                                                        const float* __restrict__ depths,
                                                        const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
                                                        uint64_t* keys, uint32_t cap)
@@ -69,7 +84,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, const rect
     const int lane = threadIdx.x & 63, q = lane >> 4;
     const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 16) + (lane & 15);
     rect4 r = rect4{0u, 0u, 0u, 0u};
-    if (idx < P) r = rects[idx];
+    if (idx < P) {
+        r = rects[idx];
+        if (q == 0) rects[idx].w = slot_blk[idx >> 8];  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
+    }
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
     const int w = x1 - x0, area = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
     const uint64_t key = area ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;

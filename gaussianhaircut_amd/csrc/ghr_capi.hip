@@ -44,12 +44,13 @@ struct Geom {
     ghr::f4* rec;
     float* depths;
     ghr::rect4* rects;
+    uint32_t* slot_blk;  // [ceil(P/256)]
     float* cov3D;
 };
 struct Img {
     float* final_T;
     uint32_t* n_contrib;
-    uint32_t* tile_count;  // [T+1]: per-tile instance count, then append cursor; [T] = gradient-slot allocator
+    uint32_t* tile_count;  // [T]: per-tile instance count, then append cursor
     uint32_t* tile_start;  // [T+1]
     uint32_t* R_dev;
 };
@@ -65,8 +66,9 @@ size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
     ghr::f4* rec = (ghr::f4*)take(P * 64);
     float* depths = (float*)take(P * 4);
     ghr::rect4* rects = (ghr::rect4*)take(P * 16);
+    uint32_t* slot_blk = (uint32_t*)take(((P + GHR_BLOCK - 1) / GHR_BLOCK) * 4);
     float* cov3D = mode_b ? (float*)take(P * 24) : nullptr;
-    if (g) *g = Geom{rec, depths, rects, cov3D};
+    if (g) *g = Geom{rec, depths, rects, slot_blk, cov3D};
     return off + ALIGN;
 }
 size_t carve_img(char* base, size_t N, size_t T, Img* im)
@@ -75,7 +77,7 @@ size_t carve_img(char* base, size_t N, size_t T, Img* im)
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
     float* final_T = (float*)take(N * 4);
     uint32_t* n_contrib = (uint32_t*)take(N * 4);
-    uint32_t* tile_count = (uint32_t*)take((T + 1) * 4);
+    uint32_t* tile_count = (uint32_t*)take(T * 4);
     uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
     uint32_t* R_dev = (uint32_t*)take(4);
     if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev};
@@ -161,7 +163,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
 
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * ((size_t)T + 1), s));
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
     ghr::PreArgs pa;
     pa.P = a->P; pa.W = a->W; pa.H = a->H; pa.gx = gx; pa.gy = gy;
     pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;
@@ -172,9 +174,10 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     pa.focal_y = a->H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:224-225
     pa.focal_x = a->W / (2.0f * a->tan_fovx);
     pa.rec = g.rec; pa.depths = g.depths; pa.rects = g.rects; pa.cov3D = g.cov3D; pa.radii = radii;
-    pa.tile_count = im.tile_count;
+    pa.tile_count = im.tile_count; pa.slot_blk = g.slot_blk;
     hipLaunchKernelGGL(ghr::k_preprocess, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, pa);
-    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev);
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
+                       g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK);
     GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, a->debug);
 }
@@ -204,7 +207,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // append cursors start at 0 (k_tile_scan left them there; re-zeroed so that stage 2 may be replayed)
         GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
-                           g.rects, g.depths, im.tile_start, im.tile_count, b.keys, R);
+                           g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, b.keys, R);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
                            b.point_list, R);
     }
@@ -281,7 +284,7 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     a->focal_x = m->W / (2.0f * m->tan_fovx);
     a->conic_eps = m->conic_eps;
     a->rec = nullptr; a->depths = nullptr; a->rects = nullptr; a->radii = nullptr; a->means2D = nullptr;
-    a->tile_count = nullptr;
+    a->tile_count = nullptr; a->slot_blk = nullptr;
     return GHR_OK;
 }
 }  // namespace
@@ -299,11 +302,12 @@ int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_w
     Geom g; Img im;
     carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * ((size_t)T + 1), s));
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
     a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
-    a.tile_count = im.tile_count;
+    a.tile_count = im.tile_count; a.slot_blk = g.slot_blk;
     hipLaunchKernelGGL(ghr::k_project, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev);
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
+                       g.slot_blk, (a.P + GHR_BLOCK - 1) / GHR_BLOCK);
     GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, m->debug);
 }

@@ -71,10 +71,11 @@ GHR_HD m3 transpose(const m3& a)
     return o;
 }
 
-// Per-Gaussian tile rect + gradient-slot base, one 16-B record: {x0 | x1<<16, y0 | y1<<16, inst_base, 0}.
-// The Gaussian's (y - y0) * (x1 - x0) + (x - x0)-th tile instance owns gradient slot inst_base + that ordinal
-// (k_render_bwd writes it with plain stores, the per-Gaussian backward sums the slots in ordinal order: no float
-// atomics, bit-reproducible gradients).
+// Per-Gaussian tile rect + gradient-slot base, one 16-B record: {x0 | x1<<16, y0 | y1<<16, base_lo, base_hi}.
+// The Gaussian's (y - y0) * (x1 - x0) + (x - x0)-th tile instance owns gradient slot base_lo + base_hi + that ordinal,
+// where base_lo is the exclusive prefix of the rect areas inside the Gaussian's 256-thread K1 workgroup and base_hi the
+// exclusive prefix over the workgroups before it (k_tile_scan; copied in by k_scatter).  No atomics: a single
+// allocation counter would serialise every wavefront of K1 on one address (measured: ~90 us at 500k Gaussians).
 typedef uint4 rect4;
 GHR_HD rect4 make_rect4(int x0, int y0, int x1, int y1, uint32_t base)
 {
@@ -88,14 +89,14 @@ GHR_HD uint32_t rect4_area(const rect4& r)
 GHR_HD uint32_t rect4_slot(const rect4& r, int tx, int ty)
 {
     const uint32_t x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu;
-    return r.z + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
+    return r.z + r.w + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
 }
 
 // Sum of a Gaussian's per-instance gradient lines in tile-ordinal order (deterministic).
 GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga)
 {
     const uint32_t cnt = rect4_area(r);
-    const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)r.z;
+    const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * ((size_t)r.z + r.w);
     f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     for (uint32_t k = 0; k < cnt; k++, p += 4) {
         s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 += p[3];
@@ -105,22 +106,23 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga)
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// Wave-aggregated allocation of n (per lane, may be 0) consecutive units from *counter: one atomic per wavefront.
-// Every lane of the wave must call it.
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t n, uint32_t* counter)
+// Exclusive prefix sum of n over the 256 threads of the workgroup (thread order); *total = sum.  Every thread of the
+// workgroup must call it.  s_tmp: 4 LDS words.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t n, uint32_t* s_tmp, uint32_t* total)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = n;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
         if (lane >= off) incl += v;
     }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    uint32_t base = 0;
-    if (lane == 63 && total) base = atomicAdd(counter, total);
-    base = (uint32_t)__shfl((int)base, 63);
-    return base + incl - n;
+    if (lane == 63) s_tmp[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = s_tmp[0], w1 = s_tmp[1], w2 = s_tmp[2], w3 = s_tmp[3];
+    const uint32_t before = wave == 0 ? 0u : (wave == 1 ? w0 : (wave == 2 ? w0 + w1 : w0 + w1 + w2));
+    *total = w0 + w1 + w2 + w3;
+    return before + incl - n;
 }
 
 // Run-aggregated atomicAdd(&counter[t], 1) for every lane with `active`: a run of ADJACENT lanes that target the same

@@ -26,7 +26,8 @@ struct PreArgs {
     rect4* rects;
     float* cov3D;  // mode B only
     int* radii;
-    uint32_t* tile_count;  // [T] per-tile instance counts, [T] (one past) = gradient-slot allocation counter
+    uint32_t* tile_count;  // [T] per-tile instance counts
+    uint32_t* slot_blk;    // [ceil(P/256)] gradient slots used by each K1 workgroup (scanned by k_tile_scan)
 };
 
 // forward.cu:118-152.  The quaternion is used as given (normalisation is commented out at :127).
@@ -181,9 +182,12 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
 #if defined(__HIP_DEVICE_COMPILE__)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    __shared__ uint32_t s_scan[4];
     const bool ok = idx < a.P && preprocess_one(a, idx, x0, y0, x1, y1);
-    const uint32_t base = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
+    uint32_t blk_total;
+    const uint32_t base = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
     if (ok) a.rects[idx].z = base;
+    if (threadIdx.x == 0) a.slot_blk[blockIdx.x] = blk_total;
     // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
     // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
     count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);

@@ -45,7 +45,8 @@ struct ModelArgs {
     rect4* rects;
     int* radii;
     float* means2D;  // [P,3] NDC (viewspace_points values), may be null
-    uint32_t* tile_count;  // [T] counts, [T] (one past) = gradient-slot allocation counter
+    uint32_t* tile_count;  // [T] counts
+    uint32_t* slot_blk;    // [ceil(P/256)] gradient slots per workgroup
 };
 
 struct ModelGrads {
@@ -516,8 +517,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     const int idx = base + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     const bool ok = idx < a.P && project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1);
-    const uint32_t slot0 = wave_alloc(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, a.tile_count + a.gx * a.gy);
+    __shared__ uint32_t s_scan[4];
+    uint32_t blk_total;
+    const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
     if (ok) a.rects[idx].z = slot0;
+    if (threadIdx.x == 0) a.slot_blk[blockIdx.x] = blk_total;
     count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
 #endif
 }

@@ -207,7 +207,7 @@ int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, voi
 typedef struct ghr_ws_view {
     const float* rec;          /* [P][16]: x, y, conic a, b, c, opacity, features[10] */
     const float* depths;       /* [P] */
-    const uint32_t* rects;     /* [P][4]: (xmin | xmax<<16), (ymin | ymax<<16), first gradient slot, 0 */
+    const uint32_t* rects;     /* [P][4]: (xmin | xmax<<16), (ymin | ymax<<16), first gradient slot = [2] + [3] */
     const float* cov3D;        /* [P][6] (mode B) or NULL */
     const float* final_T;      /* [H*W] */
     const uint32_t* n_contrib; /* [H*W] */

@@ -99,8 +99,9 @@ def test_cfg3_full_size_properties_and_oracle(oracle_mod, dev):
     assert area.sum() == run.R
     # gradient slots: the [base, base + area) ranges of the visible Gaussians partition [0, R)
     vis = area > 0
-    order = np.argsort(rects[vis, 2].astype(np.int64), kind="stable")
-    b, a_ = rects[vis, 2].astype(np.int64)[order], area[vis][order]
+    base = rects[:, 2].astype(np.int64) + rects[:, 3].astype(np.int64)
+    order = np.argsort(base[vis], kind="stable")
+    b, a_ = base[vis][order], area[vis][order]
     assert b[0] == 0 and (b[1:] == b[:-1] + a_[:-1]).all() and b[-1] + a_[-1] == run.R
     # every tile list is sorted by (depth bits, idx) and refers to Gaussians whose rect contains the tile
     keys = ins["keys"]
