@@ -156,7 +156,7 @@ def main():
     achieved = bytes_bwd_kernel / (bwd_avg * 1e-3) / 1e9 if bwd_avg > 0 else 0.0
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_k_render_bwd.json")
-    if os.path.exists(pmc_file):
+    if os.path.exists(pmc_file) and args.workload == "cfg3":  # the committed PMC passes were taken on this workload
         try:
             traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
         except Exception:
