@@ -158,14 +158,18 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
 }
 
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
-                                                         uint64_t* keys, uint32_t* point_list, uint32_t cap)
+                                                         uint64_t* keys, uint32_t* point_list, uint32_t cap,
+                                                         uint32_t* tile_cursor)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
     const uint32_t tile = xcd_tile(blockIdx.x, T);
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;
-    if (n == 0) return;
     const int tid = threadIdx.x;
+    // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may
+    // be replayed, e.g. after a too small speculative capacity)
+    if (tid == 0) tile_cursor[tile] = 0u;
+    if (n == 0) return;
     uint64_t* g = keys + s;
     if (n <= GHR_SORT_CAP) {
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) s_keys[i] = g[i];

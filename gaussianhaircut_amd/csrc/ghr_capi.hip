@@ -204,12 +204,11 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
     if (R > 0) {
-        // append cursors start at 0 (k_tile_scan left them there; re-zeroed so that stage 2 may be replayed)
-        GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+        // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, b.keys, R);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
-                           b.point_list, R);
+                           b.point_list, R, im.tile_count);
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T, im.tile_start,

@@ -14,7 +14,7 @@ from .utils.loss_utils import l1_loss, or_loss, ssim
 PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
-def view_loss(render_pkg, cam, opt, fused=None):
+def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
     """train_gaussians.py:113-140.  On a ROCm device all four terms run as one fused HIP op."""
     image, mask = render_pkg["render"], render_pkg["mask"]
     gt_image, gt_mask = cam.original_image, cam.original_mask
@@ -24,12 +24,14 @@ def view_loss(render_pkg, cam, opt, fused=None):
         # one HIP op on the rasterizer's packed [10,H,W] output, orientation term included (orient_weight =
         # ones_like(gt_mask[:1]) * gt_orient_conf, train_gaussians.py:130)
         from .fused_loss import stage1_loss
+        # `scale` (1/V of a V-view batch) is folded into the weights: no separate elementwise kernels around the loss
         return stage1_loss(render_pkg.renders_packed, gt_image, gt_mask, cam.original_orient_angle,
-                           cam.original_orient_conf, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask,
-                           opt.lambda_dorient)
+                           cam.original_orient_conf, opt.lambda_dl1 * scale, opt.lambda_dssim * scale,
+                           opt.lambda_dmask * scale, opt.lambda_dorient * scale)
     if fused and opt.lambda_dorient == 0.0:
         from .fused_loss import photometric_loss
-        return photometric_loss(image, mask, gt_image, gt_mask, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask)
+        return photometric_loss(image, mask, gt_image, gt_mask, opt.lambda_dl1 * scale, opt.lambda_dssim * scale,
+                                opt.lambda_dmask * scale)
     Ll1 = l1_loss(image, gt_image, mask=gt_mask[1:].detach())
     Lssim = 1.0 - ssim(image * gt_mask[1:], gt_image * gt_mask[1:])
     Lmask = l1_loss(mask, gt_mask)
@@ -40,7 +42,7 @@ def view_loss(render_pkg, cam, opt, fused=None):
                           mask=gt_mask[:1])
         Lorient = torch.where(torch.isnan(Lorient), torch.zeros_like(Lorient), Lorient)
         loss = loss + Lorient * opt.lambda_dorient
-    return loss
+    return loss * scale if scale != 1.0 else loss
 
 
 def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
@@ -48,14 +50,13 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     """One global gradient step over this rank's views.  Returns the (detached) summed local loss."""
     gaussians.update_learning_rate(iteration)
     V = global_views or len(cams)
-    total = None
+    losses = []
     for cam in cams:
         pkg = render(cam, gaussians, pipe, background)
-        loss = view_loss(pkg, cam, opt)
-        if V != 1:
-            loss = loss / V
+        loss = view_loss(pkg, cam, opt, scale=1.0 / V)
         loss.backward()
-        total = loss.detach() if total is None else total + loss.detach()
+        losses.append(loss.detach())
+    total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
     from .optim import FusedAdam
     if isinstance(gaussians.optimizer, FusedAdam):
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
