@@ -147,18 +147,30 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
     const float* gt = a.gt_image + ch * N;
     const float* m = a.gt_mask + N;  // gt_mask[1]
 
-    for (int i = tid; i < GHR_L_EH * GHR_L_XS; i += 256) {
-        const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
-        const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
-        float x = 0.f, y = 0.f;
-        if (lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H) {
-            const size_t p = (size_t)gy * W + gx;
-            const float mm = m[p];
-            x = img[p] * mm;
-            y = gt[p] * mm;
+    {   // window load: all (up to 15) global loads of a thread are issued before the first LDS store -- the phase is
+        // latency-bound, one dependent round trip per loop iteration cost ~2/3 of the kernel
+        constexpr int NIT = (GHR_L_EH * GHR_L_XS + 255) / 256;  // 5
+        float vi[NIT], vg[NIT], vm[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + 256 * it;
+            const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
+            const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
+            const bool in = i < GHR_L_EH * GHR_L_XS && lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const size_t p = in ? (size_t)gy * W + gx : 0;
+            vm[it] = in ? m[p] : 0.f;
+            vi[it] = in ? img[p] : 0.f;
+            vg[it] = in ? gt[p] : 0.f;
         }
-        s_x[ly][lx] = x;
-        s_y[ly][lx] = y;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + 256 * it;
+            if (i < GHR_L_EH * GHR_L_XS) {
+                const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
+                s_x[ly][lx] = vi[it] * vm[it];
+                s_y[ly][lx] = vg[it] * vm[it];
+            }
+        }
     }
     __syncthreads();
     // horizontal 11-tap pass: 26 rows x 8 groups of 4 columns, the 5 moments
@@ -283,13 +295,28 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
     const size_t N = (size_t)W * H;
     const int bx = blockIdx.x * GHR_L_TW, by = blockIdx.y * GHR_L_TH;
     const int tid = threadIdx.x;
-    for (int i = tid; i < GHR_L_EH * GHR_L_XS; i += 256) {
-        const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
-        const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
-        const bool in = lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
-        const size_t p = in ? (size_t)gy * W + gx : 0;
+    {   // window load, all global loads first (see k_loss_fwd)
+        constexpr int NIT = (GHR_L_EH * GHR_L_XS + 255) / 256;
+        float v[NIT][3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) s_m[k][ly][lx] = in ? a.maps[(k * 3 + ch) * N + p] : 0.f;
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + 256 * it;
+            const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
+            const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
+            const bool in = i < GHR_L_EH * GHR_L_XS && lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
+            const size_t p = in ? (size_t)gy * W + gx : 0;
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[it][k] = in ? a.maps[(k * 3 + ch) * N + p] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int i = tid + 256 * it;
+            if (i < GHR_L_EH * GHR_L_XS) {
+                const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
+#pragma unroll
+                for (int k = 0; k < 3; k++) s_m[k][ly][lx] = v[it][k];
+            }
+        }
     }
     __syncthreads();
     if (tid < GHR_L_EH * (GHR_L_TW / 4)) {  // horizontal pass, 4 outputs per thread
