@@ -63,7 +63,8 @@ GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, c
     cd = __builtin_elementwise_fma(f2{r2.z, r2.w}, s.dL[2], cd);
     cd = __builtin_elementwise_fma(f2{r3.x, r3.y}, s.dL[3], cd);
     cd = __builtin_elementwise_fma(f2{r3.z, r3.w}, s.dL[4], cd);
-    const float cdot = cd.x + cd.y;
+    // a pair that does not contribute must not leak a non-finite feature of its Gaussian into S or g[] (0 * inf)
+    const float cdot = c ? cd.x + cd.y : 0.0f;
     // backward.cu:519-523 collapsed to scalars (see header)
     s.S = fma_(s.last_alpha, s.last_cdot, (1.f - s.last_alpha) * s.S);
     s.last_cdot = cdot;

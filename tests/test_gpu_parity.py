@@ -279,3 +279,32 @@ def test_render_api_end_to_end_grads(oracle_mod, dev):
     img = pkg["render"].detach().cpu().numpy()
     # GPU-side torch projection vs CPU-side torch projection differ by rounding: loose tolerance, same picture
     assert np.abs(img[:, ok] - out_o[:3][:, ok]).mean() < 1e-3
+
+
+def test_non_finite_feature_of_a_non_contributing_gaussian_does_not_leak(oracle_mod, dev):
+    """The branch-free backward step evaluates pairs that do not contribute with alpha = 0; a non-finite feature of
+    such a Gaussian (here: one whose opacity is below 1/255, so it never contributes anywhere) must not poison the
+    gradients of the others (the reference skips the pair, backward.cu:494-505)."""
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS["tiny"]
+    ri = syn.raster_inputs(spec)
+    bad = torch.arange(0, ri["P"], 7)
+    ri["opacities"] = ri["opacities"].clone()
+    ri["opacities"][bad] = 1e-4
+    clean = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in ri.items()}
+    ri["colors"] = ri["colors"].clone()
+    ri["colors"][bad, 2] = float("inf")
+    ri["colors"][bad, 5] = float("nan")
+    dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
+    outs = []
+    for inp in (clean, ri):
+        run = GpuRun(to_dev(inp, dev), "A", debug=False)
+        g = run.backward(dL)
+        outs.append((run.out.cpu().numpy(), g))
+    assert np.isfinite(outs[1][0]).all() and np.array_equal(outs[0][0], outs[1][0])
+    keep = np.ones(ri["P"], bool)
+    keep[bad.numpy()] = False
+    for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors"):
+        a, b = outs[1][1][k][keep], outs[0][1][k][keep]
+        assert np.isfinite(a).all(), k
+        assert np.allclose(a, b, rtol=1e-4, atol=1e-6 * np.abs(b).max()), k
