@@ -24,18 +24,21 @@ struct PixFwd {
 };
 
 // One list entry applied to one pixel (forward.cu:351-388).  `pos1` is the 1-based position of the entry in the
-// tile's list (the reference's `contributor`).  Returns true when the pixel is finished (T would drop below 1e-4).
-GHR_HD bool fwd_step(PixFwd& s, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2, const f4& r3,
-                     uint32_t pos1)
+// tile's list (the reference's `contributor`); `live` = the pixel is not finished yet.  Returns true when the pixel
+// finishes on this entry (T would drop below 1e-4).  The three skip tests of the reference are evaluated as predicates
+// and ONE branch guards the blend (a chain of four nested wave-level branches per visit costs more than the few
+// arithmetic instructions it can skip); the blended values are bit-identical.
+GHR_HD bool fwd_step(PixFwd& s, bool live, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2,
+                     const f4& r3, uint32_t pos1)
 {
     const float dx = r0.x - pxf, dy = r0.y - pyf;
     // forward.cu:361, source order, unfused (decision input)
     const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;
-    if (power > 0.0f) return false;
     const float alpha = fminf(0.99f, r1.y * fast_exp(power));
-    if (alpha < 1.0f / 255.0f) return false;
+    const bool c = live && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
     const float test_T = s.T * (1 - alpha);
-    if (test_T < 0.0001f) return true;
+    const bool fin = c && test_T < 0.0001f;
+    if (!c || fin) return fin;
     const float w = alpha * s.T;
     s.C[0] = fma_(r1.z, w, s.C[0]);
     s.C[1] = fma_(r1.w, w, s.C[1]);
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
-                if (!done) done = fwd_step(st, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
+                done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
             }
         }
     }

@@ -114,7 +114,7 @@ void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_colo
             for (uint32_t j = 0; j < n && !done; j++) {
                 const ghr::f4* r = s->rec.data() + 4 * (size_t)s->point_list[beg + j];
                 if (!ghr::cell_hit(ghr::alpha_bbox(r[0], r[1]), ghr::ellipse_params(r[0], r[1]), r[0], sx0, sy0)) continue;  // k_render_fwd's cell cull
-                done = ghr::fwd_step(st, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
+                done = ghr::fwd_step(st, true, (float)px, (float)py, r[0], r[1], r[2], r[3], j + 1);
             }
             const size_t pix = (size_t)a->W * py + px;
             s->final_T[pix] = st.T;
