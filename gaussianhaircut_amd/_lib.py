@@ -83,7 +83,9 @@ class ModelArgs(ctypes.Structure):
                                                "orient_conf_log", "features_dc", "features_rest", "viewmatrix",
                                                "projmatrix", "campos", "background")] + \
                [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "conic_eps")] + \
-               [("debug", ctypes.c_int32)]
+               [("debug", ctypes.c_int32), ("mode", ctypes.c_int32), ("row0", ctypes.c_int32),
+                ("dir3d", ctypes.c_void_p)] + \
+               [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")]
 
 
 class LossArgs(ctypes.Structure):
@@ -106,7 +108,8 @@ class WsView(ctypes.Structure):
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_model_forward_stage1",
-           "ghr_model_backward", "ghr_loss_forward", "ghr_loss_backward", "ghr_adam_step"]
+           "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
+           "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_backward", "ghr_adam_step"]
 
 _lib = None
 
@@ -137,6 +140,10 @@ def lib() -> ctypes.CDLL:
     L.ghr_adam_step.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, i32, ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, i32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp]
+    L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
+    L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
+    L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6
+    L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 
@@ -268,14 +269,20 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     if (m->sh_degree < 0 || m->sh_degree > 3 || m->sh_coeffs < (m->sh_degree + 1) * (m->sh_degree + 1) ||
         m->sh_coeffs > GHR_SH_MAX)
         return fail(GHR_E_INVALID, "bad sh_degree / sh_coeffs");
-    if (m->P > 0 && (!m->xyz || !m->log_scales || !m->rotations || !m->opacity_logit || !m->label_logit ||
-                     !m->orient_conf_log || !m->features_dc || (m->sh_coeffs > 1 && !m->features_rest) ||
-                     !m->viewmatrix || !m->projmatrix || !m->campos || !m->background))
+    if (m->mode != 0 && m->mode != 1) return fail(GHR_E_INVALID, "ghr_model_args: mode must be 0 or 1");
+    if (m->row0 < 0 || (m->row0 & (GHR_BLOCK - 1))) return fail(GHR_E_INVALID, "ghr_model_args: row0 must be a multiple of 256");
+    const bool need_act = m->mode == 0;  // mode 1: opacity / label / confidence pointers are optional
+    if (m->P > 0 && (!m->xyz || !m->log_scales || !m->rotations || (need_act && (!m->opacity_logit || !m->label_logit ||
+                     !m->orient_conf_log)) || !m->features_dc || (m->sh_coeffs > 1 && !m->features_rest) ||
+                     !m->viewmatrix || !m->projmatrix || !m->campos))
         return fail(GHR_E_INVALID, "ghr_model_args: NULL parameter tensor");
     a->P = m->P; a->W = m->W; a->H = m->H; a->gx = grid_x(m->W); a->gy = grid_x(m->H);
     a->sh_degree = m->sh_degree; a->sh_coeffs = m->sh_coeffs;
+    a->mode = m->mode; a->row0 = m->row0;
     a->xyz = m->xyz; a->log_scales = m->log_scales; a->rotations = m->rotations;
     a->opacity_logit = m->opacity_logit; a->label_logit = m->label_logit; a->orient_conf_log = m->orient_conf_log;
+    a->dir3d = m->mode == 1 ? m->dir3d : nullptr;
+    a->const_opacity = m->const_opacity; a->const_label = m->const_label; a->const_conf = m->const_conf;
     a->features_dc = m->features_dc; a->features_rest = m->features_rest;
     a->view = m->viewmatrix; a->proj = m->projmatrix; a->campos = m->campos;
     a->scale_modifier = m->scale_modifier; a->tan_fovx = m->tan_fovx; a->tan_fovy = m->tan_fovy;
@@ -286,28 +293,112 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     a->tile_count = nullptr; a->slot_blk = nullptr;
     return GHR_OK;
 }
+inline int n_blocks(int rows) { return (rows + GHR_BLOCK - 1) / GHR_BLOCK; }
 }  // namespace
+
+int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, int32_t first, void* geom_ws,
+                              void* img_ws, int32_t* radii, float* means2D_out)
+{
+    ghr::ModelArgs a;
+    if (int rc = fill_model(m, &a)) return rc;
+    if (rows_total < 0 || (long long)a.row0 + a.P > rows_total) return fail(GHR_E_INVALID, "segment exceeds rows_total");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows_total == 0) return GHR_OK;
+    if (!geom_ws || !img_ws || !radii) return fail(GHR_E_INVALID, "workspace/radii is NULL");
+    const int T = a.gx * a.gy;
+    Geom g; Img im;
+    carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
+    carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
+    if (first) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    // rows between the end of this segment and the next multiple of 256 are padding: culled, no gradient slots
+    const int end = a.row0 + a.P;
+    const int pad_end = (int)std::min<long long>((long long)n_blocks(end) * GHR_BLOCK, rows_total);
+    if (pad_end > end) {
+        GHR_HIP(hipMemsetAsync(g.rects + end, 0, sizeof(ghr::rect4) * (size_t)(pad_end - end), s));
+        GHR_HIP(hipMemsetAsync(radii + end, 0, sizeof(int32_t) * (size_t)(pad_end - end), s));
+    }
+    if (a.P == 0) return finish(s, m->debug);
+    a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
+    a.tile_count = im.tile_count; a.slot_blk = g.slot_blk;
+    hipLaunchKernelGGL(ghr::k_project, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a);
+    return finish(s, m->debug);
+}
+
+int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_t H, int32_t debug, void* geom_ws,
+                             void* img_ws, uint32_t* R_host)
+{
+    if (rows_total < 0 || W <= 0 || H <= 0) return fail(GHR_E_INVALID, "bad rows_total/W/H");
+    if (!R_host) return fail(GHR_E_INVALID, "R_host is NULL");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows_total == 0) { *R_host = 0; return GHR_OK; }
+    if (!geom_ws || !img_ws) return fail(GHR_E_INVALID, "workspace is NULL");
+    const int T = grid_x(W) * grid_x(H);
+    Geom g; Img im;
+    carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
+    carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
+                       g.slot_blk, n_blocks(rows_total));
+    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    return finish(s, debug);
+}
 
 int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_ws, void* img_ws, int32_t* radii,
                              float* means2D_out, uint32_t* R_host)
 {
+    if (!m) return fail(GHR_E_INVALID, "ghr_model_args is NULL");
+    if (m->row0 != 0) return fail(GHR_E_INVALID, "ghr_model_forward_stage1: row0 must be 0 (use the segment calls)");
+    if (!R_host) return fail(GHR_E_INVALID, "R_host is NULL");
+    if (int rc = ghr_model_forward_segment(stream, m, m->P, 1, geom_ws, img_ws, radii, means2D_out)) return rc;
+    return ghr_model_forward_finish(stream, m->P, m->W, m->H, m->debug, geom_ws, img_ws, R_host);
+}
+
+int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
+                        const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
+                        float* grad_scratch)
+{
+    if (rows_total < 0 || W <= 0 || H <= 0) return fail(GHR_E_INVALID, "bad rows_total/W/H");
+    hipStream_t s = (hipStream_t)stream;
+    if (rows_total == 0 || R == 0) return GHR_OK;
+    if (!background || !geom_ws || !img_ws || !bin_ws || !dL_dpix || !grad_scratch)
+        return fail(GHR_E_INVALID, "ghr_render_backward: NULL buffer");
+    const int gx = grid_x(W), T = gx * grid_x(H);
+    Geom g; Img im; Bin b;
+    carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
+    carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
+    carve_bin(align_base(bin_ws), (size_t)R, &b);
+    if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
+    hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, W, H, gx, (uint32_t)T, im.tile_start,
+                       b.point_list, g.rec, background, im.final_T, im.n_contrib, dL_dpix, g.rects, grad_scratch);
+    if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
+    return finish(s, 0);
+}
+
+int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, const int32_t* radii,
+                               const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
+                               float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
+                               float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
+                               int32_t accumulate, int32_t* nan_flag)
+{
     ghr::ModelArgs a;
     if (int rc = fill_model(m, &a)) return rc;
-    if (!R_host) return fail(GHR_E_INVALID, "R_host is NULL");
+    if (rows_total < 0 || (long long)a.row0 + a.P > rows_total) return fail(GHR_E_INVALID, "segment exceeds rows_total");
     hipStream_t s = (hipStream_t)stream;
-    if (a.P == 0) { *R_host = 0; return GHR_OK; }
-    if (!geom_ws || !img_ws || !radii) return fail(GHR_E_INVALID, "workspace/radii is NULL");
-    const int T = a.gx * a.gy;
-    Geom g; Img im;
-    carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
-    carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
-    a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
-    a.tile_count = im.tile_count; a.slot_blk = g.slot_blk;
-    hipLaunchKernelGGL(ghr::k_project, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a);
-    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
-                       g.slot_blk, (a.P + GHR_BLOCK - 1) / GHR_BLOCK);
-    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (a.P == 0) return GHR_OK;
+    const bool need_act = a.mode == 0;
+    if (!radii || !geom_ws || !d_means2D || !d_xyz || !d_log_scales || !d_rotations || !d_features_dc ||
+        (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) || (a.sh_coeffs > 1 && !d_features_rest))
+        return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
+    Geom g;
+    carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
+    a.radii = const_cast<int*>(radii);
+    a.rects = g.rects;
+    ghr::ModelGrads mg;
+    mg.ginst = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
+    mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
+    mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
+    mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
+    mg.accumulate = accumulate; mg.nan_flag = nan_flag;
+    hipLaunchKernelGGL(ghr::k_project_bwd, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a, mg);
     return finish(s, m->debug);
 }
 
@@ -317,34 +408,17 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
                        float* d_features_rest, int32_t accumulate, int32_t* nan_flag)
 {
-    ghr::ModelArgs a;
-    if (int rc = fill_model(m, &a)) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    if (a.P == 0) return GHR_OK;
-    if (!radii || !geom_ws || !img_ws || (R > 0 && !bin_ws) || !dL_dpix || (R > 0 && !grad_scratch) || !d_means2D || !d_xyz ||
-        !d_log_scales || !d_rotations || !d_opacity_logit || !d_label_logit || !d_orient_conf_log || !d_features_dc ||
-        (a.sh_coeffs > 1 && !d_features_rest))
+    if (!m) return fail(GHR_E_INVALID, "ghr_model_args is NULL");
+    if (m->row0 != 0) return fail(GHR_E_INVALID, "ghr_model_backward: row0 must be 0 (use the segment calls)");
+    if (m->P == 0) return GHR_OK;
+    if (!dL_dpix || (R > 0 && (!grad_scratch || !bin_ws)) || !img_ws || !m->background)
         return fail(GHR_E_INVALID, "ghr_model_backward: NULL buffer");
-    const int T = a.gx * a.gy;
-    Geom g; Img im; Bin b;
-    carve_geom(align_base(geom_ws), (size_t)a.P, false, &g);
-    carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
-    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
-    if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    if (R > 0)
-        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a.W, a.H, a.gx, (uint32_t)T,
-                           im.tile_start, b.point_list, g.rec, m->background, im.final_T, im.n_contrib, dL_dpix,
-                           g.rects, grad_scratch);
-    if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
-    a.radii = const_cast<int*>(radii);
-    a.rects = g.rects;
-    ghr::ModelGrads mg;
-    mg.ginst = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
-    mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
-    mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
-    mg.accumulate = accumulate; mg.nan_flag = nan_flag;
-    hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, a, mg);
-    return finish(s, m->debug);
+    if (int rc = ghr_render_backward(stream, m->P, m->W, m->H, R, m->background, geom_ws, img_ws, bin_ws, dL_dpix,
+                                     grad_scratch))
+        return rc;
+    return ghr_model_backward_segment(stream, m, m->P, radii, geom_ws, grad_scratch, d_means2D, d_xyz, d_log_scales,
+                                      d_rotations, d_opacity_logit, d_label_logit, d_orient_conf_log, d_features_dc,
+                                      d_features_rest, nullptr, accumulate, nan_flag);
 }
 
 namespace ghr {

@@ -23,16 +23,29 @@ namespace ghr {
 
 #define GHR_SH_MAX 16  // (3 + 1)^2 coefficients per colour channel
 
+// Two parametrisations share the kernels:
+//   mode 0  the free-Gaussian GaussianModel: raw parameters, activations applied here (exp / sigmoid), 2D direction =
+//           longest principal axis (gaussian_model.py:344-393);
+//   mode 1  explicit linear-space Gaussians, what render_hair() feeds the rasterizer in the strand stage
+//           (gaussian_renderer/__init__.py:116-214, gaussian_model_strands.py:230-452): scaling / opacity / label /
+//           orientation confidence are already activated (a NULL pointer means the constant in const_*), the 2D direction
+//           is normalize(dir3d) @ T (zero when dir3d is NULL: the frozen head).
+// A call covers ONE segment of `P` Gaussians whose outputs land at workspace rows row0 .. row0+P-1 (row0 a multiple of
+// 256), so the frozen head and the trainable strands are projected by two launches into one rasterizer state.
 struct ModelArgs {
     int P, W, H, gx, gy;
     int sh_degree;   // active degree (0..3)
     int sh_coeffs;   // K = (max_degree + 1)^2 coefficients stored per channel (<= 16)
+    int mode;        // 0 / 1, see above
+    int row0;        // first workspace row of the segment
     const float* xyz;             // [P,3]
-    const float* log_scales;      // [P,3]  scaling = exp(.)                     gaussian_model.py:108-109
+    const float* log_scales;      // [P,3]  mode 0: scaling = exp(.) (gaussian_model.py:108-109); mode 1: scaling
     const float* rotations;       // [P,4]  raw quaternion (r,x,y,z), normalised here (general_utils.py:79-83)
-    const float* opacity_logit;   // [P]    sigmoid
-    const float* label_logit;     // [P]    sigmoid
-    const float* orient_conf_log; // [P]    exp
+    const float* opacity_logit;   // [P]    mode 0: sigmoid(.); mode 1: opacity or NULL
+    const float* label_logit;     // [P]    mode 0: sigmoid(.); mode 1: label or NULL
+    const float* orient_conf_log; // [P]    mode 0: exp(.);     mode 1: confidence or NULL
+    const float* dir3d;           // [P,3]  mode 1: strand direction or NULL
+    float const_opacity, const_label, const_conf;  // mode 1 values for NULL pointers
     const float* features_dc;     // [P,1,3]
     const float* features_rest;   // [P,K-1,3]
     const float* view;            // [16] world_view_transform
@@ -44,10 +57,10 @@ struct ModelArgs {
     float* depths;
     rect4* rects;
     int* radii;
-    float* means2D;  // [P,3] NDC (viewspace_points values), may be null
+    float* means2D;  // [rows,3] NDC (viewspace_points values), may be null
     uint32_t* tile_count;  // [T] counts
-    uint32_t* slot_blk;    // [ceil(P/256)] gradient slots per workgroup
-};
+    uint32_t* slot_blk;    // [ceil(rows/256)] gradient slots per workgroup
+};  // rec / depths / rects / radii / means2D / slot_blk are indexed by WORKSPACE ROW (row0 + idx)
 
 struct ModelGrads {
     const float* ginst;  // [R][16] per-instance packed gradients from k_render_bwd (slots: rect4_slot)
@@ -60,6 +73,8 @@ struct ModelGrads {
     float* d_orient_conf_log; // [P]
     float* d_features_dc;     // [P,1,3]
     float* d_features_rest;   // [P,K-1,3]
+    float* d_dir3d;           // [P,3] mode 1 (NULL: not wanted).  In mode 1 d_log_scales / d_opacity_logit / d_label_logit /
+                              // d_orient_conf_log receive the gradients of the LINEAR quantities and may be NULL
     int accumulate;           // != 0: parameter gradients are ADDED to the output buffers (d_means2D is always assigned)
     int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN
 };
@@ -67,6 +82,7 @@ struct ModelGrads {
 // Writes (or accumulates) one parameter-gradient element; returns whether the stored value is NaN.
 GHR_HD bool grad_out(float* p, float v, int accumulate)
 {
+    if (p == nullptr) return false;
     if (accumulate) v += *p;
     *p = v;
     return v != v;
@@ -162,7 +178,7 @@ GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
     const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        c.s0[i] = expf(a.log_scales[3 * idx + i]);
+        c.s0[i] = a.mode == 0 ? expf(a.log_scales[3 * idx + i]) : a.log_scales[3 * idx + i];
         c.s[i] = c.s0[i] * a.scale_modifier;
     }
     const float q0 = a.rotations[4 * idx], q1 = a.rotations[4 * idx + 1], q2 = a.rotations[4 * idx + 2],
@@ -230,8 +246,9 @@ GHR_HD float sh_coeff(const ModelArgs& a, int idx, const float* rest, int k, int
 // Forward for one Gaussian.  Returns false when culled.
 GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1)
 {
-    a.radii[idx] = 0;
-    a.rects[idx] = rect4{0u, 0u, 0u, 0u};
+    const size_t row = (size_t)a.row0 + idx;
+    a.radii[row] = 0;
+    a.rects[row] = rect4{0u, 0u, 0u, 0u};
     ProjCtx c;
     proj_setup(a, idx, c);
     const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
@@ -245,9 +262,9 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
     const float p_w = 1.0f / (hw + 0.0000001f);
     const float ndcx = hx * p_w, ndcy = hy * p_w;
     if (a.means2D) {
-        a.means2D[3 * idx] = ndcx;
-        a.means2D[3 * idx + 1] = ndcy;
-        a.means2D[3 * idx + 2] = hz * p_w;
+        a.means2D[3 * row] = ndcx;
+        a.means2D[3 * row + 1] = ndcy;
+        a.means2D[3 * row + 2] = hz * p_w;
     }
 
     // filter_points (gaussian_model.py:166-172) == K1's cull (auxiliary.h:154)
@@ -280,20 +297,36 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
         for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, idx, rest, k, ch);
         rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
     }
-    const float label = sigmoidf_(a.label_logit[idx]);
-    const float conf = expf(a.orient_conf_log[idx]);
-    const float opac = sigmoidf_(a.opacity_logit[idx]);
-    const float sj = sel3(c.s0, c.jmax);
-    const float d2x = sj * sel3(c.p, c.jmax), d2y = sj * sel3(c.r, c.jmax);
+    float label, conf, opac, d2x, d2y;
+    if (a.mode == 0) {
+        label = sigmoidf_(a.label_logit[idx]);
+        conf = expf(a.orient_conf_log[idx]);
+        opac = sigmoidf_(a.opacity_logit[idx]);
+        const float sj = sel3(c.s0, c.jmax);
+        d2x = sj * sel3(c.p, c.jmax);
+        d2y = sj * sel3(c.r, c.jmax);
+    } else {
+        label = a.label_logit ? a.label_logit[idx] : a.const_label;
+        conf = a.orient_conf_log ? a.orient_conf_log[idx] : a.const_conf;
+        opac = a.opacity_logit ? a.opacity_logit[idx] : a.const_opacity;
+        d2x = 0.f;
+        d2y = 0.f;
+        if (a.dir3d) {  // normalize(dir) @ T (gaussian_model_strands.py:430-431; F.normalize eps = 1e-12)
+            const float dx_ = a.dir3d[3 * idx], dy_ = a.dir3d[3 * idx + 1], dz_ = a.dir3d[3 * idx + 2];
+            const float in_ = 1.0f / fmaxf(sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_), 1e-12f);
+            d2x = (dx_ * c.u[0] + dy_ * c.u[1] + dz_ * c.u[2]) * in_;
+            d2y = (dx_ * c.v[0] + dy_ * c.v[1] + dz_ * c.v[2]) * in_;
+        }
+    }
 
-    f4* r = a.rec + 4 * (size_t)idx;
+    f4* r = a.rec + 4 * row;
     r[0] = f4{pixx, pixy, cx, cy};
     r[1] = f4{cz, opac, rgb[0], rgb[1]};
     r[2] = f4{rgb[2], label, 1.0f, d2x};
     r[3] = f4{d2y, 0.0f, conf, c.t[2]};
-    a.depths[idx] = c.t[2];
-    a.radii[idx] = (int)my_radius;
-    a.rects[idx] = make_rect4(x0, y0, x1, y1, 0u);  // the caller fills in the gradient-slot base
+    a.depths[row] = c.t[2];
+    a.radii[row] = (int)my_radius;
+    a.rects[row] = make_rect4(x0, y0, x1, y1, 0u);  // the caller fills in the gradient-slot base
     return true;
 }
 
@@ -310,12 +343,14 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
     float ddc[3] = {0, 0, 0};
+    const size_t row = (size_t)a.row0 + idx;
+    float ddir[3] = {0, 0, 0};
     const float gmx = ga[0], gmy = ga[1];
-    g.d_means2D[3 * idx] = gmx;
-    g.d_means2D[3 * idx + 1] = gmy;
-    g.d_means2D[3 * idx + 2] = 0.f;
+    g.d_means2D[3 * row] = gmx;
+    g.d_means2D[3 * row + 1] = gmy;
+    g.d_means2D[3 * row + 2] = 0.f;
 
-    if (a.radii[idx] > 0) {
+    if (a.radii[row] > 0) {
         ProjCtx c;
         proj_setup(a, idx, c);
         const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
@@ -323,12 +358,18 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
         const float gop = ga[5];
         const float* gc = ga + 6;  // colours: rgb 0-2, label 3, one 4, dir2D 5-7, conf 8, depth 9
 
-        // ---- activations
-        const float o = sigmoidf_(a.opacity_logit[idx]);
-        dlo = gop * o * (1.f - o);
-        const float l = sigmoidf_(a.label_logit[idx]);
-        dll = gc[3] * l * (1.f - l);
-        dlc = gc[8] * expf(a.orient_conf_log[idx]);
+        // ---- activations (mode 1: the inputs are the activated quantities)
+        if (a.mode == 0) {
+            const float o = sigmoidf_(a.opacity_logit[idx]);
+            dlo = gop * o * (1.f - o);
+            const float l = sigmoidf_(a.label_logit[idx]);
+            dll = gc[3] * l * (1.f - l);
+            dlc = gc[8] * expf(a.orient_conf_log[idx]);
+        } else {
+            dlo = gop;
+            dll = gc[3];
+            dlc = gc[8];
+        }
 
         // ---- conic = (c, -b, a) * k, k = 1/(det + eps)
         const float S = gA * c.c - gB * c.b + gC * c.a;
@@ -349,7 +390,7 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {  // dir2D = s0_j (p_j, r_j): only the longest axis j receives these terms
-            const float on = (i == c.jmax) ? 1.f : 0.f;
+            const float on = (a.mode == 0 && i == c.jmax) ? 1.f : 0.f;
             const float sj = c.s0[i] * on;
             Lp[i] += sj * gc[5];
             Lr[i] += sj * gc[6];
@@ -365,6 +406,32 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
                 Lu[m] += Lp[i] * c.ax[i][m];
                 Lv[m] += Lr[i] * c.ax[i][m];
             }
+        if (a.mode != 0) {
+            // d/d(log s) -> d/ds for the linear scaling of mode 1 (s = s0 * modifier, s0 > 0)
+#pragma unroll
+            for (int i = 0; i < 3; i++) dls[i] = dls[i] / c.s0[i];
+            if (a.dir3d) {  // dir2D = normalize(dir) . (u, v): cotangents for u, v and for dir (through the normalisation)
+                const float dx_ = a.dir3d[3 * idx], dy_ = a.dir3d[3 * idx + 1], dz_ = a.dir3d[3 * idx + 2];
+                const float len_ = sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_);
+                const float in_ = 1.0f / fmaxf(len_, 1e-12f);
+                const float dh[3] = {dx_ * in_, dy_ * in_, dz_ * in_};
+                float Ldh[3];
+#pragma unroll
+                for (int m = 0; m < 3; m++) {
+                    Lu[m] += gc[5] * dh[m];
+                    Lv[m] += gc[6] * dh[m];
+                    Ldh[m] = gc[5] * c.u[m] + gc[6] * c.v[m];
+                }
+                if (len_ > 1e-12f) {
+                    const float dotp = Ldh[0] * dh[0] + Ldh[1] * dh[1] + Ldh[2] * dh[2];
+#pragma unroll
+                    for (int m = 0; m < 3; m++) ddir[m] = (Ldh[m] - dh[m] * dotp) * in_;
+                } else {
+#pragma unroll
+                    for (int m = 0; m < 3; m++) ddir[m] = Ldh[m] * in_;
+                }
+            }
+        }
         // ---- rotation: rows of R(q_hat), then the normalisation q_hat = q/|q|
         {
             const float w = c.qn[0], x = c.qn[1], y = c.qn[2], z = c.qn[3];
@@ -458,9 +525,11 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) bad |= grad_out(g.d_rotations + 4 * idx + i, dq[i], acc);
-    bad |= grad_out(g.d_opacity_logit + idx, dlo, acc);
-    bad |= grad_out(g.d_label_logit + idx, dll, acc);
-    bad |= grad_out(g.d_orient_conf_log + idx, dlc, acc);
+    bad |= grad_out(g.d_opacity_logit ? g.d_opacity_logit + idx : nullptr, dlo, acc);
+    bad |= grad_out(g.d_label_logit ? g.d_label_logit + idx : nullptr, dll, acc);
+    bad |= grad_out(g.d_orient_conf_log ? g.d_orient_conf_log + idx : nullptr, dlc, acc);
+#pragma unroll
+    for (int i = 0; i < 3; i++) bad |= grad_out(g.d_dir3d ? g.d_dir3d + 3 * idx + i : nullptr, ddir[i], acc);
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) bad |= grad_out(g.d_features_dc + 3 * (size_t)idx + ch, ddc[ch], acc);
     return bad;
@@ -520,8 +589,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     __shared__ uint32_t s_scan[4];
     uint32_t blk_total;
     const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
-    if (ok) a.rects[idx].z = slot0;
-    if (threadIdx.x == 0) a.slot_blk[blockIdx.x] = blk_total;
+    if (ok) a.rects[(size_t)a.row0 + idx].z = slot0;
+    if (threadIdx.x == 0) a.slot_blk[blockIdx.x + (a.row0 >> 8)] = blk_total;
     count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
 #endif
 }
@@ -539,7 +608,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     bool bad = false;
     if (idx < a.P) {
         float ga[16];
-        gather_inst_grads(g.ginst, a.rects[idx], ga);
+        gather_inst_grads(g.ginst, a.rects[(size_t)a.row0 + idx], ga);
         bad = project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
     }
     __syncthreads();

@@ -142,8 +142,22 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     return _package(renders, screenspace_points, radii)
 
 
+def _use_fused_hair(pc, pc_hair, pipe) -> bool:
+    """Fused strand-stage path: a ``GaussianModel`` head with its ``*_precomp`` attributes and a
+    ``GaussianModelStrands`` on a ROCm device (anything else takes the generic path)."""
+    from ..scene.gaussian_model import GaussianModel
+    from ..scene.gaussian_model_strands import GaussianModelStrands
+    return (type(pc) is GaussianModel and type(pc_hair) is GaussianModelStrands and
+            getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view"))
+
+
 def render_hair(viewpoint_camera, pc, pc_hair, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
     """Frozen head Gaussians (``*_precomp`` attributes of ``pc``) + trainable hair strands (reference :116-214)."""
+    if _use_fused_hair(pc, pc_hair, pipe):
+        from .fused import render_hair_fused
+        renders, radii, screenspace_points = render_hair_fused(viewpoint_camera, pc, pc_hair, bg_color,
+                                                               scaling_modifier, getattr(pipe, "debug", False))
+        return _package(renders, screenspace_points, radii)
     head = pc.mask_precomp
     conic = torch.cat([pc.get_conic(viewpoint_camera, scaling_modifier)[head],
                        pc_hair.get_conic(viewpoint_camera, scaling_modifier)])

@@ -135,3 +135,149 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
     renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
                                              pc._features_dc, pc._features_rest, screenspace_points, cfg)
     return renders, radii, screenspace_points
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Strand stage: render_hair() = frozen head Gaussians + strand Gaussians (reference gaussian_renderer/__init__.py:116-214)
+# as TWO segments of one rasterizer state, both projected by the fused kernel in its explicit mode (include/ghr.h,
+# ghr_model_forward_segment): no concatenation of 60-float rows, no ~60 PyTorch projection kernels, and the backward
+# goes straight to the strand quantities (xyz, scaling, rotation, direction, SH, confidence), from where autograd
+# continues to the strand parameters (`_dirs`) through initialize_gaussians_hair().
+def _seg_args(P, row0, W, H, sh_degree, K, t, cam_t, cfg, eps, consts):
+    m = _lib.ModelArgs()
+    m.P, m.W, m.H, m.sh_degree, m.sh_coeffs = int(P), int(W), int(H), int(sh_degree), int(K)
+    m.xyz, m.log_scales, m.rotations = _ptr(t["xyz"]), _ptr(t["scaling"]), _ptr(t["rotation"])
+    m.opacity_logit = _ptr(t["opacity"]) if t.get("opacity") is not None else None
+    m.label_logit = None
+    m.orient_conf_log = _ptr(t["conf"]) if t.get("conf") is not None else None
+    m.dir3d = _ptr(t["dir"]) if t.get("dir") is not None else None
+    m.features_dc, m.features_rest = _ptr(t["fdc"]), _ptr(t["frest"])
+    m.viewmatrix, m.projmatrix, m.campos, m.background = [_ptr(x) for x in cam_t]
+    m.scale_modifier, m.tan_fovx, m.tan_fovy = cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"]
+    m.conic_eps = eps
+    m.debug = int(bool(cfg["debug"]))
+    m.mode, m.row0 = 1, int(row0)
+    m.const_opacity, m.const_label, m.const_conf = consts
+    return m
+
+
+class _RenderHairFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, scaling, rotation, dirs, conf, f_dc, f_rest, screenspace_points, head, cfg):
+        L = _lib.lib()
+        if not xyz.is_cuda:
+            raise RuntimeError("gaussianhaircut_amd: parameters are on %s; the HIP renderer has no CPU path" % xyz.device)
+        dev = xyz.device
+        W, H = cfg["W"], cfg["H"]
+        hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=f_dc, frest=f_rest)
+        hair = {k: v.detach().float().contiguous() for k, v in hair.items()}
+        hair["conf"] = hair["conf"].reshape(-1)
+        n_head, n_hair = head["xyz"].shape[0], xyz.shape[0]
+        row0 = (n_head + 255) // 256 * 256
+        rows = row0 + n_hair
+        K = 1 + f_rest.shape[1]
+        cam_t = [cfg[k].float().contiguous() for k in ("view", "proj", "campos", "bg")]
+        with torch.cuda.device(dev):
+            color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            radii_ws = torch.empty((rows,), dtype=torch.int32, device=dev)
+            m2d_ws = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+            gbytes, ibytes = _lib.forward_sizes(rows, W, H, False)
+            geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
+            img = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
+            m_head = _seg_args(n_head, 0, W, H, cfg["sh_degree"], K, head, cam_t, cfg, cfg["eps_head"], (1.0, 0.0, 0.0))
+            m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, cam_t, cfg, cfg["eps_hair"], (1.0, 1.0, 0.0))
+            pinned = _pinned(dev)
+            _lib.check(L.ghr_model_forward_segment(_stream(), ctypes.byref(m_head), rows, 1, _ptr(geom), _ptr(img),
+                                                   _ptr(radii_ws), _ptr(m2d_ws)))
+            _lib.check(L.ghr_model_forward_segment(_stream(), ctypes.byref(m_hair), rows, 0, _ptr(geom), _ptr(img),
+                                                   _ptr(radii_ws), _ptr(m2d_ws)))
+            _lib.check(L.ghr_model_forward_finish(_stream(), rows, W, H, int(bool(cfg["debug"])), _ptr(geom), _ptr(img),
+                                                  ctypes.c_void_p(pinned.data_ptr())))
+            va = _lib.ViewArgs()
+            va.P, va.W, va.H, va.C = rows, W, H, NUM_CHANNELS
+            va.background = _ptr(cam_t[3])
+            va.debug = int(bool(cfg["debug"]))
+
+            def launch(cap):
+                b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
+                                                _ptr(color)))
+                return b
+
+            R, cap, binb = run_stage2(dev, rows, pinned, launch)
+            # the reference's outputs are indexed by [head rows, strand rows] without the alignment padding
+            radii = torch.cat([radii_ws[:n_head], radii_ws[row0:]])
+            screenspace_points.detach().copy_(torch.cat([m2d_ws[:n_head], m2d_ws[row0:]]))
+        LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(rows)
+        ctx.cfg, ctx.R, ctx.K, ctx.cap, ctx.dims = cfg, R, K, cap, (n_head, n_hair, row0, rows)
+        ctx.mark_non_differentiable(radii)
+        ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t,
+                              radii_ws, geom, img, binb)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_color, _):
+        L = _lib.lib()
+        cfg, R, K = ctx.cfg, ctx.R, ctx.K
+        n_head, n_hair, row0, rows = ctx.dims
+        xyz, scaling, rotation, dirs, conf, fdc, frest, view, proj, campos, bg, radii_ws, geom, img, binb = ctx.saved_tensors
+        dev = xyz.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        W, H = cfg["W"], cfg["H"]
+        with torch.cuda.device(dev):
+            d_m2d_ws = torch.zeros((rows, 3), **f32)   # head rows keep 0: the head is frozen
+            d_xyz, d_sc = torch.empty((n_hair, 3), **f32), torch.empty((n_hair, 3), **f32)
+            d_rot, d_dir = torch.empty((n_hair, 4), **f32), torch.empty((n_hair, 3), **f32)
+            d_conf = torch.empty((n_hair, 1), **f32)
+            d_fdc, d_frest = torch.empty((n_hair, 1, 3), **f32), torch.empty((n_hair, K - 1, 3), **f32)
+            scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)
+            dL = grad_color.float().contiguous()
+            hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
+            m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, [view, proj, campos, bg], cfg,
+                               cfg["eps_hair"], (1.0, 1.0, 0.0))
+            if rows > 0:
+                _lib.check(L.ghr_render_backward(_stream(), rows, W, H, ctx.cap, _ptr(bg), _ptr(geom), _ptr(img),
+                                                 _ptr(binb), _ptr(dL), _ptr(scratch)))
+            if n_hair > 0:
+                _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
+                                                        _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
+                                                        _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
+                                                        _ptr(d_dir), 0, None))
+            d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
+        return d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d, None, None
+
+
+def head_segment(pc):
+    """Contiguous fp32 tensors of the frozen head Gaussians (the ``*_precomp`` attributes of the reference's
+    train_strands.py:65-73) in the layout the fused kernel reads; cached on the model."""
+    cache = getattr(pc, "_fused_head_cache", None)
+    key = (pc.xyz_precomp.data_ptr(), pc.xyz_precomp.shape[0])
+    if cache is None or cache[0] != key:
+        sv = pc.shs_view  # [n, 3, K] -> features layout [n, K, 3]
+        feats = sv.transpose(1, 2).contiguous().float()
+        t = dict(xyz=pc.xyz_precomp.detach().float().contiguous(),
+                 scaling=pc.scaling_precomp.detach().float().contiguous(),
+                 rotation=pc.rotation_precomp.detach().float().contiguous(),
+                 opacity=pc.opacity_precomp.detach().float().reshape(-1).contiguous(),
+                 fdc=feats[:, :1].contiguous(), frest=feats[:, 1:].contiguous())
+        pc._fused_head_cache = cache = (key, t)
+    return cache[1]
+
+
+def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
+    """Returns (renders[10,H,W], radii[n_head + n_hair], screenspace_points leaf)."""
+    import math
+    head = head_segment(pc)
+    xyz = pc_hair.get_xyz
+    n = head["xyz"].shape[0] + xyz.shape[0]
+    screenspace_points = torch.empty((n, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
+    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
+               proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
+               sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier),
+               tanfovx=math.tan(float(cam.FoVx) * 0.5), tanfovy=math.tan(float(cam.FoVy) * 0.5),
+               eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
+               debug=bool(debug))
+    renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
+                                            pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
+                                            screenspace_points, head, cfg)
+    return renders, radii, screenspace_points

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 4
+#define GHR_ABI_VERSION 5
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -132,8 +132,17 @@ typedef struct ghr_model_args {
     const float* campos;          /* [3] */
     const float* background;      /* [C] */
     float scale_modifier, tan_fovx, tan_fovy;
-    float conic_eps;              /* 1e-12 (gaussian_model.py:312) */
+    float conic_eps;              /* 1e-12 (gaussian_model.py:312); strand stage 1e-7 (gaussian_model_strands.py:355) */
     int32_t debug;
+    /* ---- explicit linear-space Gaussians: what render_hair() feeds the rasterizer in the strand stage
+     * (src/gaussian_renderer/__init__.py:116-214).  mode 1: log_scales holds the scaling, opacity_logit / label_logit /
+     * orient_conf_log the ACTIVATED values (NULL = the constant below), dir3d the strand direction whose normalised
+     * projection normalize(dir) @ T is the 2D direction (NULL = zero direction: frozen head Gaussians).
+     * row0: first workspace row of this segment (ghr_model_forward_segment); a multiple of 256. */
+    int32_t mode;
+    int32_t row0;
+    const float* dir3d;           /* [P,3] or NULL */
+    float const_opacity, const_label, const_conf;
 } ghr_model_args;
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
@@ -147,6 +156,28 @@ int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_w
  * buffers hold (they may be the optimizer's own flat gradient buffer: no separate accumulation pass).
  * nan_flag (nullable, device int): set to 1 when any stored parameter-gradient value is NaN (the stage-1 loop's NaN
  * guard, src/train_gaussians.py:174-181, without a scan over the gradients). */
+/* ---- segmented form (strand stage): several ghr_model_args segments, each covering rows row0 .. row0+P-1 of ONE
+ * rasterizer state of rows_total rows (workspaces sized with ghr_forward_sizes(rows_total, ...); radii / means2D_out
+ * [rows_total(,3)]).  Call ghr_model_forward_segment for every segment (first != 0 on the first), then
+ * ghr_model_forward_finish (tile scan + *R_host), then ghr_forward_stage2 with P = rows_total as usual.  Rows between
+ * the end of a segment and the next multiple of 256 are culled padding. */
+int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, int32_t first, void* geom_ws,
+                              void* img_ws, int32_t* radii, float* means2D_out);
+int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_t H, int32_t debug, void* geom_ws,
+                             void* img_ws, uint32_t* R_host);
+/* Backward in two steps: K8 over the whole state (rows_total rows), then the per-Gaussian chain for the segments that
+ * need gradients.  d_means2D is [rows_total,3]; the parameter gradients are per segment ([P,...]); in mode 1
+ * d_log_scales / d_opacity_logit / d_label_logit / d_orient_conf_log are the gradients of the linear quantities and,
+ * like d_dir3d, may be NULL. */
+int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
+                        const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
+                        float* grad_scratch);
+int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, const int32_t* radii,
+                               const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
+                               float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
+                               float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
+                               int32_t accumulate, int32_t* nan_flag);
+
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,

@@ -200,10 +200,11 @@ class HostSim:
 # --------------------------------------------------------------------------------------------------------------------
 class ModelArgsC(ctypes.Structure):
     """Mirror of ghr::ModelArgs (gaussianhaircut_amd/csrc/ghr_project.h) for the host-sim."""
-    _fields_ = [(n, ctypes.c_int) for n in ("P", "W", "H", "gx", "gy", "sh_degree", "sh_coeffs")] + \
+    _fields_ = [(n, ctypes.c_int) for n in ("P", "W", "H", "gx", "gy", "sh_degree", "sh_coeffs", "mode", "row0")] + \
                [(n, ctypes.c_void_p) for n in ("xyz", "log_scales", "rotations", "opacity_logit", "label_logit",
-                                               "orient_conf_log", "features_dc", "features_rest", "view", "proj",
-                                               "campos")] + \
+                                               "orient_conf_log", "dir3d")] + \
+               [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")] + \
+               [(n, ctypes.c_void_p) for n in ("features_dc", "features_rest", "view", "proj", "campos")] + \
                [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "focal_x", "focal_y",
                                               "conic_eps")] + \
                [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "radii", "means2D", "tile_count", "slot_blk")]
@@ -227,4 +228,5 @@ def model_args_from(model, cam, keep, conic_eps=1e-12):
     a.tan_fovx, a.tan_fovy = math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5)
     a.focal_x, a.focal_y = a.W / (2.0 * a.tan_fovx), a.H / (2.0 * a.tan_fovy)
     a.conic_eps = conic_eps
+    a.mode, a.row0, a.dir3d = 0, 0, None
     return a

@@ -227,9 +227,20 @@ void ghrsim_project_forward(const ghr::ModelArgs* a_in, float* out_rec, int* out
     std::memcpy(out_rec, rec.data(), sizeof(float) * 16 * (size_t)P);
 }
 
+void ghrsim_project_backward2(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
+                              float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
+                              float* d_fdc, float* d_frest, float* d_dir);
 void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
                              float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
                              float* d_fdc, float* d_frest)
+{
+    ghrsim_project_backward2(a_in, radii, gacc, d_means2D, d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest,
+                             nullptr);
+}
+// + the strand-direction gradient of mode 1 (d_dir may be NULL)
+void ghrsim_project_backward2(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
+                              float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
+                              float* d_fdc, float* d_frest, float* d_dir)
 {
     ghr::ModelArgs a = *a_in;
     a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
@@ -237,7 +248,7 @@ void ghrsim_project_backward(const ghr::ModelArgs* a_in, const int* radii, const
     ghr::ModelGrads g;
     g.ginst = nullptr; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
-    g.d_features_rest = d_frest;
+    g.d_features_rest = d_frest; g.d_dir3d = d_dir;
     g.accumulate = 0; g.nan_flag = nullptr;
     const int row = 3 * (a.sh_coeffs - 1);
     for (int i = 0; i < a.P; i++)

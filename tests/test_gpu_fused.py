@@ -249,3 +249,42 @@ def test_speculative_stage2_capacity_guess_never_changes_the_result(pipe):
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
         for a, b in zip(o[2:], outs[0][2:]):   # float atomics inside a tile: order-dependent rounding only
             assert torch.allclose(a, b, rtol=1e-4, atol=1e-7 * float(b.abs().max()))
+
+
+def test_fused_render_hair_matches_generic_path():
+    """Strand stage: the segmented fused projection behind render_hair() (explicit mode of k_project / k_project_bwd,
+    head + strands as two segments of one rasterizer state) vs the generic PyTorch projection path: image, radii,
+    viewspace points and the gradients that reach the strand parameters through initialize_gaussians_hair()."""
+    from gaussianhaircut_amd.gaussian_renderer import render_hair
+    from tests.test_api_cpu import _hair_scene
+    dev = torch.device("cuda:0")
+    res = {}
+    for name, pipe in (("fused", FUSED), ("generic", GENERIC)):
+        spec, head, hair, cam = _hair_scene(dev)
+        # strand parameters are the leaves: rebuild the per-Gaussian tensors inside the graph like train_strands.py:102
+        hair.initialize_gaussians_hair()
+        w = torch.randn(7, spec.H, spec.W, generator=torch.Generator().manual_seed(3)).to(dev)
+        pkg = render_hair(cam, head, hair, pipe, syn.background(dev))
+        full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
+        (full * w).sum().backward()
+        res[name] = (full.detach().cpu().numpy(), pkg["radii"].cpu().numpy(),
+                     pkg["viewspace_points"].detach().cpu().numpy(),
+                     {n: getattr(hair, n).grad.detach().cpu().numpy() for n in
+                      ("_dirs", "_features_dc", "_features_rest", "_orient_conf")},
+                     pkg["viewspace_points"].grad.detach().cpu().numpy())
+    (img_f, rad_f, vs_f, g_f, vg_f), (img_g, rad_g, vs_g, g_g, vg_g) = res["fused"], res["generic"]
+    assert rad_f.shape == rad_g.shape and (rad_f != rad_g).mean() < 1e-3
+    err = np.abs(img_f[:6] - img_g[:6]) / np.maximum(1.0, np.abs(img_g[:6]))
+    assert np.quantile(err, 0.999) < 1e-4
+    assert np.abs(vs_f[:, :2] - vs_g[:, :2]).max() < 1e-5
+    n_head = int((rad_f.shape[0] - g_f["_features_dc"].shape[0]))
+    # densification signal of the strand rows (the head is frozen: its rows stay 0 on the fused path)
+    a, b = vg_f[n_head:, :2], vg_g[n_head:, :2]
+    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() and np.abs(vg_f[:n_head]).max() == 0
+    for k in g_g:
+        a, b = g_f[k].reshape(len(g_f[k]), -1), g_g[k].reshape(len(g_g[k]), -1)
+        assert np.isfinite(a).all()
+        scale = np.abs(b).max() + 1e-30
+        rows = np.abs(b).max(axis=1, keepdims=True)
+        e = np.abs(a - b) / (rows + 1e-3 * scale)
+        assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())

@@ -123,3 +123,117 @@ def test_fused_projection_forward_and_backward(hostsim, cfg, deg):
         # fp32 kernel vs fp64 autograd: per-row relative; thin strands amplify rounding in the conic chain
         assert np.quantile(err, 0.995) < 5e-3 and np.isfinite(got).all(), (k, np.quantile(err, 0.995), err.max())
     assert np.array_equal(outs["d_means2D"][:, :2], gacc[:, 0:2])
+
+
+def test_fused_projection_explicit_mode_matches_strand_pipeline(hostsim):
+    """mode 1 of the fused projection (explicit linear-space Gaussians = what render_hair() assembles for the strands:
+    conic eps 1e-7, unit opacity / label, 2D direction = normalize(dir) @ T, linear confidence) against the PyTorch
+    strand pipeline in fp64, forward and hand-derived backward incl. the strand-direction term."""
+    from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
+    from tests.test_api_cpu import _hair_scene
+    spec, _, hair, cam = _hair_scene()
+    P = hair.get_xyz.shape[0]
+    deg = 3
+    hair.active_sh_degree = deg
+    # fp64 twin whose per-Gaussian quantities are independent leaves
+    md = GaussianModelStrands(3)
+    md.active_sh_degree = deg
+    with torch.no_grad():
+        leaves = dict(_xyz=hair._xyz.double(), _scaling=hair._scaling.double(), _rotation=hair._rotation.double(),
+                      _dir=hair._dir.double(), _features_dc=hair._features_dc.double(),
+                      _features_rest=hair._features_rest.double(), conf=hair.get_orient_conf.double())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    for k in ("_xyz", "_scaling", "_rotation", "_dir", "_features_dc", "_features_rest"):
+        setattr(md, k, leaves[k])
+    import copy
+    cd = copy.copy(cam)
+    for k, v in list(cd.__dict__.items()):
+        if isinstance(v, torch.Tensor) and v.is_floating_point():
+            setattr(cd, k, v.double())
+    conic = md.get_conic(cd)
+    means2D = md.get_mean_2d(cd)
+    shs_view = md.get_features.transpose(1, 2).reshape(-1, 3, 16)
+    d = md.get_xyz - cd.camera_center[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    rgb = torch.clamp_min(eval_sh(deg, shs_view, d) + 0.5, 0.0)
+    ones = torch.ones(P, 1, dtype=torch.float64)
+    colors = torch.cat([rgb, ones, ones, md.get_direction_2d(cd), leaves["conf"], md.get_depths(cd)], dim=-1)
+    keep = md.filter_points(cd).numpy()
+
+    # ---- product code (host-sim), mode 1
+    keep_alive = []
+    a = hp.ModelArgsC()
+    arr = dict(xyz=hp.np32(hair._xyz), log_scales=hp.np32(hair._scaling), rotations=hp.np32(hair._rotation),
+               dir3d=hp.np32(hair._dir), orient_conf_log=hp.np32(hair.get_orient_conf).reshape(-1),
+               features_dc=hp.np32(hair._features_dc), features_rest=hp.np32(hair._features_rest),
+               view=hp.np32(cam.world_view_transform).reshape(-1), proj=hp.np32(cam.full_proj_transform).reshape(-1),
+               campos=hp.np32(cam.camera_center))
+    keep_alive.append(arr)
+    for k, v in arr.items():
+        setattr(a, k, v.ctypes.data)
+    a.opacity_logit, a.label_logit = None, None
+    a.const_opacity, a.const_label, a.const_conf = 1.0, 1.0, 0.0
+    a.P, a.W, a.H, a.sh_degree, a.sh_coeffs, a.mode, a.row0 = P, spec.W, spec.H, deg, 16, 1, 0
+    import math
+    a.scale_modifier = 1.0
+    a.tan_fovx, a.tan_fovy = math.tan(float(cam.FoVx) * 0.5), math.tan(float(cam.FoVy) * 0.5)
+    a.focal_x, a.focal_y = a.W / (2.0 * a.tan_fovx), a.H / (2.0 * a.tan_fovy)
+    a.conic_eps = 1e-7
+    rec = np.zeros((P, 16), np.float32)
+    radii = np.zeros(P, np.int32)
+    m2d = np.zeros((P, 3), np.float32)
+    depths = np.zeros(P, np.float32)
+    hostsim.L.ghrsim_project_forward(ctypes.byref(a), ctypes.c_void_p(rec.ctypes.data),
+                                     ctypes.c_void_p(radii.ctypes.data), ctypes.c_void_p(m2d.ctypes.data),
+                                     ctypes.c_void_p(depths.ctypes.data))
+    vis = radii > 0
+    assert (vis == keep).mean() > 0.999 and vis.sum() > 100
+    both = vis & keep
+
+    def close(x, ref, tol=2e-4):
+        x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
+        err = np.abs(x - ref) / (np.abs(ref).max(axis=-1, keepdims=True) + 1e-6)
+        assert np.quantile(err, 0.999) < tol and err.max() < 50 * tol, (np.quantile(err, 0.999), err.max())
+
+    close(m2d[:, :2], means2D[:, :2].detach().numpy(), 1e-5)
+    close(rec[both, 2:5], conic.detach().numpy()[both], 2e-3)
+    assert np.all(rec[both, 5] == 1.0) and np.all(rec[both, 9] == 1.0) and np.all(rec[both, 10] == 1.0)
+    close(rec[both, 6:16], colors.detach().numpy()[both], 2e-4)
+
+    # ---- backward
+    g = torch.Generator().manual_seed(23)
+    g_conic = torch.randn(P, 3, generator=g, dtype=torch.float64)
+    g_m = torch.randn(P, 2, generator=g, dtype=torch.float64)
+    g_col = torch.randn(P, 10, generator=g, dtype=torch.float64)
+    mask = torch.from_numpy(both.astype(np.float64))[:, None]
+    L = ((conic * g_conic).sum(-1, keepdim=True) * mask).sum() + ((means2D[:, :2] * g_m).sum(-1, keepdim=True) * mask).sum() \
+        + ((colors * g_col).sum(-1, keepdim=True) * mask).sum()
+    L.backward()
+    gacc = np.zeros((P, 16), np.float32)
+    gacc[:, 0:2] = g_m.numpy()
+    gacc[:, 2] = g_conic[:, 0].numpy()
+    gacc[:, 3] = 0.5 * g_conic[:, 1].numpy()
+    gacc[:, 4] = g_conic[:, 2].numpy()
+    gacc[:, 6:16] = g_col.numpy()
+    gacc *= both[:, None]
+    outs = dict(d_means2D=np.zeros((P, 3), np.float32), d_xyz=np.zeros((P, 3), np.float32),
+                d_ls=np.zeros((P, 3), np.float32), d_rot=np.zeros((P, 4), np.float32), d_op=np.zeros(P, np.float32),
+                d_label=np.zeros(P, np.float32), d_conf=np.zeros(P, np.float32),
+                d_fdc=np.zeros((P, 1, 3), np.float32), d_frest=np.zeros((P, 15, 3), np.float32),
+                d_dir=np.zeros((P, 3), np.float32))
+    radii_in = (both * 1).astype(np.int32)
+    hostsim.L.ghrsim_project_backward2(ctypes.byref(a), ctypes.c_void_p(radii_in.ctypes.data),
+                                       ctypes.c_void_p(gacc.ctypes.data),
+                                       *[ctypes.c_void_p(outs[k].ctypes.data) for k in
+                                         ("d_means2D", "d_xyz", "d_ls", "d_rot", "d_op", "d_label", "d_conf", "d_fdc",
+                                          "d_frest", "d_dir")])
+    ref = dict(d_xyz=leaves["_xyz"].grad, d_ls=leaves["_scaling"].grad, d_rot=leaves["_rotation"].grad,
+               d_conf=leaves["conf"].grad[:, 0], d_fdc=leaves["_features_dc"].grad,
+               d_frest=leaves["_features_rest"].grad, d_dir=leaves["_dir"].grad)
+    for k, r in ref.items():
+        r = r.numpy()
+        got = outs[k].astype(np.float64)
+        scale = np.abs(r).max() + 1e-30
+        rowscale = np.abs(r.reshape(P, -1)).max(axis=1, keepdims=True).reshape((P,) + (1,) * (r.ndim - 1))
+        err = np.abs(got - r) / (rowscale + 1e-3 * scale)
+        assert np.quantile(err, 0.995) < 5e-3 and np.isfinite(got).all(), (k, np.quantile(err, 0.995), err.max())
