@@ -93,7 +93,8 @@ class LossArgs(ctypes.Structure):
     _fields_ = [("W", ctypes.c_int32), ("H", ctypes.c_int32)] + \
                [(n, ctypes.c_void_p) for n in ("image", "mask", "dir2d", "orient_conf", "gt_image", "gt_mask",
                                                "gt_orient_angle", "gt_orient_conf")] + \
-               [(n, ctypes.c_float) for n in ("w_l1", "w_ssim", "w_mask", "w_orient")]
+               [(n, ctypes.c_float) for n in ("w_l1", "w_ssim", "w_mask", "w_orient")] + \
+               [("unmasked_colours", ctypes.c_int32)]
 
 
 LOSS_SUMS = 1288  # GHR_LOSS_SUMS

@@ -455,7 +455,7 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
     hipStream_t s = (hipStream_t)stream;
     GHR_HIP(hipMemsetAsync(sums, 0, GHR_LOSS_SUMS * sizeof(float), s));
     ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
-                    l->gt_orient_angle, l->gt_orient_conf, maps, sums};
+                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
     hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, l->w_l1, l->w_ssim, l->w_mask,
@@ -476,7 +476,8 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
         return fail(GHR_E_INVALID, "ghr_loss_backward: w_orient != 0 needs the orientation inputs and d_dir2d / d_orient_conf");
     hipStream_t s = (hipStream_t)stream;
     ghr::LossBwdArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image,
-                       l->gt_mask, l->gt_orient_angle, l->gt_orient_conf, maps, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
+                       l->gt_mask, l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps,
+                       sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
                        grad_loss, l->w_l1, l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, d_image, d_mask, d_dir2d,
                        d_orient_conf, zero_plane_a, zero_plane_b};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);

@@ -58,6 +58,7 @@ struct LossArgs {
     const float* gt_mask;   // [2,H,W]; channel 1 masks the colour terms, channel 0 the orientation term
     const float* gt_angle;  // [1,H,W] orientation angle / pi in [0,1)
     const float* gt_oconf;  // [1,H,W] per-pixel weight of the orientation term
+    int mask_colours;       // 0: colour terms on the whole image (strand stage)
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
     float* sums;            // [GHR_LOSS_SLOTS][GHR_LOSS_TERMS] partial sums, zeroed by the caller; block b adds into
                             // slot b % SLOTS (one hot address would serialise ~73k atomics)
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
             const int gx = bx + lx - GHR_SSIM_R, gy = by + ly - GHR_SSIM_R;
             const bool in = i < GHR_L_EH * GHR_L_XS && lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const size_t p = in ? (size_t)gy * W + gx : 0;
-            vm[it] = in ? m[p] : 0.f;
+            vm[it] = in ? (a.mask_colours ? m[p] : 1.0f) : 0.f;
             vi[it] = in ? img[p] : 0.f;
             vg[it] = in ? gt[p] : 0.f;
         }
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
             a.maps[(0 * 3 + ch) * N + p] = d0;
             a.maps[(1 * 3 + ch) * N + p] = d1;
             a.maps[(2 * 3 + ch) * N + p] = d2;
-            sums[0] += fabsf(img[p] - gt[p]) * m[p];
+            sums[0] += fabsf(img[p] - gt[p]) * (a.mask_colours ? m[p] : 1.0f);
             if (ch < 2) sums[2] += fabsf(a.mask[ch * N + p] - a.gt_mask[ch * N + p]);
             if (orient) {  // the blocks of the third colour channel also carry the orientation term
                 const float w = a.gt_oconf[p];
@@ -273,6 +274,7 @@ struct LossBwdArgs {
     const float* gt_mask;
     const float* gt_angle;
     const float* gt_oconf;
+    int mask_colours;
     const float* maps;
     const float* aux;        // {sum of orientation weights, orientation-term-is-NaN flag} from k_loss_finalize
     const float* grad_loss;  // device scalar dL/dloss (may be null => 1)
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
         const int gy = by + 2 * tr + o;
         if (!(gx < W && gy < H)) continue;
         const size_t p = (size_t)gy * W + gx;
-        const float mm = a.gt_mask[N + p];
+        const float mm = a.mask_colours ? a.gt_mask[N + p] : 1.0f;
         const float im = a.image[ch * N + p], g = a.gt_image[ch * N + p];
         const float x = im * mm, y = g * mm;
         // d(mean ssim)/dx(p), then Lssim = 1 - mean  and x = image * m

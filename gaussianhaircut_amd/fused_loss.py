@@ -20,7 +20,7 @@ def _f32c(t):
     return t.detach().float().contiguous()
 
 
-def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf, w):
+def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf, w, unmasked=False):
     a = _lib.LossArgs()
     a.W, a.H = int(W), int(H)
     a.image, a.mask, a.dir2d, a.orient_conf = image, mask, dir2d, oconf
@@ -28,6 +28,7 @@ def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf
     a.gt_orient_angle = _ptr(gt_angle) if gt_angle is not None else None
     a.gt_orient_conf = _ptr(gt_oconf) if gt_oconf is not None else None
     a.w_l1, a.w_ssim, a.w_mask, a.w_orient = [float(x) for x in w]
+    a.unmasked_colours = int(bool(unmasked))
     return a
 
 
@@ -36,7 +37,7 @@ class _Stage1LossPacked(torch.autograd.Function):
     (no split / cat / zero-fill kernels between the loss and the rasterizer backward)."""
 
     @staticmethod
-    def forward(ctx, renders, gt_image, gt_mask, gt_angle, gt_oconf, w_l1, w_ssim, w_mask, w_orient):
+    def forward(ctx, renders, gt_image, gt_mask, gt_angle, gt_oconf, w_l1, w_ssim, w_mask, w_orient, unmasked=False):
         assert renders.is_cuda, "fused loss has no CPU path"
         C, H, W = renders.shape
         assert C == _lib.NUM_CHANNELS
@@ -52,11 +53,12 @@ class _Stage1LossPacked(torch.autograd.Function):
             sums = torch.empty(_lib.LOSS_SUMS, dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             a = _args(W, H, _off(r, 0, n), _off(r, 3, n), _off(r, 5, n), _off(r, 8, n), gt_image_c, gt_mask_c,
-                      gt_angle_c, gt_oconf_c, (w_l1, w_ssim, w_mask, w_orient if orient else 0.0))
+                      gt_angle_c, gt_oconf_c, (w_l1, w_ssim, w_mask, w_orient if orient else 0.0), unmasked)
             _lib.check(_lib.lib().ghr_loss_forward(_stream(), ctypes.byref(a), _ptr(maps), _ptr(sums),
                                                    ctypes.c_void_p(loss.data_ptr())))
         ctx.save_for_backward(r, gt_image_c, gt_mask_c, maps, sums, *([gt_angle_c, gt_oconf_c] if orient else []))
         ctx.w = (w_l1, w_ssim, w_mask, w_orient if orient else 0.0)
+        ctx.unmasked = bool(unmasked)
         return loss
 
     @staticmethod
@@ -70,11 +72,11 @@ class _Stage1LossPacked(torch.autograd.Function):
             d = torch.empty_like(r)
             gl = _f32c(grad_loss)
             a = _args(W, H, _off(r, 0, n), _off(r, 3, n), _off(r, 5, n), _off(r, 8, n), gt_image, gt_mask, gt_angle,
-                      gt_oconf, ctx.w)
+                      gt_oconf, ctx.w, ctx.unmasked)
             _lib.check(_lib.lib().ghr_loss_backward(_stream(), ctypes.byref(a), _ptr(maps), _ptr(sums),
                                                     ctypes.c_void_p(gl.data_ptr()), _off(d, 0, n), _off(d, 3, n),
                                                     _off(d, 5, n), _off(d, 8, n), _off(d, 7, n), _off(d, 9, n)))
-        return d, None, None, None, None, None, None, None, None
+        return d, None, None, None, None, None, None, None, None, None
 
 
 class _PhotometricLoss(torch.autograd.Function):
@@ -118,10 +120,12 @@ def photometric_loss(image, mask, gt_image, gt_mask, w_l1, w_ssim, w_mask):
     return _PhotometricLoss.apply(image, mask, gt_image, gt_mask, float(w_l1), float(w_ssim), float(w_mask))
 
 
-def stage1_loss(renders, gt_image, gt_mask, gt_orient_angle, gt_orient_conf, w_l1, w_ssim, w_mask, w_orient):
+def stage1_loss(renders, gt_image, gt_mask, gt_orient_angle, gt_orient_conf, w_l1, w_ssim, w_mask, w_orient,
+                mask_colours=True):
     """The whole loss of src/train_gaussians.py:126-140 on the packed [10,H,W] rasterizer output ``renders``
     (channels: rgb 0-2, mask 3-4, 2D direction 5-6, orientation confidence 8):
     photometric terms + ``w_orient * or_loss(orient_angle, gt_orient_angle, orient_conf, weight=gt_orient_conf,
-    mask=gt_mask[:1])`` with a NaN orientation term dropped."""
+    mask=gt_mask[:1])`` with a NaN orientation term dropped.  ``mask_colours=False``: L1 / SSIM on the whole image, the
+    strand-stage form (src/train_strands.py:128-129)."""
     return _Stage1LossPacked.apply(renders, gt_image, gt_mask, gt_orient_angle, gt_orient_conf, float(w_l1),
-                                   float(w_ssim), float(w_mask), float(w_orient))
+                                   float(w_ssim), float(w_mask), float(w_orient), not mask_colours)

@@ -21,8 +21,9 @@ class GaussianModelStrands(GaussianModel):
         super().__init__(sh_degree)
         self.scale = scale
 
-    def create_from_strands(self, origins, dirs, features, orient_conf_log=None):
+    def create_from_strands(self, origins, dirs, features, orient_conf_log=None, spatial_lr_scale: float = 1.0):
         """origins: (S,1,3) roots, dirs: (S,n_seg,3) segment vectors, features: (S*n_seg, K, 3)."""
+        self.spatial_lr_scale = spatial_lr_scale
         self.pts_origins = origins.detach().clone().float()
         self._dirs = nn.Parameter(dirs.detach().clone().float().requires_grad_(True))
         P = dirs.shape[0] * dirs.shape[1]
@@ -79,7 +80,8 @@ class GaussianModelStrands(GaussianModel):
     def param_groups(self, training_args):
         """gaussian_model_strands.py:578-589 (directions, SH, orientation confidence)."""
         return [
-            {'params': [self._dirs], 'lr': training_args.position_lr_init * max(self.spatial_lr_scale, 1.0), "name": "dirs"},
+            # the reference names the strand-direction group "xyz" so that update_learning_rate() schedules it (:582,:596-602)
+            {'params': [self._dirs], 'lr': training_args.position_lr_init * self.spatial_lr_scale, "name": "xyz"},
             {'params': [self._features_dc], 'lr': training_args.feature_lr, "name": "f_dc"},
             {'params': [self._features_rest], 'lr': training_args.feature_lr / 20.0, "name": "f_rest"},
             {'params': [self._orient_conf], 'lr': training_args.orient_conf_lr, "name": "orient_conf"},

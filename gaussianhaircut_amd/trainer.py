@@ -110,6 +110,60 @@ def densification_step(gaussians, render_pkg, opt, iteration: int, cameras_exten
     return changed
 
 
+def strand_view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
+    """The strand-stage loss (src/train_strands.py:121-147 without the diffusion-prior term, whose networks are out of
+    scope): L1 and SSIM on the WHOLE image, mask L1, orientation loss weighted by the ground-truth confidence."""
+    image, mask = render_pkg["render"], render_pkg["mask"]
+    gt_image, gt_mask = cam.original_image, cam.original_mask
+    if fused is None:
+        fused = image.is_cuda
+    if fused and getattr(render_pkg, "renders_packed", None) is not None and opt.train_orient_conf:
+        from .fused_loss import stage1_loss
+        w_conf = cam.original_orient_conf if opt.use_gt_orient_conf else torch.ones_like(gt_mask[:1])
+        return stage1_loss(render_pkg.renders_packed, gt_image, gt_mask, cam.original_orient_angle, w_conf,
+                           opt.lambda_dl1 * scale, opt.lambda_dssim * scale, opt.lambda_dmask * scale,
+                           opt.lambda_dorient * scale, mask_colours=False)
+    loss = l1_loss(image, gt_image) * opt.lambda_dl1 + (1.0 - ssim(image, gt_image)) * opt.lambda_dssim + \
+        l1_loss(mask, gt_mask) * opt.lambda_dmask
+    if opt.lambda_dorient != 0.0:
+        w = torch.ones_like(gt_mask[:1])
+        if opt.use_gt_orient_conf:
+            w = w * cam.original_orient_conf
+        conf = render_pkg["orient_conf"] if opt.train_orient_conf else None
+        Lorient = or_loss(render_pkg["orient_angle"], cam.original_orient_angle, conf, weight=w, mask=gt_mask[:1])
+        Lorient = torch.where(torch.isnan(Lorient), torch.zeros_like(Lorient), Lorient)
+        loss = loss + Lorient * opt.lambda_dorient
+    return loss * scale if scale != 1.0 else loss
+
+
+def strand_training_step(gaussians, gaussians_hair, cams: List, background, opt, iteration: int, pipe=PIPE):
+    """One iteration of the strand stage (src/train_strands.py:98-160): rebuild the strand Gaussians from the strand
+    parameters, render head + hair, loss, backward, NaN guard on the strand parameters, Adam."""
+    from .gaussian_renderer import render_hair
+    gaussians_hair.initialize_gaussians_hair()
+    gaussians_hair.update_learning_rate(iteration)
+    V = len(cams)
+    losses = []
+    for cam in cams:
+        pkg = render_hair(cam, gaussians, gaussians_hair, pipe, background)
+        loss = strand_view_loss(pkg, cam, opt, scale=1.0 / V)
+        loss.backward()
+        losses.append(loss.detach())
+        if cam is not cams[-1]:
+            gaussians_hair.initialize_gaussians_hair()  # a fresh graph for the next view
+    from .optim import FusedAdam
+    if isinstance(gaussians_hair.optimizer, FusedAdam):
+        gaussians_hair.optimizer.step(zero_grad=True)  # device-side NaN guard over every strand parameter
+    else:
+        ps = [gaussians_hair._dirs, gaussians_hair._features_dc, gaussians_hair._features_rest]
+        if any(p.grad is not None and bool(p.grad.isnan().any()) for p in ps):  # train_strands.py:151-155
+            gaussians_hair.optimizer.zero_grad(set_to_none=True)
+            print('NaN during backprop was found, skipping iteration...')
+        gaussians_hair.optimizer.step()
+        gaussians_hair.optimizer.zero_grad()
+    return losses[0] if len(losses) == 1 else torch.stack(losses).sum()
+
+
 def _world_size() -> int:
     import torch.distributed as dist
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1

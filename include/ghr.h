@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 5
+#define GHR_ABI_VERSION 6
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -202,6 +202,7 @@ typedef struct ghr_loss_args {
     const float* gt_orient_angle;
     const float* gt_orient_conf;
     float w_l1, w_ssim, w_mask, w_orient;
+    int32_t unmasked_colours;     /* != 0: L1 / SSIM on the whole image (train_strands.py:128-129) instead of * gt_mask[1] */
 } ghr_loss_args;
 /* maps: 9*H*W floats of scratch kept for backward.  sums: GHR_LOSS_SUMS device floats of scratch kept for backward.
  * loss_out: device scalar. */

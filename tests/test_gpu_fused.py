@@ -288,3 +288,34 @@ def test_fused_render_hair_matches_generic_path():
         rows = np.abs(b).max(axis=1, keepdims=True)
         e = np.abs(a - b) / (rows + 1e-3 * scale)
         assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())
+
+
+def test_strand_training_step_learns_on_gpu():
+    """trainer.strand_training_step (src/train_strands.py:98-160): fused render_hair + fused strand-stage loss + Adam on
+    the strand parameters; the loss towards a perturbed copy of the strands goes down, for both optimizers."""
+    from gaussianhaircut_amd.gaussian_renderer import render_hair
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import strand_training_step
+    from tests.test_api_cpu import _hair_scene
+    dev = torch.device("cuda:0")
+    opt = OptimizationParams()
+    opt.lambda_dorient, opt.lambda_dmask = 0.1, 0.1          # run.sh:177
+    bg = syn.background(dev)
+    for fused_adam in (True, False):
+        spec, head, hair, cam = _hair_scene(dev)
+        _, _, gt_hair, _ = _hair_scene(dev)
+        with torch.no_grad():
+            gt_hair._features_dc.add_(0.4)
+            gt_hair._dirs.mul_(1.1)
+            gt_hair.initialize_gaussians_hair()
+            pkg = render_hair(cam, head, gt_hair, FUSED, bg)
+            cam.original_image = pkg["render"].clamp(0, 1).detach()
+            cam.original_mask = pkg["mask"].clamp(0, 1).detach()
+            cam.original_orient_angle = pkg["orient_angle"].detach()
+            cam.original_orient_conf = torch.ones_like(pkg["orient_conf"]).detach()
+        hair.training_setup(opt, fused=fused_adam)
+        assert [g["name"] for g in hair.optimizer.param_groups] == ["xyz", "f_dc", "f_rest", "orient_conf"]
+        d0 = hair._dirs.detach().clone()
+        losses = [float(strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=FUSED)) for i in range(10)]
+        assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+        assert (hair._dirs.detach() - d0).abs().max() > 0

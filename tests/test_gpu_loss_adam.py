@@ -140,3 +140,34 @@ def test_fused_stage1_loss_nan_orientation_is_dropped():
     assert torch.isfinite(lf) and abs(float(lf.detach()) - float(lt.detach())) < 5e-6
     lf.backward()
     assert torch.isfinite(a.grad).all() and float(a.grad[5:].abs().max()) == 0.0
+
+
+def test_fused_strand_stage_loss_unmasked_colours_matches_torch():
+    """mask_colours=False: L1 / SSIM over the whole image (src/train_strands.py:128-129) + mask L1 + orientation."""
+    from gaussianhaircut_amd.fused_loss import stage1_loss
+    from gaussianhaircut_amd.gaussian_renderer import orient_angle_from
+    dev = torch.device("cuda:0")
+    H, W = 70, 96
+    g = torch.Generator().manual_seed(77)
+    base = torch.rand(3, H // 4 + 2, W // 4 + 2, generator=g)
+    gt = torch.nn.functional.interpolate(base[None], size=(H, W), mode="bilinear")[0]
+    r = torch.rand(10, H, W, generator=g)
+    r[0:3] = (gt + 0.1 * torch.randn(3, H, W, generator=g)).clamp(0, 1)
+    r[5:8] = torch.randn(3, H, W, generator=g) * 0.3
+    r[8] = torch.rand(H, W, generator=g) + 0.1
+    gt_mask = (torch.rand(2, H, W, generator=g) > 0.4).float()
+    gt_angle, gt_oconf = torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    w = (0.8, 0.2, 0.1, 0.1)
+    a = r.to(dev).requires_grad_(True)
+    b = r.to(dev).requires_grad_(True)
+    c = [t.to(dev) for t in (gt, gt_mask, gt_angle, gt_oconf)]
+    lf = stage1_loss(a, *c, *w, mask_colours=False)
+    image, mask, cov2d, oconf, _ = b.split([3, 2, 3, 1, 1], dim=0)
+    lo = lu.or_loss(orient_angle_from(cov2d), c[2], oconf, weight=torch.ones_like(c[1][:1]) * c[3], mask=c[1][:1])
+    lt = w[0] * lu.l1_loss(image, c[0]) + w[1] * (1.0 - lu.ssim(image, c[0])) + w[2] * lu.l1_loss(mask, c[1]) + w[3] * lo
+    assert abs(float(lf.detach()) - float(lt.detach())) < 5e-6 * max(1.0, abs(float(lt.detach())))
+    lf.backward()
+    lt.backward()
+    x, y = a.grad.cpu().numpy(), b.grad.cpu().numpy()
+    for lo_, hi_ in ((0, 3), (3, 5)):
+        assert np.abs(x[lo_:hi_] - y[lo_:hi_]).max() <= 2e-4 * np.abs(y[lo_:hi_]).max()
