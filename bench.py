@@ -239,13 +239,18 @@ def cpu_baseline(spec, model, cam):
     from tests import helpers as hp
     cpu_model_inputs = syn.raster_inputs(spec, "cpu")
     dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
-    t0 = time.perf_counter()
-    out_o, radii_o, st = hp.oracle_forward(oracle, cpu_model_inputs, "A")
-    t1 = time.perf_counter()
-    hp.oracle_backward(oracle, st, cpu_model_inputs, dL, "A")
-    t2 = time.perf_counter()
+    best = None
+    for _ in range(3):  # bounded sample: three passes over one view (~1 s each on a 128-core host), best pass reported
+        t0 = time.perf_counter()
+        out_o, radii_o, st = hp.oracle_forward(oracle, cpu_model_inputs, "A")
+        t1 = time.perf_counter()
+        hp.oracle_backward(oracle, st, cpu_model_inputs, dL, "A")
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[2] - best[0]:
+            best = (t0, t1, t2)
+    t0, t1, t2 = best
     return {"value": round(spec.P / (t2 - t0), 1), "unit": "Gaussians/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "1 view of %s, rasterizer fwd (%.2f s) + bwd (%.2f s) only; projection/loss/Adam not included" %
+            "sample": "1 view of %s, best of 3 passes, rasterizer fwd (%.2f s) + bwd (%.2f s) only; projection/loss/Adam not included" %
                       (spec.name, t1 - t0, t2 - t1)}
 
 

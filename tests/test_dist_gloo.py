@@ -93,3 +93,40 @@ def test_flat_bucket_aliases_grads():
     assert model._xyz.grad.data_ptr() == b.flat.data_ptr()
     b.zero()
     assert model._xyz.grad.abs().sum() == 0
+
+
+def _densify_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gaussianhaircut_amd.parallel import all_reduce_densification_stats
+    opt = OptimizationParams()
+    model = syn.make_model(SPEC)
+    model.training_setup(opt)
+    # every rank saw different views: different local statistics
+    g = torch.Generator().manual_seed(100 + rank)
+    model.xyz_gradient_accum = torch.rand(SPEC.P, 1, generator=g) * 6e-4
+    model.denom = torch.randint(0, 3, (SPEC.P, 1), generator=g).float()
+    model.max_radii2D = torch.rand(SPEC.P, generator=g) * 30
+    all_reduce_densification_stats(model.xyz_gradient_accum, model.denom, model.max_radii2D)
+    model.densify_and_prune(opt.densify_grad_threshold, 0.005, 2.5, 20, generator=torch.Generator().manual_seed(7))
+    q.put((rank, model.get_xyz.shape[0], param_checksum(model.leaf_parameters())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_densification_keeps_replicas_identical():
+    """densify / prune under data parallelism -- all-reduced statistics (SUM, SUM, MAX) and a shared
+    generator seed for the split samples give bit-identical replicas."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_densify_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=250) for _ in range(2)])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] != SPEC.P and res[0][2] == res[1][2]
