@@ -207,19 +207,30 @@ def main():
 
 
 def op_only_bench(dev, cfg="cfg2", iters=20, warm=5):
-    """Rasterizer op alone (C ABI, no autograd): BASELINE.json configs[1], Gaussians / (t_fwd + t_bwd)."""
+    """Rasterizer op alone -- the product's GaussianRasterizer autograd op (mode A: conic + colours precomputed, what
+    render() hands it), forward and backward: BASELINE.json configs[1], Gaussians / (t_fwd + t_bwd)."""
+    from gaussianhaircut_amd import diff_gaussian_rasterization as dgr
     from gaussianhaircut_amd.utils import synthetic as syn
-    from tests.gpu_helpers import GpuRun, to_dev
     spec = syn.CONFIGS[cfg]
-    ri = to_dev(syn.raster_inputs(spec), dev)
-    dL = syn.grad_image(spec, 101, dev) * (spec.H * spec.W)
+    ri = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in syn.raster_inputs(spec).items()}
+    dL = (syn.grad_image(spec, 101) * (spec.H * spec.W)).to(dev).contiguous()
+    rs = dgr.GaussianRasterizationSettings(image_height=spec.H, image_width=spec.W, tanfovx=ri["tanfovx"],
+                                           tanfovy=ri["tanfovy"], bg=ri["bg"], scale_modifier=1.0,
+                                           viewmatrix=ri["viewmatrix"], projmatrix=ri["projmatrix"], sh_degree=3,
+                                           campos=ri["campos"], prefiltered=True, debug=False)
+    rast = dgr.GaussianRasterizer(rs)
+    leaves = {k: ri[k].clone().requires_grad_(True) for k in ("means3D", "means2D", "colors", "opacities", "conic")}
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     tf, tb = [], []
     for i in range(iters + warm):
+        for t in leaves.values():
+            t.grad = None
         e[0].record()
-        run = GpuRun(ri, "A", debug=False)
+        color, radii = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], shs=None,
+                            colors_precomp=leaves["colors"], opacities=leaves["opacities"], cov3D_precomp=ri["cov3D"],
+                            conic_precomp=leaves["conic"])
         e[1].record()
-        run.backward(dL)
+        torch.autograd.backward(color, grad_tensors=dL)
         e[2].record()
         torch.cuda.synchronize()
         if i >= warm:
@@ -227,9 +238,9 @@ def op_only_bench(dev, cfg="cfg2", iters=20, warm=5):
             tb.append(e[1].elapsed_time(e[2]))
     tf.sort(), tb.sort()
     mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
-    return {"workload": spec.name, "P": ri["P"], "num_rendered": run.R, "fwd_ms": round(mf, 4), "bwd_ms": round(mb, 4),
-            "gaussians_per_sec_fwd_bwd": round(ri["P"] / ((mf + mb) * 1e-3), 1),
-            "note": "includes workspace allocation + the host sync on num_rendered in forward"}
+    return {"workload": spec.name, "P": ri["P"], "num_rendered": dgr.LAST_STATS["num_rendered"], "fwd_ms": round(mf, 4),
+            "bwd_ms": round(mb, 4), "gaussians_per_sec_fwd_bwd": round(ri["P"] / ((mf + mb) * 1e-3), 1),
+            "note": "GaussianRasterizer op (autograd, workspace allocation and the num_rendered read included)"}
 
 
 def cpu_baseline(spec, model, cam):
