@@ -147,7 +147,8 @@ def _use_fused_hair(pc, pc_hair, pipe) -> bool:
     ``GaussianModelStrands`` on a ROCm device (anything else takes the generic path)."""
     from ..scene.gaussian_model import GaussianModel
     from ..scene.gaussian_model_strands import GaussianModelStrands
-    return (type(pc) is GaussianModel and type(pc_hair) is GaussianModelStrands and
+    from ..scene.gaussian_model_latent_strands import GaussianModelLatentStrands
+    return (type(pc) is GaussianModel and type(pc_hair) in (GaussianModelStrands, GaussianModelLatentStrands) and
             getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view"))
 
 
