@@ -257,49 +257,83 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         }
         __syncthreads();  // also orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
 
-        for (uint32_t sub = 0; sub < cnt; sub += 64) {
-            // per-GROUP ordered list (64-bit mask) of the entries whose alpha >= 1/255 region touches the group's cell
-            const uint32_t e = sub + lane;
-            const uint32_t ec = e < cnt ? e : 0;
-            unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
-            // entry j sits at list position n_eff-1-(base+j); positions >= gmax are dead for this cell
-            const long long jmin = (long long)n_eff - (long long)gmax - (long long)(base + sub);
-            if (jmin > 0) todo = jmin >= 64 ? 0ull : (todo & (~0ull << jmin));
-
-            // Entries that ALL FOUR cells of the strip visit (a splat covering the strip) are walked by the whole wave
+        // per-GROUP ordered lists (one 64-bit mask per 64 entries) of the batch entries whose alpha >= 1/255 region
+        // touches the group's cell, and -- wave-uniform -- the entries that ALL FOUR cells of the strip visit
+        unsigned long long todo[4], common[4];
+        int n_common = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t sub = 64u * k;
+            todo[k] = 0ull;
+            common[k] = 0ull;
+            if (sub < cnt) {  // wave-uniform
+                const uint32_t e = sub + lane;
+                const uint32_t ec = e < cnt ? e : 0;
+                unsigned long long m_ = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
+                // entry j sits at list position n_eff-1-(base+j); positions >= gmax are dead for this cell
+                const long long jmin = (long long)n_eff - (long long)gmax - (long long)(base + sub);
+                if (jmin > 0) m_ = jmin >= 64 ? 0ull : (m_ & (~0ull << jmin));
+                todo[k] = m_;
+                common[k] = rowmask(m_, 0) & rowmask(m_, 16) & rowmask(m_, 32) & rowmask(m_, 48);
+                n_common += __builtin_popcountll(common[k]);
+            }
+        }
+        auto cell_pass = [&](uint32_t j) {  // one entry, one cell (16 lanes)
+            const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
+            float g[16];
+            bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
+            const float v = row_reduce16(g, l);
+            // lane l adds component l of the cell's total: 16 lanes -> one 64-B line, resolved in this XCD's L2
+            __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + l, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        if (n_common < 8) {
+            // Needle lists (the common case for strands): every cell walks ITS list over the whole batch without
+            // waiting for the other three at the 64-entry boundaries (measured on cfg3: 12 % fewer wave passes than
+            // re-synchronising per 64 entries).  Divergent per GROUP: the 16 lanes of a DPP row share k / cur.
+            int k = 0;
+            unsigned long long cur = todo[0];
+            for (;;) {
+                while (cur == 0ull && k < 3) {
+                    k++;
+                    cur = k == 1 ? todo[1] : (k == 2 ? todo[2] : todo[3]);
+                }
+                if (cur == 0ull) break;
+                const uint32_t j = 64u * k + (uint32_t)__builtin_ctzll(cur);
+                cur &= cur - 1;
+                cell_pass(j);
+            }
+        } else {
+            // Entries that all four cells of the strip visit (a splat covering the strip) are walked by the whole wave
             // at once -- scalar loop, broadcast LDS reads, one 64-lane reduction and ONE line of atomics instead of
             // four on the same line (which serialise in L2: measured 38 % of the kernel on isotropic blobs).  The
             // per-pixel order is preserved: between two common entries every cell first finishes its private entries.
-            unsigned long long common = rowmask(todo, 0) & rowmask(todo, 16) & rowmask(todo, 32) & rowmask(todo, 48);
-            if (__builtin_popcountll(common) < 4) common = 0ull;  // needle lists: stay in pure cell mode
-            unsigned long long rest = todo & ~common;
-            for (;;) {
-                const int nc = common ? __builtin_ctzll(common) : 64;  // next common entry (wave-uniform)
-                unsigned long long mine = nc < 64 ? (rest & ((1ull << nc) - 1ull)) : rest;
-                rest &= ~mine;
-                while (mine) {  // divergent per GROUP (all 16 lanes of a DPP row share `mine`)
-                    const uint32_t j = sub + (uint32_t)__builtin_ctzll(mine);
-                    mine &= mine - 1;
-                    const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t sub = 64u * k;
+                unsigned long long cm = common[k], rest = todo[k] & ~cm;
+                for (;;) {
+                    const int nc = cm ? __builtin_ctzll(cm) : 64;  // next common entry (wave-uniform)
+                    unsigned long long mine = nc < 64 ? (rest & ((1ull << nc) - 1ull)) : rest;
+                    rest &= ~mine;
+                    while (mine) {  // divergent per GROUP
+                        const uint32_t j = sub + (uint32_t)__builtin_ctzll(mine);
+                        mine &= mine - 1;
+                        cell_pass(j);
+                    }
+                    if (nc == 64) break;
+                    cm &= cm - 1;
+                    const uint32_t j = sub + (uint32_t)nc;  // wave-uniform
+                    const uint32_t pos = n_eff - 1 - (base + j);
                     float g[16];
-                    bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx,
-                             ddely_dy, g);
-                    const float v = row_reduce16(g, l);
-                    // lane l adds component l of the cell's total: 16 lanes -> one 64-B line, resolved in this XCD's L2
-                    __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + l, v, __ATOMIC_RELAXED,
-                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy,
+                             g);
+                    const float v = wave_reduce16(g, lane);
+                    if ((lane & 3) == 0)
+                        __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] +
+                                                   (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 +
+                                                    ((lane >> 2) & 1)),
+                                               v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
-                if (nc == 64) break;
-                common &= common - 1;
-                const uint32_t j = sub + (uint32_t)nc;  // wave-uniform
-                const uint32_t pos = n_eff - 1 - (base + j);
-                float g[16];
-                bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
-                const float v = wave_reduce16(g, lane);
-                if ((lane & 3) == 0)
-                    __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + (((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 +
-                                                                            ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)),
-                                           v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     }
