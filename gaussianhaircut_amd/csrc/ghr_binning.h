@@ -32,24 +32,35 @@ __device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* ds
     const int b = tid * per, e = min(n, b + per);
     uint32_t sum = 0;
     for (int i = b; i < e; i++) sum += src[i];
-    __syncthreads();  // s_part may still be read by a previous call
-    s_part[tid] = sum;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over the 1024 partials
-    for (int off = 1; off < GHR_SCAN_BLOCK; off <<= 1) {
-        uint32_t v = (tid >= off) ? s_part[tid - off] : 0u;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
+    // inclusive scan of the 1024 partials: shuffles inside each of the 16 wavefronts, then the 16 wave totals
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += v;
     }
-    uint32_t run = s_part[tid] - sum;  // exclusive prefix of this thread's chunk
+    __syncthreads();  // s_part may still be read by a previous call
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        uint32_t w = lane < GHR_SCAN_BLOCK / 64 ? s_part[lane] : 0u;
+#pragma unroll
+        for (int off = 1; off < GHR_SCAN_BLOCK / 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)w, off);
+            if (lane >= off) w += v;
+        }
+        if (lane < GHR_SCAN_BLOCK / 64) s_part[64 + lane] = w;  // inclusive prefix of the wave totals
+    }
+    __syncthreads();
+    uint32_t run = incl - sum + (wave ? s_part[64 + wave - 1] : 0u);  // exclusive prefix of this thread's chunk
     for (int i = b; i < e; i++) {
         const uint32_t c = src[i];
         if (zero_src) src[i] = 0u;
         dst[i] = run;
         run += c;
     }
-    return s_part[GHR_SCAN_BLOCK - 1];
+    return s_part[64 + GHR_SCAN_BLOCK / 64 - 1];
 }
 #endif
 
