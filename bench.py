@@ -94,7 +94,7 @@ def main():
 
     # ---- HIP events around the two render kernels, recorded by the library on the launch stream -------------------
     K, Wm = args.steps, args.warmup
-    n_ev = K * V
+    n_ev = K  # the last view of every timed step carries the events (its instance count is the one reported)
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
     for quad in evs:
         for e in quad:
@@ -105,14 +105,21 @@ def main():
     from gaussianhaircut_amd import trainer as _tr
     from gaussianhaircut_amd.gaussian_renderer import render as _render
 
+    view_i = [0]
+
     def render_with_events(cam, pc, pipe, bgc, scaling_modifier=1.0):
-        q = evs[ev_i[0] % n_ev]
-        ev_i[0] += 1
-        L.ghr_set_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in q])
+        view_i[0] += 1
+        if view_i[0] == V:
+            q = evs[ev_i[0] % n_ev]
+            ev_i[0] += 1
+            L.ghr_set_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in q])
+        elif view_i[0] == 1:
+            L.ghr_set_profile_events(None, None, None, None)
         return _render(cam, pc, pipe, bgc, scaling_modifier)
 
     def step(it, timed):
         _tr.render = render_with_events if timed else _render
+        view_i[0] = 0
         if not timed:
             L.ghr_set_profile_events(None, None, None, None)
         return training_step(model, cams, bg, opt, it, bucket=bucket, global_views=global_views)

@@ -68,7 +68,8 @@ __device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* ds
 // append cursor; publishes R = tile_start[T]) and, in place, slot_blk[nblk] -> exclusive prefix of the gradient slots
 // used by the K1 workgroups.
 __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
-                                                              uint32_t* R_out, uint32_t* slot_blk, int nblk)
+                                                              uint32_t* R_out, uint32_t* slot_blk, int nblk,
+                                                              uint32_t* R_mapped)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
@@ -76,6 +77,9 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
     if (threadIdx.x == 0) {
         tile_start[T] = total;
         *R_out = total;
+        // the host's copy of the count, stored straight into its pinned (device-mapped) word: visible to the host
+        // when the kernel retires, without a separate 4-byte copy command between this kernel and k_scatter
+        if (R_mapped) *R_mapped = total;
     }
     scan_1024(nblk, slot_blk, slot_blk, false, s_part);
 #endif

@@ -37,6 +37,18 @@ int fail(int code, const char* fmt, const char* detail = "")
         if (e_ != hipSuccess) return fail(GHR_E_HIP, #expr ": %s", hipGetErrorString(e_)); \
     } while (0)
 
+// Device-visible alias of the host word that receives num_rendered, when that word lives in pinned (hipHostMalloc /
+// hipHostRegister) memory; nullptr for pageable memory, which then gets a stream-ordered 4-byte copy instead.
+uint32_t* mapped_word(uint32_t* host)
+{
+    void* dev = nullptr;
+    if (hipHostGetDevicePointer(&dev, host, 0) != hipSuccess) {
+        (void)hipGetLastError();  // not an error for the caller: fall back to the copy
+        return nullptr;
+    }
+    return (uint32_t*)dev;
+}
+
 constexpr size_t ALIGN = 256;
 inline size_t up(size_t x) { return (x + ALIGN - 1) / ALIGN * ALIGN; }
 
@@ -177,9 +189,10 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     pa.rec = g.rec; pa.depths = g.depths; pa.rects = g.rects; pa.cov3D = g.cov3D; pa.radii = radii;
     pa.tile_count = im.tile_count; pa.slot_blk = g.slot_blk;
     hipLaunchKernelGGL(ghr::k_preprocess, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, pa);
+    uint32_t* R_mapped = mapped_word(R_host);
     hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
-                       g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK);
-    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                       g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK, R_mapped);
+    if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, a->debug);
 }
 
@@ -336,9 +349,10 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
     Geom g; Img im;
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
+    uint32_t* R_mapped = mapped_word(R_host);
     hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
-                       g.slot_blk, n_blocks(rows_total));
-    GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                       g.slot_blk, n_blocks(rows_total), R_mapped);
+    if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, debug);
 }
 

@@ -196,6 +196,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.bin_cap = bin_cap  # layout of binningBuffer
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         # same tuple as the reference (__init__.py:102); tensors are the contiguous fp32 versions the kernels read
         ctx.save_for_backward(colors_c if colors_c is not None else torch.empty(0), means3D_c,
                               scales_c if scales_c is not None else torch.empty(0),
@@ -214,6 +215,9 @@ class _RasterizeGaussians(torch.autograd.Function):
          binningBuffer, imgBuffer, opacities, bg, view, proj) = ctx.saved_tensors
         L = _lib.lib()
         P = means3D.size(0)
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((NUM_CHANNELS, int(rs.image_height), int(rs.image_width)),
+                                         dtype=torch.float32, device=means3D.device)
         dev = means3D.device
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

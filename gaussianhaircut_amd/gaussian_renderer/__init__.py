@@ -21,7 +21,19 @@ from ..utils.sh_utils import eval_sh
 
 
 def _tan_half(fov) -> float:
-    return math.tan(float(fov) * 0.5)
+    """tan(FoV/2) as a host float (the reference's ``torch.tan(FoV * 0.5).item()``).  A device-resident FoV tensor costs
+    a blocking D2H read that drains the launch queue, so the value is remembered on the tensor object and re-read only
+    when the tensor was written since (its autograd version counter moves with every in-place update)."""
+    if not isinstance(fov, torch.Tensor):
+        return math.tan(float(fov) * 0.5)
+    cached = getattr(fov, "_ghr_tan_half", None)
+    if cached is None or cached[0] != fov._version:
+        cached = (fov._version, math.tan(float(fov) * 0.5))
+        try:
+            fov._ghr_tan_half = cached
+        except AttributeError:
+            pass
+    return cached[1]
 
 
 def _raster_settings(cam, bg_color, scaling_modifier, sh_degree, debug):

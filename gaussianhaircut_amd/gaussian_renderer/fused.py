@@ -12,6 +12,7 @@ import ctypes
 import torch
 
 from .. import _lib
+from . import _tan_half
 from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
 
 
@@ -69,6 +70,7 @@ class _RenderModelFused(torch.autograd.Function):
         # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         ctx.save_for_backward(*params, view, proj, campos, bg, radii, geom, img, binb)
         return color, radii
 
@@ -77,6 +79,8 @@ class _RenderModelFused(torch.autograd.Function):
         L = _lib.lib()
         cfg, R, K = ctx.cfg, ctx.R, ctx.K
         *params, view, proj, campos, bg, radii, geom, img, binb = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros((NUM_CHANNELS, cfg["H"], cfg["W"]), dtype=torch.float32, device=radii.device)
         xyz = params[0]
         dev, P = xyz.device, xyz.shape[0]
         f32 = dict(dtype=torch.float32, device=dev)
@@ -126,7 +130,7 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
     cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
                proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
-               tanfovx=math.tan(float(cam.FoVx) * 0.5), tanfovy=math.tan(float(cam.FoVy) * 0.5),
+               tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
                conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug))
     from ..optim import FusedAdam
     opt = getattr(pc, "optimizer", None)
@@ -211,6 +215,7 @@ class _RenderHairFused(torch.autograd.Function):
         LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(rows)
         ctx.cfg, ctx.R, ctx.K, ctx.cap, ctx.dims = cfg, R, K, cap, (n_head, n_hair, row0, rows)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t,
                               radii_ws, geom, img, binb)
         return color, radii
@@ -224,6 +229,8 @@ class _RenderHairFused(torch.autograd.Function):
         dev = xyz.device
         f32 = dict(dtype=torch.float32, device=dev)
         W, H = cfg["W"], cfg["H"]
+        if grad_color is None:
+            grad_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
         with torch.cuda.device(dev):
             d_m2d_ws = torch.zeros((rows, 3), **f32)   # head rows keep 0: the head is frozen
             d_xyz, d_sc = torch.empty((n_hair, 3), **f32), torch.empty((n_hair, 3), **f32)
@@ -274,7 +281,7 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
     cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
                proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
                sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier),
-               tanfovx=math.tan(float(cam.FoVx) * 0.5), tanfovy=math.tan(float(cam.FoVy) * 0.5),
+               tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
                eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
                debug=bool(debug))
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,

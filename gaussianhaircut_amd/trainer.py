@@ -14,6 +14,18 @@ from .utils.loss_utils import l1_loss, or_loss, ssim
 PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
+_ONES = {}
+
+
+def _one_like(loss):
+    """A cached scalar 1 to seed backward() with (saves autograd's ones_like fill kernel on every view)."""
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return one
+
+
 def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
     """train_gaussians.py:113-140.  On a ROCm device all four terms run as one fused HIP op."""
     image, mask = render_pkg["render"], render_pkg["mask"]
@@ -54,7 +66,7 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     for cam in cams:
         pkg = render(cam, gaussians, pipe, background)
         loss = view_loss(pkg, cam, opt, scale=1.0 / V)
-        loss.backward()
+        loss.backward(gradient=_one_like(loss))
         losses.append(loss.detach())
     total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
     from .optim import FusedAdam
@@ -147,7 +159,7 @@ def strand_training_step(gaussians, gaussians_hair, cams: List, background, opt,
     for cam in cams:
         pkg = render_hair(cam, gaussians, gaussians_hair, pipe, background)
         loss = strand_view_loss(pkg, cam, opt, scale=1.0 / V)
-        loss.backward()
+        loss.backward(gradient=_one_like(loss))
         losses.append(loss.detach())
         if cam is not cams[-1]:
             gaussians_hair.initialize_gaussians_hair()  # a fresh graph for the next view

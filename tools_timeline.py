@@ -12,7 +12,8 @@ adam = [i for i, n in enumerate(names) if "k_adam(" in n]
 if len(adam) < 3:
     print("not enough steps", len(adam))
     sys.exit(0)
-a, b = adam[-3], adam[-2]
+k = int(sys.argv[2]) if len(sys.argv) > 2 else -3  # which step (index into the k_adam launches)
+a, b = adam[k], adam[k + 1]
 t0 = int(rows[a]["End_Timestamp"])
 prev_end = t0
 busy = 0
