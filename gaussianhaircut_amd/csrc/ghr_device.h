@@ -98,8 +98,20 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga)
     const uint32_t cnt = rect4_area(r);
     const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * ((size_t)r.z + r.w);
     f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    for (uint32_t k = 0; k < cnt; k++, p += 4) {
-        s0 += p[0]; s1 += p[1]; s2 += p[2]; s3 += p[3];
+    // four lines (16 independent 16-B loads) are requested per round trip: the loop is pure memory latency, and one
+    // line per trip cost cnt_max-of-the-wave serialized trips.  Lines past `cnt` are not read and add +0; the sum
+    // order (ascending ordinal) is unchanged.
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    for (uint32_t k = 0; k < cnt; k += 4, p += 16) {
+        f4 v[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool in = k + j < cnt;
+#pragma unroll
+            for (int q = 0; q < 4; q++) v[4 * j + q] = in ? p[4 * j + q] : z;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s0 += v[4 * j]; s1 += v[4 * j + 1]; s2 += v[4 * j + 2]; s3 += v[4 * j + 3]; }
     }
     ga[0] = s0.x; ga[1] = s0.y; ga[2] = s0.z; ga[3] = s0.w; ga[4] = s1.x; ga[5] = s1.y; ga[6] = s1.z; ga[7] = s1.w;
     ga[8] = s2.x; ga[9] = s2.y; ga[10] = s2.z; ga[11] = s2.w; ga[12] = s3.x; ga[13] = s3.y; ga[14] = s3.z; ga[15] = s3.w;

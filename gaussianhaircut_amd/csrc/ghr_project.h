@@ -542,27 +542,57 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
 #define GHR_REST_MAX (3 * (GHR_SH_MAX - 1))  // 45
 
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ void slab_copy(float* dst, const float* src, size_t n_floats, int tid)
+#define GHR_SLAB_IT ((GHR_BLOCK * GHR_REST_MAX / 4 + GHR_BLOCK - 1) / GHR_BLOCK)  // 12 b128 accesses per thread
+// Global -> registers: ALL of a thread's (up to 12) loads are issued back to back; a rolled `d4[i] = s4[i]` loop
+// compiles to load / s_waitcnt vmcnt(0) / ds_write per trip, i.e. 12 serialized HBM round trips per workgroup.
+__device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats, int tid)
 {
-    // src/dst start 16-B aligned (256 * 3(K-1) * 4 bytes per block is a multiple of 16); the tail is scalar
-    const size_t n4 = n_floats / 4;
+    // src starts 16-B aligned (256 * 3(K-1) * 4 bytes per block is a multiple of 16)
+    const uint32_t n4 = (uint32_t)(n_floats / 4);
     const f4* s4 = reinterpret_cast<const f4*>(src);
+#pragma unroll
+    for (int it = 0; it < GHR_SLAB_IT; it++) {
+        const uint32_t i = tid + GHR_BLOCK * it;
+        if (i < n4) v[it] = s4[i];
+    }
+}
+// registers -> LDS (+ the scalar tail of a partial last block straight from global)
+__device__ __forceinline__ void slab_to_lds(float* dst, const f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats,
+                                            int tid)
+{
+    const uint32_t n4 = (uint32_t)(n_floats / 4);
     f4* d4 = reinterpret_cast<f4*>(dst);
-    for (size_t i = tid; i < n4; i += GHR_BLOCK) d4[i] = s4[i];
-    for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
+#pragma unroll
+    for (int it = 0; it < GHR_SLAB_IT; it++) {
+        const uint32_t i = tid + GHR_BLOCK * it;
+        if (i < n4) d4[i] = v[it];
+    }
+    for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
 }
 // LDS gradient slab -> global, assigning or accumulating; returns whether a stored value was NaN
 __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_floats, int tid, int accumulate)
 {
-    const size_t n4 = n_floats / 4;
+    const uint32_t n4 = (uint32_t)(n_floats / 4);
     const f4* s4 = reinterpret_cast<const f4*>(src);
     f4* d4 = reinterpret_cast<f4*>(dst);
     bool bad = false;
-    for (size_t i = tid; i < n4; i += GHR_BLOCK) {
-        f4 v = s4[i];
-        if (accumulate) v += d4[i];
-        d4[i] = v;
-        bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+    f4 old[GHR_SLAB_IT];
+    if (accumulate) {  // the read half of the read-modify-write, all loads in flight together (see slab_load)
+#pragma unroll
+        for (int it = 0; it < GHR_SLAB_IT; it++) {
+            const uint32_t i = tid + GHR_BLOCK * it;
+            if (i < n4) old[it] = d4[i];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < GHR_SLAB_IT; it++) {
+        const uint32_t i = tid + GHR_BLOCK * it;
+        if (i < n4) {
+            f4 v = s4[i];
+            if (accumulate) v += old[it];
+            d4[i] = v;
+            bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+        }
     }
     for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) {
         float v = src[i];
@@ -581,7 +611,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     const int row = 3 * (a.sh_coeffs - 1);
     const int base = blockIdx.x * GHR_BLOCK;
     const int nb = min(GHR_BLOCK, a.P - base);
-    if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    if (row > 0) {
+        f4 v[GHR_SLAB_IT];
+        slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+        slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    }
     __syncthreads();
     const int idx = base + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
@@ -602,15 +636,19 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     const int row = 3 * (a.sh_coeffs - 1);
     const int base = blockIdx.x * GHR_BLOCK;
     const int nb = min(GHR_BLOCK, a.P - base);
-    if (row > 0) slab_copy(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
-    __syncthreads();
     const int idx = base + threadIdx.x;
+    // request the rect, then the coefficient slab, and gather this Gaussian's gradient lines while the slab is in
+    // flight (vmcnt retires in order: the rect must be the OLDEST request or waiting for it drains the slab too)
+    rect4 r = make_rect4(0, 0, 0, 0, 0u);
+    if (idx < a.P) r = a.rects[(size_t)a.row0 + idx];
+    f4 v[GHR_SLAB_IT];
+    if (row > 0) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    float ga[16];
+    gather_inst_grads(g.ginst, r, ga);
+    if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    __syncthreads();
     bool bad = false;
-    if (idx < a.P) {
-        float ga[16];
-        gather_inst_grads(g.ginst, a.rects[(size_t)a.row0 + idx], ga);
-        bad = project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
-    }
+    if (idx < a.P) bad = project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
     __syncthreads();
     if (row > 0) bad |= slab_out(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
