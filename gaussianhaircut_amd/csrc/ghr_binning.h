@@ -178,6 +178,7 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
     const uint32_t tile = xcd_tile(blockIdx.x, T);
+    if (tile >= T) return;  // grid padding
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;
     const int tid = threadIdx.x;

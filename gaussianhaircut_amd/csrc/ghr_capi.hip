@@ -221,12 +221,13 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, b.keys, R);
-        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(T), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T, im.tile_start, b.keys,
-                           b.point_list, R, im.tile_count);
+        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
+                           im.tile_start, b.keys, b.point_list, R, im.tile_count);
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
-    hipLaunchKernelGGL(ghr::k_render_fwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T, im.tile_start,
-                       b.point_list, g.rec, a->background, out_color, im.final_T, im.n_contrib, R);
+    hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
+                       (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
+                       im.n_contrib, R);
     if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }
@@ -257,9 +258,9 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
 
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
-        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx, (uint32_t)T,
-                           im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib, dL_dpix,
-                           g.rects, grad_scratch);
+        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
+                           (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib,
+                           dL_dpix, g.rects, grad_scratch);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -381,8 +382,9 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
     carve_bin(align_base(bin_ws), (size_t)R, &b);
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    hipLaunchKernelGGL(ghr::k_render_bwd, dim3(T), dim3(GHR_BLOCK), 0, s, W, H, gx, (uint32_t)T, im.tile_start,
-                       b.point_list, g.rec, background, im.final_T, im.n_contrib, dL_dpix, g.rects, grad_scratch);
+    hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, W, H, gx, (uint32_t)T,
+                       im.tile_start, b.point_list, g.rec, background, im.final_T, im.n_contrib, dL_dpix, g.rects,
+                       grad_scratch);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }

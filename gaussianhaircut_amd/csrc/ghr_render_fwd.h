@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
+    if (tile >= T_tiles) return;  // grid padding
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l = lane & 15;
     // this lane's pixel: cell (wave, grp) of the tile, 4x4 pixels, lane l -> (l & 3, l >> 2)

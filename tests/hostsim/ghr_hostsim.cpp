@@ -281,16 +281,21 @@ int ghrsim_bbox_violations(const float* rec16, int n, int W, int H)
     return bad;
 }
 
-// xcd_tile must be a bijection of [0, n)
+// xcd_tile over the padded grid must visit every tile of [0, n) exactly once (padding workgroups map to >= n)
 int ghrsim_xcd_bijective(uint32_t n)
 {
     std::vector<uint8_t> seen(n, 0);
-    for (uint32_t b = 0; b < n; b++) {
+    uint32_t visited = 0;
+    const uint32_t grid = ghr::xcd_grid(n);
+    if (grid < n || grid >= n + 8u * GHR_XCD_RUN) return 0;
+    for (uint32_t b = 0; b < grid; b++) {
         const uint32_t t = ghr::xcd_tile(b, n);
-        if (t >= n || seen[t]) return 0;
+        if (t >= n) continue;
+        if (seen[t]) return 0;
         seen[t] = 1;
+        visited++;
     }
-    return 1;
+    return visited == n;
 }
 
 // sorts `n` keys with the product's network; returns 1 if the result is ascending
