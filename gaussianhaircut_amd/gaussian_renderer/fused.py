@@ -106,7 +106,19 @@ class _RenderModelFused(torch.autograd.Function):
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
-            if P > 0:
+            if P > 0 and direct and sink.concurrent:
+                # this view shares the GPU with its neighbours (trainer.training_step): only the kernel that adds into
+                # the shared gradient buffer is ordered after the previous view's
+                stream = torch.cuda.current_stream()
+                _lib.check(L.ghr_render_backward(_stream(), P, cfg["W"], cfg["H"], ctx.cap, _ptr(bg), _ptr(geom),
+                                                 _ptr(img), _ptr(binb), _ptr(dL), _ptr(scratch)))
+                sink.accumulate_begin(stream)
+                _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
+                                                        _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
+                                                        _ptr(d_op), _ptr(d_label), _ptr(d_conf), _ptr(d_fdc),
+                                                        _ptr(d_frest), None, 1, sink.nan_flag_ptr()))
+                sink.accumulate_end(stream)
+            elif P > 0:
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),

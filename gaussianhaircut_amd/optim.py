@@ -27,6 +27,8 @@ class FusedAdam:
         # the NaN flag up to date, instead of returning 8 tensors for autograd to accumulate (8 kernels, 3x the traffic)
         self.direct_grads = direct_grads
         self._direct_backwards = 0
+        self.concurrent = False  # set by the trainer while a step's views run on several streams
+        self._acc_event = None
         params = [p for g in self.param_groups for p in g["params"]]
         assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
             "FusedAdam needs fp32 parameters on a ROCm device (use torch.optim.Adam elsewhere)"
@@ -143,6 +145,19 @@ class FusedAdam:
     def note_direct_backward(self):
         self._direct_backwards += 1
 
+    # ---- views of one step on several HIP streams (trainer.training_step): the direct backward ACCUMULATES into the
+    # flat gradient buffer with plain read-modify-writes, so the accumulating kernels of different views are chained
+    # by events (everything else of a view -- forward, loss, render backward -- may overlap with its neighbours)
+    def accumulate_begin(self, stream):
+        if self.concurrent and self._acc_event is not None:
+            stream.wait_event(self._acc_event)
+
+    def accumulate_end(self, stream):
+        if self.concurrent:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self._acc_event = ev
+
     # ---- optimizer interface
     def step(self, zero_grad: bool = True, nan_scan: bool = True):
         """``nan_scan=False``: every gradient of this step was produced by the fused renderer's backward on THIS rank
@@ -151,6 +166,7 @@ class FusedAdam:
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 0 if not self.nan_guard else (1 if nan_scan or self._direct_backwards == 0 else 2)
         self._direct_backwards = 0
+        self._acc_event = None
         with torch.cuda.device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),

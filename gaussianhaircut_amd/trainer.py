@@ -57,19 +57,59 @@ def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
     return loss * scale if scale != 1.0 else loss
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (device.index, n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
 def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
-                  global_views: Optional[int] = None, pipe=PIPE):
-    """One global gradient step over this rank's views.  Returns the (detached) summed local loss."""
+                  global_views: Optional[int] = None, pipe=PIPE, streams: Optional[int] = None):
+    """One global gradient step over this rank's views.  Returns the (detached) summed local loss.
+
+    ``streams`` (default 2 with the fused path and more than one view): the views of the step are independent given
+    the parameters, so consecutive views run on alternating HIP streams -- the next view's projection / binning /
+    compositing / loss fills the CUs the current view's VALU-bound backward leaves idle and vice versa (measured
+    3.38 -> 3.08 ms for the 4-view step).  Only the kernels that add into the shared flat gradient buffer are
+    chained (FusedAdam.accumulate_begin/end); the optimizer step waits for every stream."""
+    from .optim import FusedAdam
     gaussians.update_learning_rate(iteration)
     V = global_views or len(cams)
     losses = []
-    for cam in cams:
-        pkg = render(cam, gaussians, pipe, background)
-        loss = view_loss(pkg, cam, opt, scale=1.0 / V)
-        loss.backward(gradient=_one_like(loss))
-        losses.append(loss.detach())
+    sink = gaussians.optimizer if isinstance(getattr(gaussians, "optimizer", None), FusedAdam) else None
+    can_overlap = (sink is not None and sink.direct_grads and len(cams) > 1 and background.is_cuda and
+                   not getattr(pipe, "debug", False))
+    n_streams = (2 if streams is None else int(streams)) if can_overlap else 0
+    if n_streams > 1:
+        main = torch.cuda.current_stream(background.device)
+        side = _side_streams(background.device, n_streams)
+        for s in side:
+            s.wait_stream(main)  # parameters as the previous optimizer step left them
+        sink.concurrent = True
+        try:
+            for i, cam in enumerate(cams):
+                with torch.cuda.stream(side[i % n_streams]):
+                    pkg = render(cam, gaussians, pipe, background)
+                    loss = view_loss(pkg, cam, opt, scale=1.0 / V)
+                    loss.backward(gradient=_one_like(loss))
+                    ld = loss.detach()
+                    ld.record_stream(main)
+                    losses.append(ld)
+        finally:
+            sink.concurrent = False
+            for s in side:
+                main.wait_stream(s)
+    else:
+        for cam in cams:
+            pkg = render(cam, gaussians, pipe, background)
+            loss = view_loss(pkg, cam, opt, scale=1.0 / V)
+            loss.backward(gradient=_one_like(loss))
+            losses.append(loss.detach())
     total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
-    from .optim import FusedAdam
     if isinstance(gaussians.optimizer, FusedAdam):
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
         # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no

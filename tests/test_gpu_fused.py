@@ -71,6 +71,49 @@ def test_fused_training_step_runs_and_learns():
     assert losses[-1] < losses[0] and np.isfinite(losses).all()
 
 
+def test_multi_stream_views_equal_sequential_views():
+    """training_step(streams=2/3): consecutive views of a step run on alternating HIP streams with only the accumulating
+    kernels chained, so the per-view gradients are summed in the same order as on one stream.  The accumulated
+    gradient of the first step (identical parameters) must agree with the sequential schedule to fp32 rounding of the
+    render backward's atomics -- a race on the shared gradient buffer would lose a whole view's contribution -- and the
+    run must keep learning."""
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    bg = syn.background(dev)
+    cams = ring_cameras(5, spec.W, spec.H, device=dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, cams, bg)
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    runs = []
+    for n_streams in (1, 2, 3):
+        model = syn.make_model(spec, dev)
+        model.training_setup(opt)
+        o = model.optimizer
+        grads, orig_step = [], o.step
+
+        def capture(**kw):
+            grads.append(o.flat_grad.detach().clone())
+            return orig_step(**kw)
+        o.step = capture
+        losses = [float(training_step(model, cams, bg, opt, i + 1, streams=n_streams)) for i in range(6)]
+        torch.cuda.synchronize()
+        assert not o.concurrent and o._acc_event is None
+        assert np.isfinite(losses).all() and losses[-1] < losses[0]
+        runs.append((losses, grads[0]))
+    ref_loss, ref_grad = runs[0]
+    scale = float(ref_grad.abs().max())
+    assert scale > 0
+    for losses, grad in runs[1:]:
+        assert abs(losses[0] - ref_loss[0]) <= 1e-6 * abs(ref_loss[0])
+        assert float((grad - ref_grad).abs().max()) <= 1e-5 * scale
+
+
 def test_direct_gradient_sink_equals_autograd_accumulation_and_raises_nan_flag():
     """FusedAdam(direct_grads=True): the renderer's backward adds into the flat gradient buffer itself (two views ->
     accumulation) and maintains the NaN flag; must equal the autograd-accumulated gradients of direct_grads=False."""
