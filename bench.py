@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "tiny"])
     ap.add_argument("--views-per-gpu", type=int, default=4,
                     help="views per GPU per global step; 4 = the per-GPU shard of BASELINE.json configs[3] (32 views on 8 GPUs)")
+    ap.add_argument("--streams", type=int, default=None,
+                    help="HIP streams the views of a step alternate on (default: trainer's choice, 2; 1 = one stream, "
+                         "the setting per-kernel rocprof averages should be taken with)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-op-only", action="store_true")
     args = ap.parse_args()
@@ -92,37 +95,13 @@ def main():
     bucket = None
     torch.cuda.synchronize()
 
-    # ---- HIP events around the two render kernels, recorded by the library on the launch stream -------------------
     K, Wm = args.steps, args.warmup
-    n_ev = K  # the last view of every timed step carries the events (its instance count is the one reported)
-    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
-    for quad in evs:
-        for e in quad:
-            e.record()  # materialise the hipEvent_t
-    torch.cuda.synchronize()
-
-    ev_i = [0]
     from gaussianhaircut_amd import trainer as _tr
     from gaussianhaircut_amd.gaussian_renderer import render as _render
-
-    view_i = [0]
-
-    def render_with_events(cam, pc, pipe, bgc, scaling_modifier=1.0):
-        view_i[0] += 1
-        if view_i[0] == V:
-            q = evs[ev_i[0] % n_ev]
-            ev_i[0] += 1
-            L.ghr_set_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in q])
-        elif view_i[0] == 1:
-            L.ghr_set_profile_events(None, None, None, None)
-        return _render(cam, pc, pipe, bgc, scaling_modifier)
+    L.ghr_set_profile_events(None, None, None, None)
 
     def step(it, timed):
-        _tr.render = render_with_events if timed else _render
-        view_i[0] = 0
-        if not timed:
-            L.ghr_set_profile_events(None, None, None, None)
-        return training_step(model, cams, bg, opt, it, bucket=bucket, global_views=global_views)
+        return training_step(model, cams, bg, opt, it, bucket=bucket, global_views=global_views, streams=args.streams)
 
     for i in range(Wm):
         step(i + 1, False)
@@ -138,8 +117,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+
+    # ---- roofline leg: HIP events around the two render kernels, recorded by the library on the launch stream.  In the
+    # timed steps above the kernels of two views share the GPU (two streams), so a kernel's wall time there is not a
+    # property of the kernel; here the same view (this rank's first camera, same parameters) runs alone:
+    # render + loss + backward, K passes, no optimizer step (the accumulated gradients are dropped afterwards).
+    n_ev = max(K, 10)
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n_ev)]
+    for quad in evs:
+        for e in quad:
+            e.record()  # materialise the hipEvent_t
+    torch.cuda.synchronize()
+    V1 = 1.0 / global_views
+    for q in [None, None] + evs:
+        if q is not None:
+            L.ghr_set_profile_events(*[ctypes.c_void_p(e.cuda_event) for e in q])
+        pkg = _render(cams[0], model, _tr.PIPE, bg)
+        loss = _tr.view_loss(pkg, cams[0], opt, scale=V1)
+        loss.backward()
     L.ghr_set_profile_events(None, None, None, None)
-    _tr.render = _render
+    torch.cuda.synchronize()
+    model.optimizer.flat_grad.zero_()
+    model.optimizer.state_dev[1:2].zero_()
+    model.optimizer._direct_backwards = 0
+    torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -171,7 +172,8 @@ def main():
     roofline = {"kernel": "k_render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "VALU/LDS-bound gradient walk; algorithmic bytes per SURVEY.md 8(d)"}
+                "note": "VALU/LDS-bound gradient walk; algorithmic bytes per SURVEY.md 8(d); kernel duration from HIP "
+                        "events over %d solo passes of one view (in the timed steps two views share the GPU)" % n_ev}
 
     out = {
         "metric": "gaussians_rasterized_per_sec_fwd_bwd_1080p", "value": round(value, 1), "unit": "Gaussians/s",
@@ -192,11 +194,11 @@ def main():
         # BASELINE.json configs[2]: the same stage-1 step with ONE view per gradient step
         K1 = max(10, K)
         for i in range(3):
-            training_step(model, cams[:1], bg, opt, Wm + K + i + 1, global_views=1)
+            training_step(model, cams[:1], bg, opt, Wm + K + i + 1, global_views=1, streams=args.streams)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(K1):
-            training_step(model, cams[:1], bg, opt, Wm + K + 3 + i + 1, global_views=1)
+            training_step(model, cams[:1], bg, opt, Wm + K + 3 + i + 1, global_views=1, streams=args.streams)
         torch.cuda.synchronize()
         dt1 = (time.perf_counter() - t1) / K1
         out["single_view_step"] = {"workload": "BASELINE configs[2]: 1 view per gradient step", "steps": K1,

@@ -260,7 +260,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     if (R > 0)
         hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                            (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib,
-                           dL_dpix, g.rects, grad_scratch);
+                           dL_dpix, g.rects, grad_scratch, R);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -384,7 +384,7 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, W, H, gx, (uint32_t)T,
                        im.tile_start, b.point_list, g.rec, background, im.final_T, im.n_contrib, dL_dpix, g.rects,
-                       grad_scratch);
+                       grad_scratch, R);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }
@@ -393,7 +393,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
                                const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
                                float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
-                               int32_t accumulate, int32_t* nan_flag)
+                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows)
 {
     ghr::ModelArgs a;
     if (int rc = fill_model(m, &a)) return rc;
@@ -409,7 +409,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     a.radii = const_cast<int*>(radii);
     a.rects = g.rects;
     ghr::ModelGrads mg;
-    mg.ginst = grad_scratch; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
+    mg.ginst = grad_scratch; mg.ginst_rows = grad_rows ? grad_rows : 0xffffffffu; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
@@ -434,7 +434,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
         return rc;
     return ghr_model_backward_segment(stream, m, m->P, radii, geom_ws, grad_scratch, d_means2D, d_xyz, d_log_scales,
                                       d_rotations, d_opacity_logit, d_label_logit, d_orient_conf_log, d_features_dc,
-                                      d_features_rest, nullptr, accumulate, nan_flag);
+                                      d_features_rest, nullptr, accumulate, nan_flag, R);
 }
 
 namespace ghr {

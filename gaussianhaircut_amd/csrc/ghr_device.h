@@ -93,9 +93,12 @@ GHR_HD uint32_t rect4_slot(const rect4& r, int tx, int ty)
 }
 
 // Sum of a Gaussian's per-instance gradient lines in tile-ordinal order (deterministic).
-GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga)
+// `rows`: number of lines `ginst` holds.  A Gaussian whose lines would reach past it (only possible when the forward ran
+// with a capacity below the true instance count, whose results the caller discards) reads nothing.
+GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uint32_t rows = 0xffffffffu)
 {
-    const uint32_t cnt = rect4_area(r);
+    uint32_t cnt = rect4_area(r);
+    if ((uint64_t)r.z + r.w + cnt > (uint64_t)rows) cnt = 0;
     const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * ((size_t)r.z + r.w);
     f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     // four lines (16 independent 16-B loads) are requested per round trip: the loop is pure memory latency, and one

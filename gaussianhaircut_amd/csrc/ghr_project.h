@@ -64,6 +64,7 @@ struct ModelArgs {
 
 struct ModelGrads {
     const float* ginst;  // [R][16] per-instance packed gradients from k_render_bwd (slots: rect4_slot)
+    uint32_t ginst_rows; // lines in ginst (bound of the gather)
     float* d_means2D;   // [P,3]  dL/d(NDC mean) (densification signal), z = 0
     float* d_xyz;       // [P,3]
     float* d_log_scales;// [P,3]
@@ -644,7 +645,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     f4 v[GHR_SLAB_IT];
     if (row > 0) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     float ga[16];
-    gather_inst_grads(g.ginst, r, ga);
+    gather_inst_grads(g.ginst, r, ga, g.ginst_rows);
     if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     bool bad = false;

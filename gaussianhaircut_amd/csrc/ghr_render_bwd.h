@@ -190,7 +190,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                                                           const float* __restrict__ final_T,
                                                           const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpix,
-                                                          const rect4* __restrict__ rects, float* ginst)
+                                                          const rect4* __restrict__ rects, float* ginst,
+                                                          uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
@@ -209,8 +210,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     const float wx0 = (float)(tx * GHR_TILE_X);
     const float cy0 = (float)(ty * GHR_TILE_Y + 4 * wave);
 
-    const uint32_t beg = tile_start[tile];
-    const uint32_t n = tile_start[tile + 1] - beg;
+    // cap = the capacity the forward ran with = lines in ginst.  It only bites when the forward was launched with a
+    // capacity below the true instance count (speculative launch whose results the caller discards): then, like K7,
+    // stay inside the lists and inside the gradient buffer.
+    const uint32_t beg = min(tile_start[tile], cap);
+    const uint32_t n = min(tile_start[tile + 1], cap) - beg;
 
     PixBwd st;
     st.T_final = inside ? final_T[pix] : 0.f;
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)id;
             const f4 a0 = r[0], a1 = r[1];
-            const uint32_t slot = rect4_slot(rects[id], tx, ty);
+            const uint32_t slot = min(rect4_slot(rects[id], tx, ty), cap - 1u);
             f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)slot;  // zero the instance's gradient line
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
             dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
@@ -341,7 +345,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     // list entries no pixel of the tile ever reached (positions >= n_eff): their slots must read as zero
     for (uint32_t i = n_eff + tid; i < n; i += GHR_BLOCK) {
         const uint32_t id = point_list[beg + i];
-        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)rect4_slot(rects[id], tx, ty);
+        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)min(rect4_slot(rects[id], tx, ty), cap - 1u);
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
         dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
     }

@@ -31,17 +31,20 @@ NUM_CHANNELS = _lib.NUM_CHANNELS
 # last forward's sizes (read by bench.py for the roofline's algorithmic byte count)
 LAST_STATS = {"num_rendered": 0, "P": 0}
 
-# pinned host word per device that receives num_rendered from stage 1
+# pinned host words that receive num_rendered from stage 1: a ring per device, one word per forward (several forwards
+# may be in flight before their counts are read, see PendingCount)
+_PIN_SLOTS = 256
 _pinned_R = {}
 
 
 def _pinned(device: torch.device) -> torch.Tensor:
     key = device.index if device.index is not None else torch.cuda.current_device()
-    t = _pinned_R.get(key)
-    if t is None:
-        t = torch.zeros(4, dtype=torch.int32).pin_memory()
-        _pinned_R[key] = t
-    return t
+    ring = _pinned_R.get(key)
+    if ring is None:
+        ring = _pinned_R[key] = [torch.zeros(_PIN_SLOTS, dtype=torch.int32).pin_memory(), 0]
+    i = ring[1]
+    ring[1] = (i + 1) % _PIN_SLOTS
+    return ring[0][i:i + 1]
 
 
 def _ptr(t):
@@ -95,13 +98,43 @@ def _stream():
 _R_HINT = {}  # device index -> binning capacity guess (1.25 x the previous frame's instance count)
 
 
-def run_stage2(dev, P, pinned, launch):
+def _note_count(dev_index, R, P):
+    _R_HINT[dev_index] = R + R // 4 + 4096
+    LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
+
+
+class PendingCount:
+    """Instance count of a forward whose stage 2 was launched with a guessed capacity and whose true count has not been
+    read yet (``run_stage2(defer=True)``).  ``resolve()`` waits for stage 1 (long finished in practice), returns
+    ``(num_rendered, overflow)``; with ``overflow`` the forward's outputs AND everything derived from them (loss,
+    gradients) are invalid and must be recomputed -- the kernels stayed inside their buffers (include/ghr.h)."""
+
+    def __init__(self, slot, event, cap, dev_index, P):
+        self.slot, self.event, self.cap, self.dev_index, self.P = slot, event, cap, dev_index, P
+        self.result = None
+
+    def resolve(self):
+        if self.result is None:
+            self.event.synchronize()
+            R = int(self.slot[0].item())
+            self.result = (R, R > self.cap)
+            _note_count(self.dev_index, R, self.P)
+        return self.result
+
+
+def run_stage2(dev, P, pinned, launch, defer=False):
     """Reads stage 1's instance count and runs stage 2 (``launch(capacity) -> binning buffer``).  After the first
     frame stage 2 is launched SPECULATIVELY with a capacity guessed from the previous frame before the 4-byte count is
     read back, so the GPU already works on scatter / sort / compositing while the host waits; it is relaunched only if
-    the true count exceeds the guess (include/ghr.h, ghr_forward_stage2).  Returns (num_rendered, capacity, buffer)."""
+    the true count exceeds the guess (include/ghr.h, ghr_forward_stage2).  Returns (num_rendered, capacity, buffer).
+    ``defer``: do not wait at all -- num_rendered comes back as a ``PendingCount`` the caller resolves later (the
+    training step: once per step, after every view is queued)."""
     stream = torch.cuda.current_stream()
     hint = _R_HINT.get(dev.index) if P > 0 else None
+    if hint and defer:
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return PendingCount(pinned, ev, hint, dev.index, P), hint, launch(hint)
     if hint:
         ev = torch.cuda.Event()
         ev.record(stream)      # completes when stage 1's count has landed in pinned memory ...
@@ -115,7 +148,7 @@ def run_stage2(dev, P, pinned, launch):
         R = int(pinned[0].item()) if P > 0 else 0
         binb, cap = launch(R), R
     if P > 0:
-        _R_HINT[dev.index] = R + R // 4 + 4096
+        _note_count(dev.index, R, P)
     return R, cap, binb
 
 

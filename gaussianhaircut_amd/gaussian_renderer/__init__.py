@@ -69,6 +69,7 @@ class RenderPackage(dict):
         super().__init__(**kw)
         self._cov2d = cov2d
         self.renders_packed = renders
+        self.count = None  # fused path: num_rendered (int) or a PendingCount
 
     def _materialise(self, k=None):
         if k in (None, "orient_angle") and not dict.__contains__(self, "orient_angle"):
@@ -124,9 +125,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     """Render the scene (reference :23-113).  ``bg_color`` (10 floats) must be on the GPU."""
     if _use_fused(pc, pipe):
         from .fused import render_model_fused
-        renders, radii, screenspace_points = render_model_fused(viewpoint_camera, pc, bg_color, scaling_modifier,
-                                                                getattr(pipe, "debug", False))
-        return _package(renders, screenspace_points, radii)
+        # pipe.defer_count (set by trainer.training_step, which owns the recovery): queue the view without ever
+        # reading num_rendered back; the package then carries a PendingCount in `.count`
+        renders, radii, screenspace_points, count = render_model_fused(
+            viewpoint_camera, pc, bg_color, scaling_modifier, getattr(pipe, "debug", False),
+            defer_count=getattr(pipe, "defer_count", False) and not getattr(pipe, "debug", False))
+        pkg = _package(renders, screenspace_points, radii)
+        pkg.count = count
+        return pkg
     conic = pc.get_conic(viewpoint_camera, scaling_modifier)  # must precede direction / filter (cached state)
     screenspace_points = pc.get_mean_2d(viewpoint_camera)
     try:

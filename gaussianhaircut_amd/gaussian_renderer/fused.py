@@ -63,8 +63,9 @@ class _RenderModelFused(torch.autograd.Function):
                                                 _ptr(color)))
                 return b
 
-            R, cap, binb = run_stage2(dev, P, pinned, launch)  # speculative: see diff_gaussian_rasterization.run_stage2
-        LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
+            # speculative (see diff_gaussian_rasterization.run_stage2); with cfg["defer_count"] R is a PendingCount
+            R, cap, binb = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
+        cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
         # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
         # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
@@ -102,7 +103,9 @@ class _RenderModelFused(torch.autograd.Function):
                 d_conf = torch.empty((P, 1), **f32)
                 d_fdc = torch.empty((P, 1, 3), **f32)
                 d_frest = torch.empty((P, K - 1, 3), **f32)
-            scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)  # one line per instance
+            # one line per instance; `cap` lines while the count is still pending (include/ghr.h, ghr_backward)
+            rows = max(int(R), 1) if isinstance(R, int) else max(int(ctx.cap), 1)
+            scratch = torch.empty((rows, _lib.GRAD_STRIDE), **f32)
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
@@ -116,7 +119,7 @@ class _RenderModelFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
                                                         _ptr(d_op), _ptr(d_label), _ptr(d_conf), _ptr(d_fdc),
-                                                        _ptr(d_frest), None, 1, sink.nan_flag_ptr()))
+                                                        _ptr(d_frest), None, 1, sink.nan_flag_ptr(), rows))
                 sink.accumulate_end(stream)
             elif P > 0:
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
@@ -130,8 +133,9 @@ class _RenderModelFused(torch.autograd.Function):
         return d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d, None
 
 
-def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
-    """Returns (renders[10,H,W], radii[P], screenspace_points[P,3] leaf whose .grad receives dL/d(NDC mean))."""
+def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False):
+    """Returns (renders[10,H,W], radii[P], screenspace_points[P,3] leaf whose .grad receives dL/d(NDC mean),
+    num_rendered: int, or a PendingCount with ``defer_count``)."""
     import math
     xyz = pc.get_xyz
     P = xyz.shape[0]
@@ -143,14 +147,14 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug):
                proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
                tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
-               conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug))
+               conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug), defer_count=bool(defer_count))
     from ..optim import FusedAdam
     opt = getattr(pc, "optimizer", None)
     if isinstance(opt, FusedAdam) and opt.direct_grads:
         cfg["grad_sink"] = opt
     renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
                                              pc._features_dc, pc._features_rest, screenspace_points, cfg)
-    return renders, radii, screenspace_points
+    return renders, radii, screenspace_points, cfg.get("count")
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -261,7 +265,7 @@ class _RenderHairFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
                                                         _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
-                                                        _ptr(d_dir), 0, None))
+                                                        _ptr(d_dir), 0, None, scratch.shape[0]))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
         return d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d, None, None
 

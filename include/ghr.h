@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 6
+#define GHR_ABI_VERSION 7
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -98,7 +98,9 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
 /* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  R: the capacity stage 2 was run with (layout of bin_ws).
  * grad_scratch: GHR_GRAD_STRIDE floats (one 64-B gradient line) per Gaussian-tile instance actually reported by stage 1
  * (may be NULL when that count is 0), uninitialised on entry: every line is zero-filled and accumulated by K8 and the
- * lines of a Gaussian are summed in a fixed order -- no cross-tile float atomics.
+ * lines of a Gaussian are summed in a fixed order -- no cross-tile float atomics.  A caller that launched stage 2
+ * speculatively and has not read the count yet passes R lines instead: no line index >= R is ever touched, so a count
+ * above the capacity (whose results the caller must discard and recompute) cannot write outside the buffer.
  * Outputs (all fully written, no pre-zeroing needed), shapes of rasterize_points.cu:160-168:
  *   dL_dmeans2D [P,3] (z = 0), dL_dconic [P,2,2] ([0][0], [0][1] = HALF of d/db as in backward.cu:554, [1][1]),
  *   dL_dopacity [P], dL_dcolors [P,C], dL_dmeans3D [P,3], dL_dcov3D [P,6], dL_dscales [P,3], dL_drotations [P,4]. */
@@ -168,7 +170,7 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
 /* Backward in two steps: K8 over the whole state (rows_total rows), then the per-Gaussian chain for the segments that
  * need gradients.  d_means2D is [rows_total,3]; the parameter gradients are per segment ([P,...]); in mode 1
  * d_log_scales / d_opacity_logit / d_label_logit / d_orient_conf_log are the gradients of the linear quantities and,
- * like d_dir3d, may be NULL. */
+ * like d_dir3d, may be NULL.  grad_rows: number of lines in grad_scratch (0: not bounded), see ghr_backward. */
 int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
                         const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
                         float* grad_scratch);
@@ -176,7 +178,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
                                const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
                                float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
-                               int32_t accumulate, int32_t* nan_flag);
+                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows);
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,

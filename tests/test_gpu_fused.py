@@ -114,6 +114,65 @@ def test_multi_stream_views_equal_sequential_views():
         assert float((grad - ref_grad).abs().max()) <= 1e-5 * scale
 
 
+def test_deferred_counts_recover_from_a_too_small_capacity_guess():
+    """training_step never waits for num_rendered (defer_counts): every view runs with the capacity guessed from the
+    previous frame and the counts are checked after the step is queued.  With the guess forced far too small the
+    forward drops instances and the backward clamps its gradient lines into the buffer; the step must notice, discard
+    and recompute -- same gradient as a run that always waited."""
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    import gaussianhaircut_amd.trainer as tr
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    bg = syn.background(dev)
+    cams = ring_cameras(3, spec.W, spec.H, device=dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    tr.make_ground_truth(gt, cams, bg)
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    grads, passes = {}, {}
+    orig = tr._views_forward_backward
+    for mode in ("wait", "defer_ok", "defer_overflow"):
+        model = syn.make_model(spec, dev)
+        model.training_setup(opt)
+        o = model.optimizer
+        render(cams[0], model, tr.PIPE, bg)  # a blocking forward establishes a sane guess (parameters untouched)
+        R_true = dgr.LAST_STATS["num_rendered"]
+        assert R_true > 1000
+        if mode == "defer_overflow":
+            dgr._R_HINT[dev.index] = 64
+        n_pass = [0]
+
+        def counted(*a, **k):
+            n_pass[0] += 1
+            return orig(*a, **k)
+        tr._views_forward_backward = counted
+        captured, orig_step = [], o.step
+
+        def capture(**kw):
+            captured.append(o.flat_grad.detach().clone())
+            assert int(o.state_dev[1]) == 0
+            return orig_step(**kw)
+        o.step = capture
+        try:
+            loss = float(tr.training_step(model, cams, bg, opt, 1, defer_counts=(mode != "wait")))
+        finally:
+            tr._views_forward_backward = orig
+        torch.cuda.synchronize()
+        grads[mode], passes[mode] = (loss, captured[0]), n_pass[0]
+        assert dgr._R_HINT[dev.index] > R_true // 2  # the guess recovered
+    assert passes == {"wait": 1, "defer_ok": 1, "defer_overflow": 2}
+    ref_loss, ref = grads["wait"]
+    scale = float(ref.abs().max())
+    for mode in ("defer_ok", "defer_overflow"):
+        loss, g = grads[mode]
+        assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss)
+        assert float((g - ref).abs().max()) <= 1e-5 * scale
+
+
 def test_direct_gradient_sink_equals_autograd_accumulation_and_raises_nan_flag():
     """FusedAdam(direct_grads=True): the renderer's backward adds into the flat gradient buffer itself (two views ->
     accumulation) and maintains the NaN flag; must equal the autograd-accumulated gradients of direct_grads=False."""

@@ -2,7 +2,7 @@
 # per-kernel averages of the bench step (GPU box tool); every command is time-boxed
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rm -rf /tmp/kts; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kts -o kt -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-op-only ${BENCH_ARGS} > /dev/null 2>&1 )
+rm -rf /tmp/kts; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kts -o kt -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-op-only ${BENCH_ARGS---streams 1} > /dev/null 2>&1 )
 python - <<PY
 import csv,glob
 for f in glob.glob('/tmp/kts/**/*kernel_stats.csv', recursive=True):
