@@ -196,6 +196,15 @@ GHR_HD float fast_exp(float x)
     return exp2f(x * 1.4426950408889634f);
 #endif
 }
+// v_sqrt_f32 (1 ulp) instead of the correctly rounded expansion (~8 VALU)
+GHR_HD float fast_sqrt(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 GHR_HD float fast_rcp(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

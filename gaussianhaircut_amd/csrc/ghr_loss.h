@@ -38,7 +38,8 @@ GHR_HD float ssim_point(float mu1, float mu2, float e11, float e22, float e12, f
     const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
     const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
     const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
-    const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
+    // v_rcp_f32 (1 ulp): a correctly rounded division is ~10 VALU, and this runs per pixel and channel
+    const float iB1 = fast_rcp(B1), iB2 = fast_rcp(B2);
     const float f1 = A1 * iB1, f2 = A2 * iB2;
     dm_de11 = -f1 * f2 * iB2;                 // via sigma1_sq
     dm_de12 = 2.f * f1 * iB2;                 // via sigma12
@@ -70,14 +71,16 @@ struct OrientPix { float l, dl_dd0, dl_dd1, dl_dconf; };
 GHR_HD OrientPix orient_pixel(float d0, float d1, float conf, float gt_angle, float m)
 {
     const float PI = 3.14159265358979323846f;
-    const float nrm = sqrtf(d0 * d0 + d1 * d1);
+    const float INV_PI = 0.31830988618379067154f;
+    const float nrm = fast_sqrt(d0 * d0 + d1 * d1);
     const float den = fmaxf(nrm, 1e-12f);                 // F.normalize(dim=0), eps = 1e-12
-    const float u0 = d0 / den, u1 = d1 / den;
+    const float iden = fast_rcp(den);
+    const float u0 = d0 * iden, u1 = d1 * iden;
     const float mirror = u0 < 0.f ? -1.f : 1.f;
     const float lo = -1.f + 1e-3f, hi = 1.f - 1e-3f;
     const float uc = fminf(hi, fmaxf(lo, u1));
     const float c = uc * mirror;
-    const float angle = acosf(c) / PI;
+    const float angle = acosf(c) * INV_PI;
     const float diff = angle - gt_angle;
     const float a0 = fabsf(diff), a1 = fabsf(diff - 1.f), a2 = fabsf(diff + 1.f);
     float lmin = a0, arg = diff;
@@ -85,18 +88,18 @@ GHR_HD OrientPix orient_pixel(float d0, float d1, float conf, float gt_angle, fl
     if (a2 < lmin) { lmin = a2; arg = diff + 1.f; }
     OrientPix o;
     o.l = (lmin * PI * conf - logf(conf + 1e-7f)) * m;
-    o.dl_dconf = (lmin * PI - 1.0f / (conf + 1e-7f)) * m;
+    o.dl_dconf = (lmin * PI - fast_rcp(conf + 1e-7f)) * m;
     const float sgn = arg > 0.f ? 1.f : (arg < 0.f ? -1.f : 0.f);
     const float dl_dangle = PI * conf * m * sgn;
-    const float dl_dc = dl_dangle * (-1.0f / (PI * sqrtf(1.f - c * c)));
+    const float dl_dc = -dl_dangle * INV_PI * fast_rcp(fast_sqrt(1.f - c * c));
     const float dl_du1 = (u1 >= lo && u1 <= hi) ? dl_dc * mirror : 0.f;   // clamp passes gradient inside the range
     if (nrm > 1e-12f) {  // u = d / |d|:  du1/dd0 = -d0 d1 / |d|^3,  du1/dd1 = d0^2 / |d|^3
-        const float i3 = 1.0f / (nrm * nrm * nrm);
+        const float i3 = iden * iden * iden;  // nrm > eps here, so den == nrm
         o.dl_dd0 = dl_du1 * (-d0 * d1 * i3);
         o.dl_dd1 = dl_du1 * (d0 * d0 * i3);
     } else {             // clamped denominator: u = d / eps
         o.dl_dd0 = 0.f;
-        o.dl_dd1 = dl_du1 / 1e-12f;
+        o.dl_dd1 = dl_du1 * 1e12f;
     }
     return o;
 }
@@ -356,6 +359,8 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
     }
     const int gx = bx + tx;
     const float up = a.grad_loss ? a.grad_loss[0] : 1.0f;
+    // the per-pixel divisions by the (uniform) element counts as multiplications by their reciprocals
+    const float inv3N = 1.0f / (3.0f * (float)N), inv2N = 1.0f / (2.0f * (float)N);
 #pragma unroll
     for (int o = 0; o < 2; o++) {
         const int gy = by + 2 * tr + o;
@@ -365,21 +370,21 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
         const float im = a.image[ch * N + p], g = a.gt_image[ch * N + p];
         const float x = im * mm, y = g * mm;
         // d(mean ssim)/dx(p), then Lssim = 1 - mean  and x = image * m
-        const float dssim_dx = (c[o][0] + 2.f * x * c[o][1] + y * c[o][2]) / (3.0f * (float)N);
+        const float dssim_dx = (c[o][0] + 2.f * x * c[o][1] + y * c[o][2]) * inv3N;
         const float diff = im - g;
         const float sgn = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);
-        a.d_image[ch * N + p] = up * (a.w_l1 * sgn * mm / (3.0f * (float)N) - a.w_ssim * dssim_dx * mm);
+        a.d_image[ch * N + p] = up * (a.w_l1 * sgn * mm * inv3N - a.w_ssim * dssim_dx * mm);
         if (ch < 2) {
             const float dm = a.mask[ch * N + p] - a.gt_mask[ch * N + p];
             const float sm = dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f);
-            a.d_mask[ch * N + p] = up * a.w_mask * sm / (2.0f * (float)N);
+            a.d_mask[ch * N + p] = up * a.w_mask * sm * inv2N;
             float* z = ch == 0 ? a.zero_a : a.zero_b;
             if (z) z[p] = 0.f;
         } else if (a.d_dir2d != nullptr) {
             float g0 = 0.f, g1 = 0.f, gc = 0.f;
             if (a.dir2d != nullptr && a.w_orient != 0.f && a.aux[1] == 0.f) {
                 const OrientPix op = orient_pixel(a.dir2d[p], a.dir2d[N + p], a.oconf[p], a.gt_angle[p], a.gt_mask[p]);
-                const float sc = up * a.w_orient * a.gt_oconf[p] / a.aux[0];
+                const float sc = up * a.w_orient * a.gt_oconf[p] * fast_rcp(a.aux[0]);
                 g0 = sc * op.dl_dd0; g1 = sc * op.dl_dd1; gc = sc * op.dl_dconf;
             }
             a.d_dir2d[p] = g0;
