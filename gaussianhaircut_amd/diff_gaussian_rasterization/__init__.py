@@ -95,11 +95,17 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_R_HINT = {}  # device index -> binning capacity guess (1.25 x the previous frame's instance count)
+_R_HINT = {}    # device index -> binning capacity guess: 1.25 x the largest instance count of the last 64 frames
+_R_RECENT = {}  # device index -> those counts (cameras of a training set differ; a guess from the last frame alone would
+                # overflow every time a wide view follows a narrow one)
 
 
 def _note_count(dev_index, R, P):
-    _R_HINT[dev_index] = R + R // 4 + 4096
+    import collections
+    recent = _R_RECENT.setdefault(dev_index, collections.deque(maxlen=64))
+    recent.append(int(R))
+    m = max(recent)
+    _R_HINT[dev_index] = m + m // 4 + 4096
     LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
 
 

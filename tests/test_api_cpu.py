@@ -205,3 +205,16 @@ def _hair_colors(head, hair, cam):
     conf = torch.cat([z1, hair.get_orient_conf])
     depth = torch.cat([head.get_depths(cam)[m], hair.get_depths(cam)])
     return torch.cat([rgb, label, torch.ones_like(label), dir2d, conf, depth], dim=-1)
+
+
+def test_tan_half_fov_is_cached_per_tensor_version():
+    """render() needs tan(FoV/2) as a host float; for a device-resident FoV tensor that is a blocking read, so the value
+    is remembered on the tensor and refreshed only when the tensor is written (trainable FoV in the reference)."""
+    import math
+    from gaussianhaircut_amd.gaussian_renderer import _tan_half
+    fov = torch.tensor(0.8)
+    assert _tan_half(fov) == pytest.approx(math.tan(0.4))
+    assert getattr(fov, "_ghr_tan_half")[0] == fov._version
+    fov.fill_(1.0)  # in-place update bumps the version: the cache must not serve the old value
+    assert _tan_half(fov) == pytest.approx(math.tan(0.5))
+    assert _tan_half(0.6) == pytest.approx(math.tan(0.3))  # plain floats pass through

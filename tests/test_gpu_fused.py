@@ -338,6 +338,7 @@ def test_speculative_stage2_capacity_guess_never_changes_the_result(pipe):
     outs = []
     for hint in (None, 64, 10_000_000):
         dgr._R_HINT.pop(dev.index, None)
+        dgr._R_RECENT.pop(dev.index, None)
         if hint:
             dgr._R_HINT[dev.index] = hint
         model = syn.make_model(spec, dev)
