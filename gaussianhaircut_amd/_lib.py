@@ -94,7 +94,7 @@ class LossArgs(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ("image", "mask", "dir2d", "orient_conf", "gt_image", "gt_mask",
                                                "gt_orient_angle", "gt_orient_conf")] + \
                [(n, ctypes.c_float) for n in ("w_l1", "w_ssim", "w_mask", "w_orient")] + \
-               [("unmasked_colours", ctypes.c_int32)]
+               [("unmasked_colours", ctypes.c_int32), ("gt_stats", ctypes.c_void_p)]
 
 
 LOSS_SUMS = 1288  # GHR_LOSS_SUMS
@@ -110,7 +110,7 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_backward", "ghr_adam_step"]
+           "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step"]
 
 _lib = None
 
@@ -137,6 +137,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
     L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]
+    L.ghr_loss_gt_stats.argtypes = [vp, ctypes.POINTER(LossArgs), vp]
     L.ghr_loss_backward.argtypes = [vp, ctypes.POINTER(LossArgs)] + [vp] * 9
     L.ghr_adam_step.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, i32, ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, i32]

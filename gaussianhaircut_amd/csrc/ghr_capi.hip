@@ -471,12 +471,25 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
     hipStream_t s = (hipStream_t)stream;
     GHR_HIP(hipMemsetAsync(sums, 0, GHR_LOSS_SUMS * sizeof(float), s));
     ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
-                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums};
+                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums, l->gt_stats, nullptr};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
+    if (l->gt_stats) hipLaunchKernelGGL(ghr::k_loss_fwd_cached, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
     hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, l->w_l1, l->w_ssim, l->w_mask,
                        orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
                        loss_out);
+    return finish(s, 0);
+}
+
+int ghr_loss_gt_stats(void* stream, const ghr_loss_args* l, float* stats_out)
+{
+    if (!l || l->W <= 0 || l->H <= 0 || !l->gt_image || !l->gt_mask || !stats_out)
+        return fail(GHR_E_INVALID, "ghr_loss_gt_stats: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    ghr::LossArgs a{l->W, l->H, l->gt_image, nullptr, nullptr, nullptr, l->gt_image, l->gt_mask, nullptr, nullptr,
+                    l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out};
+    const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
+    hipLaunchKernelGGL(ghr::k_loss_gt_stats, grid, dim3(256), 0, s, a);
     return finish(s, 0);
 }
 

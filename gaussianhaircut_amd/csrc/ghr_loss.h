@@ -63,6 +63,8 @@ struct LossArgs {
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
     float* sums;            // [GHR_LOSS_SLOTS][GHR_LOSS_TERMS] partial sums, zeroed by the caller; block b adds into
                             // slot b % SLOTS (one hot address would serialise ~73k atomics)
+    const float* gt_stats;  // [2][3][H*W] window moments of the masked ground truth (mu2, E[y^2]) or NULL
+    float* stats_out;       // k_loss_gt_stats: where those moments go
 };
 
 // Orientation term of ONE pixel (gaussian_renderer/__init__.py:100-105 + loss_utils.py:31-47), value and the partial
@@ -135,12 +137,24 @@ __device__ __forceinline__ void block_sum_n(float* v, float (*s_red)[8])
 }
 #endif
 
-// grid (ceil(W/32), ceil(H/16), 3 colour channels), block 256
-__global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
+// Forward body in three variants (MODE):
+//   0  all five window moments (x, y, x^2, y^2, xy) of the masked render x and ground truth y
+//   1  the ground-truth moments (mu2 = w*y, E[y^2] = w*y^2) come from a.gt_stats, computed once per camera by MODE 2
+//      (ground truth and mask are constants of a training view): three moments instead of five in both passes and in
+//      LDS -- 40 % of the window arithmetic
+//   2  computes only those two moments into a.stats_out (no loss terms)
+// The arithmetic of each moment is identical in all variants, so MODE 1 + MODE 2 reproduce MODE 0 bit for bit.
+template <int MODE>
+__device__ __forceinline__ void loss_fwd_body(const LossArgs& a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr bool HAVE_X = MODE != 2;              // x, x^2, xy
+    constexpr bool HAVE_Y = MODE != 1;              // y, y^2
+    constexpr int NM = MODE == 0 ? 5 : (MODE == 1 ? 3 : 2);
+    // plane index of each moment (x, y, xx, yy, xy) in s_h
+    constexpr int PX = 0, PY = MODE == 0 ? 1 : 0, PXX = MODE == 0 ? 2 : 1, PYY = MODE == 0 ? 3 : 1, PXY = MODE == 0 ? 4 : 2;
     __shared__ __attribute__((aligned(16))) float s_x[GHR_L_EH][GHR_L_XS], s_y[GHR_L_EH][GHR_L_XS];
-    __shared__ __attribute__((aligned(16))) float s_h[5][GHR_L_EH][GHR_L_HS];
+    __shared__ __attribute__((aligned(16))) float s_h[NM][GHR_L_EH][GHR_L_HS];
     __shared__ float s_red[4][8];
     const int ch = blockIdx.z;
     const int W = a.W, H = a.H;
@@ -163,7 +177,7 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
             const bool in = i < GHR_L_EH * GHR_L_XS && lx < GHR_L_EW && gx >= 0 && gx < W && gy >= 0 && gy < H;
             const size_t p = in ? (size_t)gy * W + gx : 0;
             vm[it] = in ? (a.mask_colours ? m[p] : 1.0f) : 0.f;
-            vi[it] = in ? img[p] : 0.f;
+            vi[it] = (HAVE_X && in) ? img[p] : 0.f;
             vg[it] = in ? gt[p] : 0.f;
         }
 #pragma unroll
@@ -171,22 +185,26 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
             const int i = tid + 256 * it;
             if (i < GHR_L_EH * GHR_L_XS) {
                 const int ly = i / GHR_L_XS, lx = i - ly * GHR_L_XS;
-                s_x[ly][lx] = vi[it] * vm[it];
+                if (HAVE_X) s_x[ly][lx] = vi[it] * vm[it];
                 s_y[ly][lx] = vg[it] * vm[it];
             }
         }
     }
     __syncthreads();
-    // horizontal 11-tap pass: 26 rows x 8 groups of 4 columns, the 5 moments
+    // horizontal 11-tap pass: 26 rows x 8 groups of 4 columns
     if (tid < GHR_L_EH * (GHR_L_TW / 4)) {
         const int ly = tid >> 3, c0 = (tid & 7) * 4;
         float xs[16], ys[16];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const f4 vx = *reinterpret_cast<const f4*>(&s_x[ly][c0 + 4 * q]);
             const f4 vy = *reinterpret_cast<const f4*>(&s_y[ly][c0 + 4 * q]);
-            xs[4 * q] = vx.x; xs[4 * q + 1] = vx.y; xs[4 * q + 2] = vx.z; xs[4 * q + 3] = vx.w;
             ys[4 * q] = vy.x; ys[4 * q + 1] = vy.y; ys[4 * q + 2] = vy.z; ys[4 * q + 3] = vy.w;
+            if (HAVE_X) {
+                const f4 vx = *reinterpret_cast<const f4*>(&s_x[ly][c0 + 4 * q]);
+                xs[4 * q] = vx.x; xs[4 * q + 1] = vx.y; xs[4 * q + 2] = vx.z; xs[4 * q + 3] = vx.w;
+            } else {
+                xs[4 * q] = xs[4 * q + 1] = xs[4 * q + 2] = xs[4 * q + 3] = 0.f;
+            }
         }
         float xx[14], yy[14], xy[14];
 #pragma unroll
@@ -198,48 +216,69 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
 #pragma unroll
             for (int k = 0; k < 11; k++) {
                 const float w = c_ssim_w[k];
-                h0 = fma_(w, xs[o + k], h0); h1 = fma_(w, ys[o + k], h1); h2 = fma_(w, xx[o + k], h2);
-                h3 = fma_(w, yy[o + k], h3); h4 = fma_(w, xy[o + k], h4);
+                if (HAVE_X) { h0 = fma_(w, xs[o + k], h0); h2 = fma_(w, xx[o + k], h2); h4 = fma_(w, xy[o + k], h4); }
+                if (HAVE_Y) { h1 = fma_(w, ys[o + k], h1); h3 = fma_(w, yy[o + k], h3); }
             }
             h[0][o] = h0; h[1][o] = h1; h[2][o] = h2; h[3][o] = h3; h[4][o] = h4;
         }
-#pragma unroll
-        for (int k = 0; k < 5; k++) *reinterpret_cast<f4*>(&s_h[k][ly][c0]) = f4{h[k][0], h[k][1], h[k][2], h[k][3]};
+        if (HAVE_X) {
+            *reinterpret_cast<f4*>(&s_h[PX][ly][c0]) = f4{h[0][0], h[0][1], h[0][2], h[0][3]};
+            *reinterpret_cast<f4*>(&s_h[PXX][ly][c0]) = f4{h[2][0], h[2][1], h[2][2], h[2][3]};
+            *reinterpret_cast<f4*>(&s_h[PXY][ly][c0]) = f4{h[4][0], h[4][1], h[4][2], h[4][3]};
+        }
+        if (HAVE_Y) {
+            *reinterpret_cast<f4*>(&s_h[PY][ly][c0]) = f4{h[1][0], h[1][1], h[1][2], h[1][3]};
+            *reinterpret_cast<f4*>(&s_h[PYY][ly][c0]) = f4{h[3][0], h[3][1], h[3][2], h[3][3]};
+        }
     }
     __syncthreads();
     // vertical pass: column tx, rows 2*tr and 2*tr + 1
     const int tx = tid & 31, tr = tid >> 5;
-    float acc[2][5];
+    float acc[2][NM];
 #pragma unroll
     for (int o = 0; o < 2; o++)
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[o][k] = 0.f;
+        for (int k = 0; k < NM; k++) acc[o][k] = 0.f;
 #pragma unroll
     for (int r = 0; r < 12; r++) {
-        float v[5];
+        float v[NM];
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = s_h[k][2 * tr + r][tx];
+        for (int k = 0; k < NM; k++) v[k] = s_h[k][2 * tr + r][tx];
         if (r < 11) {
             const float w = c_ssim_w[r];
 #pragma unroll
-            for (int k = 0; k < 5; k++) acc[0][k] = fma_(w, v[k], acc[0][k]);
+            for (int k = 0; k < NM; k++) acc[0][k] = fma_(w, v[k], acc[0][k]);
         }
         if (r >= 1) {
             const float w = c_ssim_w[r - 1];
 #pragma unroll
-            for (int k = 0; k < 5; k++) acc[1][k] = fma_(w, v[k], acc[1][k]);
+            for (int k = 0; k < NM; k++) acc[1][k] = fma_(w, v[k], acc[1][k]);
         }
+    }
+    const int gx = bx + tx;
+    if (MODE == 2) {
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            const int gy = by + 2 * tr + o;
+            if (gx < W && gy < H) {
+                const size_t p = (size_t)gy * W + gx;
+                a.stats_out[(0 * 3 + ch) * N + p] = acc[o][PY];
+                a.stats_out[(1 * 3 + ch) * N + p] = acc[o][PYY];
+            }
+        }
+        return;
     }
     const bool orient = ch == 2 && a.dir2d != nullptr;
     float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // |image-gt|*m, ssim, |mask-gt_mask|, orientation num, den
-    const int gx = bx + tx;
 #pragma unroll
     for (int o = 0; o < 2; o++) {
         const int gy = by + 2 * tr + o;
         if (gx < W && gy < H) {
             const size_t p = (size_t)gy * W + gx;
             float d0, d1, d2;
-            sums[1] += ssim_point(acc[o][0], acc[o][1], acc[o][2], acc[o][3], acc[o][4], d0, d1, d2);
+            const float mu2 = MODE == 1 ? a.gt_stats[(0 * 3 + ch) * N + p] : acc[o][PY];
+            const float e22 = MODE == 1 ? a.gt_stats[(1 * 3 + ch) * N + p] : acc[o][PYY];
+            sums[1] += ssim_point(acc[o][PX], mu2, acc[o][PXX], e22, acc[o][PXY], d0, d1, d2);
             a.maps[(0 * 3 + ch) * N + p] = d0;
             a.maps[(1 * 3 + ch) * N + p] = d1;
             a.maps[(2 * 3 + ch) * N + p] = d2;
@@ -266,6 +305,11 @@ __global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a)
     }
 #endif
 }
+
+// grid (ceil(W/32), ceil(H/16), 3 colour channels), block 256
+__global__ void __launch_bounds__(256) k_loss_fwd(LossArgs a) { loss_fwd_body<0>(a); }
+__global__ void __launch_bounds__(256) k_loss_fwd_cached(LossArgs a) { loss_fwd_body<1>(a); }
+__global__ void __launch_bounds__(256) k_loss_gt_stats(LossArgs a) { loss_fwd_body<2>(a); }
 
 struct LossBwdArgs {
     int W, H;

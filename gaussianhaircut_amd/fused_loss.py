@@ -20,7 +20,7 @@ def _f32c(t):
     return t.detach().float().contiguous()
 
 
-def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf, w, unmasked=False):
+def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf, w, unmasked=False, gt_stats=None):
     a = _lib.LossArgs()
     a.W, a.H = int(W), int(H)
     a.image, a.mask, a.dir2d, a.orient_conf = image, mask, dir2d, oconf
@@ -29,7 +29,22 @@ def _args(W, H, image, mask, dir2d, oconf, gt_image, gt_mask, gt_angle, gt_oconf
     a.gt_orient_conf = _ptr(gt_oconf) if gt_oconf is not None else None
     a.w_l1, a.w_ssim, a.w_mask, a.w_orient = [float(x) for x in w]
     a.unmasked_colours = int(bool(unmasked))
+    a.gt_stats = _ptr(gt_stats) if gt_stats is not None else None
     return a
+
+
+def gt_ssim_stats(gt_image, gt_mask, mask_colours=True):
+    """[2,3,H,W] SSIM window moments of the (masked) ground truth: constants of a training view.  Pass them to
+    ``stage1_loss(..., gt_stats=)`` and its forward convolves three window moments instead of five; the values are
+    bit-identical to what it would compute itself."""
+    assert gt_image.is_cuda, "fused loss has no CPU path"
+    _, H, W = gt_image.shape
+    gi, gm = _f32c(gt_image), _f32c(gt_mask)
+    with torch.cuda.device(gi.device):
+        out = torch.empty((2, 3, H, W), dtype=torch.float32, device=gi.device)
+        a = _args(W, H, None, None, None, None, gi, gm, None, None, (0.0, 0.0, 0.0, 0.0), not mask_colours)
+        _lib.check(_lib.lib().ghr_loss_gt_stats(_stream(), ctypes.byref(a), _ptr(out)))
+    return out
 
 
 class _Stage1LossPacked(torch.autograd.Function):
@@ -37,7 +52,8 @@ class _Stage1LossPacked(torch.autograd.Function):
     (no split / cat / zero-fill kernels between the loss and the rasterizer backward)."""
 
     @staticmethod
-    def forward(ctx, renders, gt_image, gt_mask, gt_angle, gt_oconf, w_l1, w_ssim, w_mask, w_orient, unmasked=False):
+    def forward(ctx, renders, gt_image, gt_mask, gt_angle, gt_oconf, w_l1, w_ssim, w_mask, w_orient, unmasked=False,
+                gt_stats=None):
         assert renders.is_cuda, "fused loss has no CPU path"
         C, H, W = renders.shape
         assert C == _lib.NUM_CHANNELS
@@ -52,8 +68,10 @@ class _Stage1LossPacked(torch.autograd.Function):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
             sums = torch.empty(_lib.LOSS_SUMS, dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
+            if gt_stats is not None:
+                assert gt_stats.shape == (2, 3, H, W) and gt_stats.is_contiguous() and gt_stats.dtype == torch.float32
             a = _args(W, H, _off(r, 0, n), _off(r, 3, n), _off(r, 5, n), _off(r, 8, n), gt_image_c, gt_mask_c,
-                      gt_angle_c, gt_oconf_c, (w_l1, w_ssim, w_mask, w_orient if orient else 0.0), unmasked)
+                      gt_angle_c, gt_oconf_c, (w_l1, w_ssim, w_mask, w_orient if orient else 0.0), unmasked, gt_stats)
             _lib.check(_lib.lib().ghr_loss_forward(_stream(), ctypes.byref(a), _ptr(maps), _ptr(sums),
                                                    ctypes.c_void_p(loss.data_ptr())))
         ctx.save_for_backward(r, gt_image_c, gt_mask_c, maps, sums, *([gt_angle_c, gt_oconf_c] if orient else []))
@@ -76,7 +94,7 @@ class _Stage1LossPacked(torch.autograd.Function):
             _lib.check(_lib.lib().ghr_loss_backward(_stream(), ctypes.byref(a), _ptr(maps), _ptr(sums),
                                                     ctypes.c_void_p(gl.data_ptr()), _off(d, 0, n), _off(d, 3, n),
                                                     _off(d, 5, n), _off(d, 8, n), _off(d, 7, n), _off(d, 9, n)))
-        return d, None, None, None, None, None, None, None, None, None
+        return d, None, None, None, None, None, None, None, None, None, None
 
 
 class _PhotometricLoss(torch.autograd.Function):
@@ -121,11 +139,12 @@ def photometric_loss(image, mask, gt_image, gt_mask, w_l1, w_ssim, w_mask):
 
 
 def stage1_loss(renders, gt_image, gt_mask, gt_orient_angle, gt_orient_conf, w_l1, w_ssim, w_mask, w_orient,
-                mask_colours=True):
+                mask_colours=True, gt_stats=None):
     """The whole loss of src/train_gaussians.py:126-140 on the packed [10,H,W] rasterizer output ``renders``
     (channels: rgb 0-2, mask 3-4, 2D direction 5-6, orientation confidence 8):
     photometric terms + ``w_orient * or_loss(orient_angle, gt_orient_angle, orient_conf, weight=gt_orient_conf,
     mask=gt_mask[:1])`` with a NaN orientation term dropped.  ``mask_colours=False``: L1 / SSIM on the whole image, the
-    strand-stage form (src/train_strands.py:128-129)."""
+    strand-stage form (src/train_strands.py:128-129).  ``gt_stats``: optional ``gt_ssim_stats(gt_image, gt_mask,
+    mask_colours)`` of this view (same result, 40 % less window arithmetic in the forward)."""
     return _Stage1LossPacked.apply(renders, gt_image, gt_mask, gt_orient_angle, gt_orient_conf, float(w_l1),
-                                   float(w_ssim), float(w_mask), float(w_orient), not mask_colours)
+                                   float(w_ssim), float(w_mask), float(w_orient), not mask_colours, gt_stats)

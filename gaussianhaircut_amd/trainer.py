@@ -26,6 +26,27 @@ def _one_like(loss):
     return one
 
 
+CACHE_GT_SSIM_STATS = True  # keep the SSIM window moments of every camera's ground truth (2*3*H*W floats per camera)
+
+
+def _gt_stats(cam, gt_image, gt_mask, mask_colours):
+    """Ground truth and mask are constants of a training view: their SSIM window moments are computed once per camera
+    (fused_loss.gt_ssim_stats) and re-used until either tensor is replaced or written."""
+    if not CACHE_GT_SSIM_STATS:
+        return None
+    key = (gt_image.data_ptr(), gt_image._version, gt_mask.data_ptr(), gt_mask._version, tuple(gt_image.shape),
+           bool(mask_colours))
+    cached = getattr(cam, "_ghr_gt_stats", None)
+    if cached is None or cached[0] != key:
+        from .fused_loss import gt_ssim_stats
+        cached = (key, gt_ssim_stats(gt_image, gt_mask, mask_colours))
+        try:
+            cam._ghr_gt_stats = cached
+        except AttributeError:
+            return cached[1]
+    return cached[1]
+
+
 def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
     """train_gaussians.py:113-140.  On a ROCm device all four terms run as one fused HIP op."""
     image, mask = render_pkg["render"], render_pkg["mask"]
@@ -39,7 +60,8 @@ def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
         # `scale` (1/V of a V-view batch) is folded into the weights: no separate elementwise kernels around the loss
         return stage1_loss(render_pkg.renders_packed, gt_image, gt_mask, cam.original_orient_angle,
                            cam.original_orient_conf, opt.lambda_dl1 * scale, opt.lambda_dssim * scale,
-                           opt.lambda_dmask * scale, opt.lambda_dorient * scale)
+                           opt.lambda_dmask * scale, opt.lambda_dorient * scale,
+                           gt_stats=_gt_stats(cam, gt_image, gt_mask, True))
     if fused and opt.lambda_dorient == 0.0:
         from .fused_loss import photometric_loss
         return photometric_loss(image, mask, gt_image, gt_mask, opt.lambda_dl1 * scale, opt.lambda_dssim * scale,
@@ -202,7 +224,8 @@ def strand_view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
         w_conf = cam.original_orient_conf if opt.use_gt_orient_conf else torch.ones_like(gt_mask[:1])
         return stage1_loss(render_pkg.renders_packed, gt_image, gt_mask, cam.original_orient_angle, w_conf,
                            opt.lambda_dl1 * scale, opt.lambda_dssim * scale, opt.lambda_dmask * scale,
-                           opt.lambda_dorient * scale, mask_colours=False)
+                           opt.lambda_dorient * scale, mask_colours=False,
+                           gt_stats=_gt_stats(cam, gt_image, gt_mask, False))
     loss = l1_loss(image, gt_image) * opt.lambda_dl1 + (1.0 - ssim(image, gt_image)) * opt.lambda_dssim + \
         l1_loss(mask, gt_mask) * opt.lambda_dmask
     if opt.lambda_dorient != 0.0:

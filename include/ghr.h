@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 7
+#define GHR_ABI_VERSION 8
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -205,11 +205,17 @@ typedef struct ghr_loss_args {
     const float* gt_orient_conf;
     float w_l1, w_ssim, w_mask, w_orient;
     int32_t unmasked_colours;     /* != 0: L1 / SSIM on the whole image (train_strands.py:128-129) instead of * gt_mask[1] */
+    const float* gt_stats;        /* optional [2,3,H,W]: the SSIM window moments of the (masked) ground truth from
+                                     ghr_loss_gt_stats -- constants of a training view; with them ghr_loss_forward
+                                     convolves three moments instead of five, with bit-identical results */
 } ghr_loss_args;
 /* maps: 9*H*W floats of scratch kept for backward.  sums: GHR_LOSS_SUMS device floats of scratch kept for backward.
  * loss_out: device scalar. */
 #define GHR_LOSS_SUMS 1288 /* 256 slots x 5 partial sums + {sum of orientation weights, NaN flag} + pad */
 int ghr_loss_forward(void* stream, const ghr_loss_args* a, float* maps, float* sums, float* loss_out);
+/* stats_out [2,3,H,W] = {w * y, w * y^2} per colour channel, y = gt_image (* gt_mask[1] unless unmasked_colours), w the
+ * 11x11 window of loss_utils.py:91-121.  Reads only W, H, gt_image, gt_mask, unmasked_colours of `a`. */
+int ghr_loss_gt_stats(void* stream, const ghr_loss_args* a, float* stats_out);
 /* grad_loss: device scalar dL/dloss (NULL = 1).  d_image [3,H,W], d_mask [2,H,W] fully written; d_dir2d [2,H,W] and
  * d_orient_conf [1,H,W] (both or neither; zeros when the orientation term is off or was NaN); zero_plane_a/b: optional
  * H*W planes to zero-fill (the channels of a packed [10,H,W] gradient that no loss term touches). */

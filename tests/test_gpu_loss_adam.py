@@ -171,3 +171,37 @@ def test_fused_strand_stage_loss_unmasked_colours_matches_torch():
     x, y = a.grad.cpu().numpy(), b.grad.cpu().numpy()
     for lo_, hi_ in ((0, 3), (3, 5)):
         assert np.abs(x[lo_:hi_] - y[lo_:hi_]).max() <= 2e-4 * np.abs(y[lo_:hi_]).max()
+
+
+@pytest.mark.parametrize("H,W,mask_colours", [(48, 64, True), (37, 70, False), (270, 480, True), (1080, 1920, True)])
+def test_cached_ground_truth_window_moments_give_bit_identical_loss(H, W, mask_colours):
+    """gt_ssim_stats(): the SSIM window moments of the (masked) ground truth are constants of a training view; with
+    them the forward convolves three moments instead of five.  Same arithmetic per moment => same bits: loss value and
+    every gradient element."""
+    from gaussianhaircut_amd.fused_loss import gt_ssim_stats, stage1_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(H + 3 * W)
+    gt = torch.rand(3, H, W, generator=g)
+    r = torch.rand(10, H, W, generator=g)
+    r[5:8] = torch.randn(3, H, W, generator=g) * 0.3
+    r[8] = r[8] * 2 + 0.05
+    gt_mask = (torch.rand(2, H, W, generator=g) > 0.35).float()
+    gt_angle, gt_oconf = torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    consts = [t.to(dev) for t in (gt, gt_mask, gt_angle, gt_oconf)]
+    stats = gt_ssim_stats(consts[0], consts[1], mask_colours)
+    assert stats.shape == (2, 3, H, W) and torch.isfinite(stats).all()
+    # spot check against torch: mu2 = conv(y), E[y^2] = conv(y^2) with the reference's 11x11 window (zero padding)
+    from gaussianhaircut_amd.utils.loss_utils import _window
+    y = consts[0] * (consts[1][1:] if mask_colours else 1.0)
+    win = _window(11, 3, y)
+    mu = torch.nn.functional.conv2d(y[None], win, padding=5, groups=3)[0]
+    e2 = torch.nn.functional.conv2d((y * y)[None], win, padding=5, groups=3)[0]
+    assert torch.allclose(stats[0], mu, atol=2e-6) and torch.allclose(stats[1], e2, atol=2e-6)
+    outs = []
+    for st in (None, stats):
+        a = r.to(dev).requires_grad_(True)
+        loss = stage1_loss(a, *consts, 0.8, 0.2, 0.2, 0.1, mask_colours=mask_colours, gt_stats=st)
+        loss.backward()
+        outs.append((loss.detach().clone(), a.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
