@@ -34,17 +34,17 @@ def _gt_stats(cam, gt_image, gt_mask, mask_colours):
     (fused_loss.gt_ssim_stats) and re-used until either tensor is replaced or written."""
     if not CACHE_GT_SSIM_STATS:
         return None
-    key = (gt_image.data_ptr(), gt_image._version, gt_mask.data_ptr(), gt_mask._version, tuple(gt_image.shape),
-           bool(mask_colours))
+    key = (gt_image._version, gt_mask._version, bool(mask_colours))
     cached = getattr(cam, "_ghr_gt_stats", None)
-    if cached is None or cached[0] != key:
+    # the entry holds the two tensors themselves: identity (not an address that the allocator may hand out again)
+    if cached is None or cached[0] is not gt_image or cached[1] is not gt_mask or cached[2] != key:
         from .fused_loss import gt_ssim_stats
-        cached = (key, gt_ssim_stats(gt_image, gt_mask, mask_colours))
+        cached = (gt_image, gt_mask, key, gt_ssim_stats(gt_image, gt_mask, mask_colours))
         try:
             cam._ghr_gt_stats = cached
         except AttributeError:
-            return cached[1]
-    return cached[1]
+            pass
+    return cached[3]
 
 
 def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
