@@ -110,7 +110,7 @@ def test_multi_stream_views_equal_sequential_views():
     scale = float(ref_grad.abs().max())
     assert scale > 0
     for losses, grad in runs[1:]:
-        assert abs(losses[0] - ref_loss[0]) <= 1e-6 * abs(ref_loss[0])
+        assert abs(losses[0] - ref_loss[0]) <= 5e-6 * abs(ref_loss[0])  # partial sums meet in float atomics
         assert float((grad - ref_grad).abs().max()) <= 1e-5 * scale
 
 
@@ -169,7 +169,7 @@ def test_deferred_counts_recover_from_a_too_small_capacity_guess():
     scale = float(ref.abs().max())
     for mode in ("defer_ok", "defer_overflow"):
         loss, g = grads[mode]
-        assert abs(loss - ref_loss) <= 1e-6 * abs(ref_loss)
+        assert abs(loss - ref_loss) <= 5e-6 * abs(ref_loss)  # partial sums meet in float atomics
         assert float((g - ref).abs().max()) <= 1e-5 * scale
 
 
