@@ -104,8 +104,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         if (q == 0) rects[idx].w = slot_blk[idx >> 8];  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
     }
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
-    const int w = x1 - x0, area = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
-    const uint64_t key = area ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;
+    const int w = x1 - x0, full = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
+    const bool big = full > GHR_BIG_RECT;  // walked by the whole wave below
+    const int area = big ? 0 : full;
+    const uint64_t key = full ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;
     int max_area = area;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));  // same in all 4 rows
@@ -118,6 +120,21 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         if (on && tile_start[t] + pos < cap) keys[tile_start[t] + pos] = key;  // cap: see ghr_forward_stage2
         kx += 4;
         while (on && kx >= w) { kx -= w; ky++; }
+    }
+    // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- take it from row 0
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(big) & 0xffffull;
+    while (todo) {  // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bw = __shfl(w, src), bn = __shfl(full, src);
+        const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, src), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
+        const uint64_t bkey = ((uint64_t)khi << 32) | klo;
+        for (int k = lane; k < bn; k += 64) {
+            const int by = k / bw;
+            const int t = (by0 + by) * gx + bx0 + (k - by * bw);
+            const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
+            if (pos < cap) keys[pos] = bkey;
+        }
     }
 #endif
 }

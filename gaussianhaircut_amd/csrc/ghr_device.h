@@ -120,7 +120,48 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uin
     ga[8] = s2.x; ga[9] = s2.y; ga[10] = s2.z; ga[11] = s2.w; ga[12] = s3.x; ga[13] = s3.y; ga[14] = s3.z; ga[15] = s3.w;
 }
 
+// Rects with more tiles than this are not walked by their own lane: a lane's loop over a 20 x 20-tile splat (one atomic
+// or one 64-B line per step, dependent latency each) used to set the duration of the whole kernel (cfg2: the largest of
+// 97 k random blobs covers 484 tiles; k_preprocess 130 us, k_scatter 99 us, k_geom_bwd 79 us).  The wave walks them
+// together, 64 tiles per step.
+#define GHR_BIG_RECT 32
+
 #if defined(__HIP_DEVICE_COMPILE__)
+// Sum of the instance gradient lines for every lane's Gaussian.  Small rects: per lane (gather_inst_grads, ascending
+// ordinal).  Big rects: one at a time by the whole wave -- lane l sums the lines l, l+64, ... (coalesced), then a
+// butterfly over the 64 lanes; the order differs from the sequential one but is fixed.  All lanes of the wave call it.
+__device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const rect4& r, float* ga, uint32_t rows)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t cnt = rect4_area(r);
+    const bool big = cnt > GHR_BIG_RECT;
+    rect4 small = r;
+    if (big) { small.x = 0u; small.y = 0u; }  // empty rect: nothing to read
+    gather_inst_grads(ginst, small, ga, rows);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
+    while (todo) {  // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const uint32_t first = (uint32_t)__shfl((int)(r.z + r.w), src);
+        uint32_t n = (uint32_t)__shfl((int)cnt, src);
+        if ((uint64_t)first + n > (uint64_t)rows) n = 0;  // see gather_inst_grads
+        const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)first;
+        f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        for (uint32_t k = lane; k < n; k += 64) {
+            const f4* q = p + 4 * (size_t)k;
+            s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+        }
+        float v[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+#pragma unroll
+        for (int c = 0; c < 16; c++)
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v[c] += __shfl_xor(v[c], off);
+        if (lane == src)
+#pragma unroll
+            for (int c = 0; c < 16; c++) ga[c] = v[c];
+    }
+}
+
 // Exclusive prefix sum of n over the 256 threads of the workgroup (thread order); *total = sum.  Every thread of the
 // workgroup must call it.  s_tmp: 4 LDS words.
 __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t n, uint32_t* s_tmp, uint32_t* total)

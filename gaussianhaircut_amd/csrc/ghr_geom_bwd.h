@@ -169,11 +169,14 @@ GHR_HD void geom_bwd_one(const GeomBwdArgs& a, int idx, const float* g)
 
 __global__ void __launch_bounds__(GHR_BLOCK) k_geom_bwd(GeomBwdArgs a)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
+    rect4 r = make_rect4(0, 0, 0, 0, 0u);
+    if (idx < a.P) r = a.rects[idx];
     float ga[16];
-    gather_inst_grads(a.ginst, a.rects[idx], ga);
-    geom_bwd_one(a, idx, ga);
+    gather_inst_grads_wave(a.ginst, r, ga, 0xffffffffu);  // every lane of the wave takes part
+    if (idx < a.P) geom_bwd_one(a, idx, ga);
+#endif
 }
 
 }  // namespace ghr

@@ -165,7 +165,9 @@ GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1,
 // their k-th tile in lockstep, so neighbouring Gaussians with equal rects merge perfectly.  All lanes of the wave call it.
 __device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1)
 {
-    const int w = x1 - x0, area = w * (y1 - y0);
+    const int w = x1 - x0, full = w * (y1 - y0);
+    const bool big = full > GHR_BIG_RECT;
+    const int area = big ? 0 : full;
     int max_area = area;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
@@ -173,6 +175,18 @@ __device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0
     for (int k = 0; k < max_area; k++) {
         wave_inc(tile_count, (uint32_t)t, k < area, false);
         if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+    }
+    // big rects (GHR_BIG_RECT): one at a time, 64 distinct tiles per step
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
+    while (todo) {  // wave-uniform
+        const int src = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bw = __shfl(w, src), bn = __shfl(full, src);
+        for (int k = lane; k < bn; k += 64) {
+            const int ky = k / bw;
+            atomicAdd(&tile_count[(by0 + ky) * gx + bx0 + (k - ky * bw)], 1u);
+        }
     }
 }
 #endif

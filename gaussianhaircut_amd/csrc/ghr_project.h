@@ -645,7 +645,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     f4 v[GHR_SLAB_IT];
     if (row > 0) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     float ga[16];
-    gather_inst_grads(g.ginst, r, ga, g.ginst_rows);
+    gather_inst_grads_wave(g.ginst, r, ga, g.ginst_rows);
     if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     bool bad = false;
