@@ -123,8 +123,10 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uin
 // Rects with more tiles than this are not walked by their own lane: a lane's loop over a 20 x 20-tile splat (one atomic
 // or one 64-B line per step, dependent latency each) used to set the duration of the whole kernel (cfg2: the largest of
 // 97 k random blobs covers 484 tiles; k_preprocess 130 us, k_scatter 99 us, k_geom_bwd 79 us).  The wave walks them
-// together, 64 tiles per step.
-#define GHR_BIG_RECT 32
+// together, 64 tiles per step.  Thresholds measured on cfg2 (8 / 16 / 32): counting + scatter 73 / 96 / 106 us, gather
+// 92 / 39 / 29 us (its cooperative step ends in a 64-lane butterfly over 16 values); cfg3's needles (<= 9 tiles) do not care.
+#define GHR_BIG_RECT 8     // tile counting, scatter
+#define GHR_BIG_GATHER 32  // gradient-line gather
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Sum of the instance gradient lines for every lane's Gaussian.  Small rects: per lane (gather_inst_grads, ascending
@@ -134,7 +136,7 @@ __device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const
 {
     const int lane = threadIdx.x & 63;
     const uint32_t cnt = rect4_area(r);
-    const bool big = cnt > GHR_BIG_RECT;
+    const bool big = cnt > GHR_BIG_GATHER;
     rect4 small = r;
     if (big) { small.x = 0u; small.y = 0u; }  // empty rect: nothing to read
     gather_inst_grads(ginst, small, ga, rows);
