@@ -66,8 +66,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
-    rank, world = init_distributed()
+    # GHR_BENCH_BACKEND=gloo + GHR_BENCH_SHARE_GPU=1: functional check of the N > 1 path on a box with fewer GPUs than
+    # ranks (ranks share devices, the gradient all-reduce goes through gloo); never a performance number
+    share = os.environ.get("GHR_BENCH_SHARE_GPU") == "1"
+    rank, world = init_distributed(backend=os.environ.get("GHR_BENCH_BACKEND") or None)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if share:
+        local_rank %= torch.cuda.device_count()
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -141,10 +146,18 @@ def main():
     model.optimizer.state_dev[1:2].zero_()
     model.optimizer._direct_backwards = 0
     torch.cuda.synchronize()
+    replicas_identical = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # identical reduced gradients + identical Adam => the replicas must still be bit-identical
+        bits = model.optimizer.flat_param.view(torch.int32).to(torch.int64)
+        ck = torch.stack([bits.sum(), (bits * (torch.arange(bits.numel(), device=dev) % 8191 + 1)).sum()])
+        lo, hi = ck.clone(), ck.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
 
     stats = dict(dgr.LAST_STATS)
     P_model = spec.P
@@ -189,6 +202,8 @@ def main():
                        if fwd_avg > 0 else None},
         "roofline": roofline,
     }
+    if replicas_identical is not None:
+        out["replicas_identical"] = replicas_identical
 
     if rank == 0 and world == 1:
         # BASELINE.json configs[2]: the same stage-1 step with ONE view per gradient step
