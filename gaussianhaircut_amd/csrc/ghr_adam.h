@@ -14,7 +14,8 @@ namespace ghr {
 #define GHR_ADAM_MAX_GROUPS 16
 
 struct AdamArgs {
-    long long n;          // total elements
+    long long begin;      // first element of the range this launch updates
+    long long n;          // one past its last element (group lookup is by absolute index)
     float* p;             // flat parameters
     float* g;             // flat gradients (zeroed on exit when zero_grad != 0)
     float* m;             // exp_avg
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
     const double bias1 = 1.0 - pow(a.beta1, (double)step);
     const float bias2_sqrt = (float)sqrt(1.0 - pow(a.beta2, (double)step));
     const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+    for (long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         if (!skip) {
             int gi = 0;
             while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;

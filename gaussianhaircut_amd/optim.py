@@ -173,6 +173,42 @@ class FusedAdam:
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
                                                 self.betas[0], self.betas[1], self.eps, guard, int(zero_grad)))
 
+    def _chunk_ranges(self, chunks: int):
+        n = self.flat_param.numel()
+        per = -(-n // max(int(chunks), 1))
+        per = -(-per // 1024) * 1024  # whole 4-KiB pieces
+        return [(a, min(a + per, n)) for a in range(0, n, per)]
+
+    def step_chunked(self, chunks: int = 4, zero_grad: bool = True, reduce: bool = False):
+        """The same update as ``step(nan_scan=False)`` applied range by range (``ghr_adam_step_range``).  With
+        ``reduce`` (more than one rank) every range's gradient all-reduce is started up front and the range is updated
+        as soon as its sum has arrived, so all but the last chunk of the Adam pass runs under the remaining
+        communication.  The skip-on-NaN decision must be known before the first range is touched: the flag the fused
+        backward maintains is exact for this rank's gradients and is OR-ed over the ranks first (4 bytes).  Only valid
+        when every gradient of the step came through the fused renderer's direct backward (as with ``nan_scan=False``);
+        a NaN that only appears in the cross-rank sum (+inf on one rank, -inf on another) is not caught."""
+        assert self._direct_backwards > 0 or not self.nan_guard, "step_chunked needs the producer-side NaN flag"
+        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        guard = 2 if self.nan_guard else 0
+        self._direct_backwards = 0
+        self._acc_event = None
+        ranges = self._chunk_ranges(chunks)
+        works = None
+        if reduce and dist.is_initialized() and dist.get_world_size() > 1:
+            flag = self.state_dev[1:2]
+            flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
+            works = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in ranges]
+            flag_work.wait()
+        n = self.flat_param.numel()
+        with torch.cuda.device(self.flat_param.device):
+            for i, (a, b) in enumerate(ranges):
+                if works is not None:
+                    works[i].wait()  # orders the current stream behind this chunk's collective
+                _lib.check(_lib.lib().ghr_adam_step_range(
+                    _stream(), n, a, b - a, _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
+                    _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
+                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(ranges) - 1)))
+
     def state_dict(self):
         return {"flat_param": self.flat_param, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
                 "state": self.state_dev, "lrs": [g["lr"] for g in self.param_groups],

@@ -2,6 +2,7 @@
 densification / logging / GUI -- lr schedule, render, losses, backward, [grad all-reduce], NaN guard, Adam."""
 from __future__ import annotations
 
+import os
 from types import SimpleNamespace
 from typing import List, Optional
 
@@ -26,6 +27,7 @@ def _one_like(loss):
     return one
 
 
+OVERLAP_ALL_REDUCE_WITH_ADAM = os.environ.get("GHR_OVERLAP_AR_ADAM", "1") != "0"
 CACHE_GT_SSIM_STATS = True  # keep the SSIM window moments of every camera's ground truth (2*3*H*W floats per camera)
 
 
@@ -164,9 +166,19 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
         # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no
         # other rank contributes: the guard needs no scan over the gradients
-        direct_all = gaussians.optimizer._direct_backwards == len(cams) and _world_size() == 1
+        direct_local = gaussians.optimizer._direct_backwards == len(cams)
+        # The choice below must be the same on every rank (it decides the sequence of collectives): it only depends on
+        # the configuration (`fused_sink`), and a rank whose gradients did not all come through the direct backward
+        # fails loudly instead of silently taking the other branch.
+        if _world_size() > 1 and fused_sink and len(cams) > 0 and OVERLAP_ALL_REDUCE_WITH_ADAM:
+            if not direct_local:
+                raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
+                                   (gaussians.optimizer._direct_backwards, len(cams)))
+            # all-reduce in chunks, each chunk's Adam update as soon as its sum is there (FusedAdam.step_chunked)
+            gaussians.optimizer.step_chunked(chunks=4, zero_grad=True, reduce=True)
+            return total
         gaussians.optimizer.all_reduce()
-        gaussians.optimizer.step(zero_grad=True, nan_scan=not direct_all)
+        gaussians.optimizer.step(zero_grad=True, nan_scan=not (direct_local and _world_size() == 1))
         return total
     if bucket is not None:
         bucket.all_reduce()

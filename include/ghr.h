@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 8
+#define GHR_ABI_VERSION 9
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -233,6 +233,13 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, c
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
                   int32_t nan_guard, int32_t zero_grad);
+/* The same update restricted to the elements [begin, begin + count) of the n-element buffers (pointers, groups and n
+ * as for the whole buffer), so a step can be applied chunk by chunk as the chunks of an all-reduce arrive.  Every
+ * chunk of a step sees the same step number; `last` != 0 on the final chunk advances the counter and clears the
+ * flag.  nan_guard 1 (scan) is only accepted for the whole buffer. */
+int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, float* p, float* g, float* m, float* v,
+                        int32_t* state, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
+                        double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last);
 
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

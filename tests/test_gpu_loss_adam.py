@@ -74,6 +74,40 @@ def test_fused_adam_matches_torch_adam_and_nan_guard():
     assert float(fa.flat_grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("chunks", [1, 3, 4, 7])
+def test_chunked_adam_equals_whole_buffer_adam_bit_for_bit(chunks):
+    """FusedAdam.step_chunked (the update applied range by range, as the chunks of the gradient all-reduce arrive) must
+    be the same update as step(): parameters, both moments, step counter, cleared gradients -- and the same skip when the
+    producer-side NaN flag is up."""
+    from gaussianhaircut_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3001, 3), (3001, 1, 3), (3001, 15, 3), (3001, 1), (3001, 4)]   # group ends not multiples of the chunking
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 0.05, 1e-3]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    opts = []
+    for _ in range(2):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        opts.append(FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))],
+                              eps=1e-15))
+    whole, chunked = opts
+    assert len(chunked._chunk_ranges(chunks)) >= 1 and chunked._chunk_ranges(chunks)[-1][1] == chunked.flat_param.numel()
+    for it in range(4):
+        grad = torch.randn(whole.flat_grad.numel(), generator=g).to(dev) * (10.0 ** (it - 2))
+        nan_step = it == 2
+        for o in opts:
+            o.flat_grad.copy_(grad)
+            o._direct_backwards = 1          # "every gradient came through the fused backward"
+            if nan_step:
+                o.state_dev[1] = 1           # ... which raised its flag
+        whole.step(zero_grad=True, nan_scan=False)
+        chunked.step_chunked(chunks=chunks, zero_grad=True)
+        torch.cuda.synchronize()
+        for name in ("flat_param", "exp_avg", "exp_avg_sq", "flat_grad", "state_dev"):
+            assert torch.equal(getattr(whole, name), getattr(chunked, name)), (it, name)
+    assert int(whole.state_dev[0]) == 3 and int(whole.state_dev[1]) == 0   # three applied steps, one skipped
+
+
 def _torch_stage1(renders, gt_image, gt_mask, gt_angle, gt_oconf, w):
     """The reference's loss code path on the packed output (gaussian_renderer/__init__.py:100-105 +
     train_gaussians.py:126-140), PyTorch autograd."""
