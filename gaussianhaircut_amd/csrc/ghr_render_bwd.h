@@ -29,6 +29,10 @@
 #pragma once
 #include "ghr_device.h"
 
+#ifndef GHR_COMMON_MIN
+#define GHR_COMMON_MIN 8  // batch entries common to a strip's four cells from which the wave-wide path pays
+#endif
+
 namespace ghr {
 
 typedef float f2 __attribute__((ext_vector_type(2)));  // pairs of channels: v_pk_mul_f32 / v_pk_fma_f32 (2 flops/lane/issue)
@@ -291,7 +295,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             // lane l adds component l of the cell's total: 16 lanes -> one 64-B line, resolved in this XCD's L2
             __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + l, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        if (n_common < 8) {
+        if (n_common < GHR_COMMON_MIN) {
             // Needle lists (the common case for strands): every cell walks ITS list over the whole batch without
             // waiting for the other three at the 64-entry boundaries (measured on cfg3: 12 % fewer wave passes than
             // re-synchronising per 64 entries).  Divergent per GROUP: the 16 lanes of a DPP row share k / cur.
