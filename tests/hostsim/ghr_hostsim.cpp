@@ -7,13 +7,16 @@
 // barriers) is covered by the `-m gpu` parity tests.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
 #include "../../include/ghr.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_adam.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_binning.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_geom_bwd.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_loss.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_preprocess.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_project.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_render_bwd.h"
@@ -305,6 +308,38 @@ int ghrsim_bitonic(uint64_t* keys, uint32_t n)
     for (uint32_t i = 1; i < n; i++)
         if (keys[i - 1] > keys[i]) return 0;
     return 1;
+}
+
+// ---- per-pixel / per-element arithmetic of the fused loss and of fused Adam (csrc/ghr_loss.h, csrc/ghr_adam.h) --------
+// out[i] = {l, dl/dd0, dl/dd1, dl/dconf} of the orientation term of one pixel
+void ghrsim_orient_pixel(int n, const float* d0, const float* d1, const float* conf, const float* gt, const float* m,
+                         float* out)
+{
+    for (int i = 0; i < n; i++) {
+        const ghr::OrientPix o = ghr::orient_pixel(d0[i], d1[i], conf[i], gt[i], m[i]);
+        out[4 * i] = o.l; out[4 * i + 1] = o.dl_dd0; out[4 * i + 2] = o.dl_dd1; out[4 * i + 3] = o.dl_dconf;
+    }
+}
+
+// out[i] = {ssim, d/dmu1, d/dE[x^2], d/dE[xy]}
+void ghrsim_ssim_point(int n, const float* mu1, const float* mu2, const float* e11, const float* e22, const float* e12,
+                       float* out)
+{
+    for (int i = 0; i < n; i++) {
+        float a, b, c;
+        out[4 * i] = ghr::ssim_point(mu1[i], mu2[i], e11[i], e22[i], e12[i], a, b, c);
+        out[4 * i + 1] = a; out[4 * i + 2] = b; out[4 * i + 3] = c;
+    }
+}
+
+// one Adam step with k_adam's scalar preparation (step = 1-based step number)
+void ghrsim_adam(int n, float* p, const float* g, float* m, float* v, float lr, double beta1, double beta2, float eps,
+                 int step)
+{
+    const double bias1 = 1.0 - pow(beta1, (double)step);
+    const float bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
+    const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), b2 = (float)beta2;
+    for (int i = 0; i < n; i++) ghr::adam_update(p[i], g[i], m[i], v[i], (float)((double)lr / bias1), w1, b2, w2, eps, bias2_sqrt);
 }
 
 }  // extern "C"
