@@ -187,7 +187,6 @@ class FusedAdam:
         backward maintains is exact for this rank's gradients and is OR-ed over the ranks first (4 bytes).  Only valid
         when every gradient of the step came through the fused renderer's direct backward (as with ``nan_scan=False``);
         a NaN that only appears in the cross-rank sum (+inf on one rank, -inf on another) is not caught."""
-        assert self._direct_backwards > 0 or not self.nan_guard, "step_chunked needs the producer-side NaN flag"
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 2 if self.nan_guard else 0
         self._direct_backwards = 0

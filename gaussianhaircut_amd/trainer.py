@@ -161,7 +161,10 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         sink._direct_backwards = 0
         sink._acc_event = None
         losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, pipe, 0, sink)
-    total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
+    if not losses:  # a rank without views in this step still takes part in the collectives and the update
+        total = torch.zeros((), device=background.device)
+    else:
+        total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
     if isinstance(gaussians.optimizer, FusedAdam):
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
         # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no
@@ -170,7 +173,7 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         # The choice below must be the same on every rank (it decides the sequence of collectives): it only depends on
         # the configuration (`fused_sink`), and a rank whose gradients did not all come through the direct backward
         # fails loudly instead of silently taking the other branch.
-        if _world_size() > 1 and fused_sink and len(cams) > 0 and OVERLAP_ALL_REDUCE_WITH_ADAM:
+        if _world_size() > 1 and fused_sink and OVERLAP_ALL_REDUCE_WITH_ADAM:
             if not direct_local:
                 raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
                                    (gaussians.optimizer._direct_backwards, len(cams)))
