@@ -218,3 +218,26 @@ def test_tan_half_fov_is_cached_per_tensor_version():
     fov.fill_(1.0)  # in-place update bumps the version: the cache must not serve the old value
     assert _tan_half(fov) == pytest.approx(math.tan(0.5))
     assert _tan_half(0.6) == pytest.approx(math.tan(0.3))  # plain floats pass through
+
+
+def test_capacity_guess_follows_the_largest_recent_count():
+    """The speculative binning capacity is 1.25 x the largest instance count of the last 64 frames (+4096): a narrow
+    view after a wide one must not shrink it, and it must forget counts that left the window."""
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    saved = (dict(dgr._R_HINT), dict(dgr._R_RECENT), dict(dgr.LAST_STATS))
+    try:
+        dgr._R_HINT.pop(7, None)
+        dgr._R_RECENT.pop(7, None)
+        dgr._note_count(7, 1000, 10)
+        assert dgr._R_HINT[7] == 1000 + 250 + 4096 and dgr.LAST_STATS["num_rendered"] == 1000
+        dgr._note_count(7, 100, 10)                      # narrow view: the guess keeps covering the wide one
+        assert dgr._R_HINT[7] == 1000 + 250 + 4096 and dgr.LAST_STATS["num_rendered"] == 100
+        dgr._note_count(7, 4000, 10)
+        assert dgr._R_HINT[7] == 4000 + 1000 + 4096
+        for _ in range(64):                              # the wide views leave the window
+            dgr._note_count(7, 200, 10)
+        assert dgr._R_HINT[7] == 200 + 50 + 4096
+    finally:
+        dgr._R_HINT.clear(); dgr._R_HINT.update(saved[0])
+        dgr._R_RECENT.clear(); dgr._R_RECENT.update(saved[1])
+        dgr.LAST_STATS.update(saved[2])
