@@ -230,7 +230,7 @@ def main():
         dist.destroy_process_group()
 
 
-def op_only_bench(dev, cfg="cfg2", iters=20, warm=5):
+def op_only_bench(dev, cfg="cfg2", iters=50, warm=10):  # 10 warm-up + 50 timed, median and p10 / p90
     """Rasterizer op alone -- the product's GaussianRasterizer autograd op (mode A: conic + colours precomputed, what
     render() hands it), forward and backward: BASELINE.json configs[1], Gaussians / (t_fwd + t_bwd)."""
     from gaussianhaircut_amd import diff_gaussian_rasterization as dgr
@@ -262,8 +262,11 @@ def op_only_bench(dev, cfg="cfg2", iters=20, warm=5):
             tb.append(e[1].elapsed_time(e[2]))
     tf.sort(), tb.sort()
     mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
+    pct = lambda v, q: round(v[min(len(v) - 1, int(q * len(v)))], 4)
     return {"workload": spec.name, "P": ri["P"], "num_rendered": dgr.LAST_STATS["num_rendered"], "fwd_ms": round(mf, 4),
             "bwd_ms": round(mb, 4), "gaussians_per_sec_fwd_bwd": round(ri["P"] / ((mf + mb) * 1e-3), 1),
+            "fwd_ms_p10_p90": [pct(tf, 0.1), pct(tf, 0.9)], "bwd_ms_p10_p90": [pct(tb, 0.1), pct(tb, 0.9)],
+            "iters": iters, "warmup": warm,
             "note": "GaussianRasterizer op (autograd, workspace allocation and the num_rendered read included)"}
 
 
