@@ -241,3 +241,17 @@ def test_capacity_guess_follows_the_largest_recent_count():
         dgr._R_HINT.clear(); dgr._R_HINT.update(saved[0])
         dgr._R_RECENT.clear(); dgr._R_RECENT.update(saved[1])
         dgr.LAST_STATS.update(saved[2])
+
+
+@pytest.mark.parametrize("n,chunks", [(1, 4), (1023, 4), (1024, 4), (4097, 4), (30_500_000, 4), (30_500_000, 1), (5000, 64)])
+def test_adam_chunk_ranges_tile_the_buffer(n, chunks):
+    """FusedAdam.step_chunked walks `_chunk_ranges`: consecutive, non-empty, 4-KiB aligned starts, exactly covering [0, n)
+    with at most `chunks` pieces."""
+    from types import SimpleNamespace
+    from gaussianhaircut_amd.optim import FusedAdam
+    ranges = FusedAdam._chunk_ranges(SimpleNamespace(flat_param=torch.empty(n)), chunks)
+    assert 1 <= len(ranges) <= max(chunks, 1)
+    assert ranges[0][0] == 0 and ranges[-1][1] == n
+    for (a, b), (c, d) in zip(ranges, ranges[1:]):
+        assert b == c
+    assert all(a < b and a % 1024 == 0 for a, b in ranges)
