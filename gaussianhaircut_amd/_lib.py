@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GHR_LIB_PATH") or os.path.join(CSRC, "libghr_hip.so")  # override: kernel experiments
 SOURCES = ["ghr_capi.hip"]
-HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h",
+HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h", "ghr_render_bwd2.h",
            "ghr_geom_bwd.h", "ghr_project.h", "ghr_loss.h", "ghr_adam.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
                "-shared"]
@@ -108,7 +108,7 @@ class WsView(ctypes.Structure):
 
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
-           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_model_forward_stage1",
+           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_selftest_wave", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
            "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range"]
@@ -136,6 +136,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
+    L.ghr_selftest_wave.argtypes = [vp, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
     L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]
     L.ghr_loss_gt_stats.argtypes = [vp, ctypes.POINTER(LossArgs), vp]

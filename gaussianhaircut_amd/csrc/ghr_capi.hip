@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "ghr_binning.h"
@@ -17,6 +18,7 @@
 #include "ghr_preprocess.h"
 #include "ghr_project.h"
 #include "ghr_render_bwd.h"
+#include "ghr_render_bwd2.h"
 #include "ghr_render_fwd.h"
 
 namespace {
@@ -24,6 +26,27 @@ namespace {
 thread_local char g_err[512] = "";
 // Process-wide (NOT thread_local): torch's autograd engine calls ghr_backward from its own worker thread.
 hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
+
+// K8 variant: 1 = scan form (k_render_bwd_scan, lanes bound to pairs, MFMA reduction; default), 0 = cell-group form
+// (k_render_bwd).  GHR_K8=cell|scan overrides (kernel experiments, A/B timing); both leave the same line format.
+int k8_variant()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char* e = std::getenv("GHR_K8");
+        v = (e && std::strcmp(e, "cell") == 0) ? 0 : 1;
+    }
+    return v;
+}
+
+template <typename... Args>
+void launch_k8(uint32_t T, hipStream_t s, Args... args)
+{
+    if (k8_variant() == 1)
+        hipLaunchKernelGGL(ghr::k_render_bwd_scan, dim3(ghr::xcd_grid(T)), dim3(GHR_BLOCK), 0, s, args...);
+    else
+        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid(T)), dim3(GHR_BLOCK), 0, s, args...);
+}
 
 int fail(int code, const char* fmt, const char* detail = "")
 {
@@ -258,9 +281,9 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
 
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
-        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
-                           (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, im.final_T, im.n_contrib,
-                           dL_dpix, g.rects, grad_scratch, R);
+        launch_k8((uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
+                  (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, a->background, (const float*)im.final_T,
+                  (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -268,7 +291,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.ginst = grad_scratch; ga.rects = g.rects;
+    ga.ginst = grad_scratch; ga.rects = g.rects; ga.rec = g.rec; ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
@@ -382,9 +405,9 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
     carve_bin(align_base(bin_ws), (size_t)R, &b);
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, W, H, gx, (uint32_t)T,
-                       im.tile_start, b.point_list, g.rec, background, im.final_T, im.n_contrib, dL_dpix, g.rects,
-                       grad_scratch, R);
+    launch_k8((uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start, (const uint32_t*)b.point_list,
+              (const ghr::f4*)g.rec, background, (const float*)im.final_T, (const uint32_t*)im.n_contrib, dL_dpix,
+              (const ghr::rect4*)g.rects, grad_scratch, R);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }
@@ -408,6 +431,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     a.radii = const_cast<int*>(radii);
     a.rects = g.rects;
+    a.rec = g.rec;  // the gather unpacks the gradient lines with the pixel mean / conic / opacity k_project stored
     ghr::ModelGrads mg;
     mg.ginst = grad_scratch; mg.ginst_rows = grad_rows ? grad_rows : 0xffffffffu; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
@@ -557,6 +581,13 @@ int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float*
     hipLaunchKernelGGL(ghr::k_mark_visible, dim3((P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, P, means3D,
                        viewmatrix, present);
     return finish(s, 0);
+}
+
+int ghr_selftest_wave(void* stream, const float* in, float* out)
+{
+    if (!in || !out) return fail(GHR_E_INVALID, "ghr_selftest_wave: NULL buffer");
+    hipLaunchKernelGGL(ghr::k_wave_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
+    return finish((hipStream_t)stream, 1);
 }
 
 int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop)

@@ -92,19 +92,71 @@ GHR_HD uint32_t rect4_slot(const rect4& r, int tx, int ty)
     return r.z + r.w + ((uint32_t)ty - y0) * (x1 - x0) + ((uint32_t)tx - x0);
 }
 
-// Sum of a Gaussian's per-instance gradient lines in tile-ordinal order (deterministic).
+// ---- instance gradient lines ---------------------------------------------------------------------------------------
+// k_render_bwd / k_render_bwd_scan leave ONE 64-B line per (tile, Gaussian) instance.  Its first six floats are not the
+// reference's gradient terms but the raw pixel sums they are linear in (Q = G * dL/dalpha of a contributing pair,
+// d = mean - pixel, (u, v) = pixel - tile origin):
+//     L0 = sum Q dx     L1 = sum Q dy     L2 = sum Q dx u     L3 = sum Q dx v     L4 = sum Q dy v     L5 = sum Q
+// followed by the ten colour sums  sum alpha T dL/dpixel[ch]  (backward.cu:527).  u and v do not depend on the
+// Gaussian, which is what lets the scan kernel form the sums as small f32 matrix products (ghr_render_bwd2.h); the
+// second-order sums are recovered here per instance with e = mean - tile origin (d = e - (u, v)):
+//     sum Q dx^2 = ex L0 - L2     sum Q dx dy = ey L0 - L3     sum Q dy^2 = ey L1 - L4
+// (first-order cancellation only: |e| <= a few tiles against |d| of a contributing pixel), and the reference's terms
+// (backward.cu:542-558) follow per Gaussian from the conic (a, b, c) and opacity o:
+//     dmean2D.x = o (-a S0 - b S1) W/2   dmean2D.y = o (-c S1 - b S0) H/2   dconic = -o/2 (Sxx, Sxy, Syy)   dopacity = S5
+struct LineAcc {
+    float s0, s1, sxx, sxy, syy, s5;
+    f4 c0, c1, c2;  // c0.zw, c1, c2: the ten colour sums (c0.xy unused)
+};
+GHR_HD void line_acc_init(LineAcc& A)
+{
+    A.s0 = A.s1 = A.sxx = A.sxy = A.syy = A.s5 = 0.f;
+    A.c0 = f4{0.f, 0.f, 0.f, 0.f}; A.c1 = A.c0; A.c2 = A.c0;
+}
+// add the line (l0..l3) of the instance in tile (tx, ty); mx, my = the Gaussian's pixel mean
+GHR_HD void line_acc_add(LineAcc& A, const f4& l0, const f4& l1, const f4& l2, const f4& l3, float mx, float my, uint32_t tx,
+                         uint32_t ty)
+{
+    const float ex = mx - (float)(GHR_TILE_X * tx), ey = my - (float)(GHR_TILE_Y * ty);
+    A.s0 += l0.x;
+    A.s1 += l0.y;
+    A.sxx += __builtin_fmaf(ex, l0.x, -l0.z);
+    A.sxy += __builtin_fmaf(ey, l0.x, -l0.w);
+    A.syy += __builtin_fmaf(ey, l0.y, -l1.x);
+    A.s5 += l1.y;
+    A.c0 += l1; A.c1 += l2; A.c2 += l3;
+}
+// the 16 gradient terms of the reference's backward.cu:527,549-558, summed over the Gaussian's instances
+GHR_HD void line_acc_finish(const LineAcc& A, const f4& r0, const f4& r1, float half_w, float half_h, float* ga)
+{
+    const float a = r0.z, b = r0.w, c = r1.x, o = r1.y;
+    ga[0] = o * (-a * A.s0 - b * A.s1) * half_w;
+    ga[1] = o * (-c * A.s1 - b * A.s0) * half_h;
+    const float h = -0.5f * o;
+    ga[2] = h * A.sxx; ga[3] = h * A.sxy; ga[4] = h * A.syy;
+    ga[5] = A.s5;
+    ga[6] = A.c0.z; ga[7] = A.c0.w; ga[8] = A.c1.x; ga[9] = A.c1.y; ga[10] = A.c1.z; ga[11] = A.c1.w;
+    ga[12] = A.c2.x; ga[13] = A.c2.y; ga[14] = A.c2.z; ga[15] = A.c2.w;
+}
+
+// Sum of a Gaussian's per-instance gradient lines in tile-ordinal order (deterministic), converted to the reference's
+// gradient terms.  r0 / r1: the first two 16-B pieces of the Gaussian's render record (pixel mean, conic, opacity).
 // `rows`: number of lines `ginst` holds.  A Gaussian whose lines would reach past it (only possible when the forward ran
 // with a capacity below the true instance count, whose results the caller discards) reads nothing.
-GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uint32_t rows = 0xffffffffu)
+GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, const f4& r0, const f4& r1, float half_w, float half_h,
+                              float* ga, uint32_t rows = 0xffffffffu)
 {
     uint32_t cnt = rect4_area(r);
     if ((uint64_t)r.z + r.w + cnt > (uint64_t)rows) cnt = 0;
     const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * ((size_t)r.z + r.w);
-    f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const uint32_t x0 = r.x & 0xffffu, wdt = (r.x >> 16) - x0, y0 = r.y & 0xffffu;
+    LineAcc A;
+    line_acc_init(A);
     // four lines (16 independent 16-B loads) are requested per round trip: the loop is pure memory latency, and one
     // line per trip cost cnt_max-of-the-wave serialized trips.  Lines past `cnt` are not read and add +0; the sum
     // order (ascending ordinal) is unchanged.
     const f4 z = {0.f, 0.f, 0.f, 0.f};
+    uint32_t tx = 0, ty = 0;  // position of the instance's tile inside the rect
     for (uint32_t k = 0; k < cnt; k += 4, p += 16) {
         f4 v[16];
 #pragma unroll
@@ -114,10 +166,12 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uin
             for (int q = 0; q < 4; q++) v[4 * j + q] = in ? p[4 * j + q] : z;
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) { s0 += v[4 * j]; s1 += v[4 * j + 1]; s2 += v[4 * j + 2]; s3 += v[4 * j + 3]; }
+        for (int j = 0; j < 4; j++) {
+            line_acc_add(A, v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3], r0.x, r0.y, x0 + tx, y0 + ty);
+            if (++tx == wdt) { tx = 0; ty++; }
+        }
     }
-    ga[0] = s0.x; ga[1] = s0.y; ga[2] = s0.z; ga[3] = s0.w; ga[4] = s1.x; ga[5] = s1.y; ga[6] = s1.z; ga[7] = s1.w;
-    ga[8] = s2.x; ga[9] = s2.y; ga[10] = s2.z; ga[11] = s2.w; ga[12] = s3.x; ga[13] = s3.y; ga[14] = s3.z; ga[15] = s3.w;
+    line_acc_finish(A, r0, r1, half_w, half_h, ga);
 }
 
 // Rects with more tiles than this are not walked by their own lane: a lane's loop over a 20 x 20-tile splat (one atomic
@@ -132,14 +186,15 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, float* ga, uin
 // Sum of the instance gradient lines for every lane's Gaussian.  Small rects: per lane (gather_inst_grads, ascending
 // ordinal).  Big rects: one at a time by the whole wave -- lane l sums the lines l, l+64, ... (coalesced), then a
 // butterfly over the 64 lanes; the order differs from the sequential one but is fixed.  All lanes of the wave call it.
-__device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const rect4& r, float* ga, uint32_t rows)
+__device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const rect4& r, const f4& r0, const f4& r1,
+                                                       float half_w, float half_h, float* ga, uint32_t rows)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t cnt = rect4_area(r);
     const bool big = cnt > GHR_BIG_GATHER;
     rect4 small = r;
     if (big) { small.x = 0u; small.y = 0u; }  // empty rect: nothing to read
-    gather_inst_grads(ginst, small, ga, rows);
+    gather_inst_grads(ginst, small, r0, r1, half_w, half_h, ga, rows);
     unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
     while (todo) {  // wave-uniform
         const int src = __builtin_ctzll(todo);
@@ -147,20 +202,28 @@ __device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const
         const uint32_t first = (uint32_t)__shfl((int)(r.z + r.w), src);
         uint32_t n = (uint32_t)__shfl((int)cnt, src);
         if ((uint64_t)first + n > (uint64_t)rows) n = 0;  // see gather_inst_grads
+        const uint32_t rx = (uint32_t)__shfl((int)r.x, src), ry = (uint32_t)__shfl((int)r.y, src);
+        const float mx = __shfl(r0.x, src), my = __shfl(r0.y, src);
+        const uint32_t x0 = rx & 0xffffu, wdt = (rx >> 16) - x0, y0 = ry & 0xffffu;
         const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)first;
-        f4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        LineAcc A;
+        line_acc_init(A);
         for (uint32_t k = lane; k < n; k += 64) {
             const f4* q = p + 4 * (size_t)k;
-            s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3];
+            line_acc_add(A, q[0], q[1], q[2], q[3], mx, my, x0 + k % wdt, y0 + k / wdt);
         }
-        float v[16] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w, s2.x, s2.y, s2.z, s2.w, s3.x, s3.y, s3.z, s3.w};
+        float v[16] = {A.s0, A.s1, A.sxx, A.sxy, A.syy, A.s5, A.c0.z, A.c0.w, A.c1.x, A.c1.y, A.c1.z, A.c1.w,
+                       A.c2.x, A.c2.y, A.c2.z, A.c2.w};
 #pragma unroll
         for (int c = 0; c < 16; c++)
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v[c] += __shfl_xor(v[c], off);
-        if (lane == src)
-#pragma unroll
-            for (int c = 0; c < 16; c++) ga[c] = v[c];
+        if (lane == src) {
+            LineAcc S;
+            S.s0 = v[0]; S.s1 = v[1]; S.sxx = v[2]; S.sxy = v[3]; S.syy = v[4]; S.s5 = v[5];
+            S.c0 = f4{0.f, 0.f, v[6], v[7]}; S.c1 = f4{v[8], v[9], v[10], v[11]}; S.c2 = f4{v[12], v[13], v[14], v[15]};
+            line_acc_finish(S, r0, r1, half_w, half_h, ga);
+        }
     }
 }
 

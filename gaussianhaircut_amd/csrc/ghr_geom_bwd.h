@@ -21,8 +21,10 @@ struct GeomBwdArgs {
     const float* view;
     const float* proj;
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
-    const float* ginst;  // [R][16] per-instance packed gradients (slots: rect4_slot)
+    const float* ginst;  // [R][16] per-instance gradient lines (slots: rect4_slot; format: ghr_device.h LineAcc)
     const rect4* rects;
+    const f4* rec;       // [P][4] packed render records (pixel mean, conic, opacity: needed to unpack the lines)
+    float half_w, half_h;  // 0.5 W, 0.5 H (backward.cu:464-465)
     float* dL_dmeans2D;  // [P][3]
     float* dL_dconic;    // [P][4]
     float* dL_dopacity;  // [P]
@@ -173,8 +175,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_geom_bwd(GeomBwdArgs a)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
     rect4 r = make_rect4(0, 0, 0, 0, 0u);
     if (idx < a.P) r = a.rects[idx];
+    f4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
+    if (idx < a.P && rect4_area(r) != 0u) { r0 = a.rec[4 * (size_t)idx]; r1 = a.rec[4 * (size_t)idx + 1]; }
     float ga[16];
-    gather_inst_grads_wave(a.ginst, r, ga, 0xffffffffu);  // every lane of the wave takes part
+    gather_inst_grads_wave(a.ginst, r, r0, r1, a.half_w, a.half_h, ga, 0xffffffffu);  // every lane of the wave takes part
     if (idx < a.P) geom_bwd_one(a, idx, ga);
 #endif
 }

@@ -644,8 +644,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     if (idx < a.P) r = a.rects[(size_t)a.row0 + idx];
     f4 v[GHR_SLAB_IT];
     if (row > 0) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;  // pixel mean / conic / opacity of the record k_project wrote (culled rows: none)
+    if (idx < a.P && rect4_area(r) != 0u) { q0 = a.rec[4 * ((size_t)a.row0 + idx)]; q1 = a.rec[4 * ((size_t)a.row0 + idx) + 1]; }
     float ga[16];
-    gather_inst_grads_wave(g.ginst, r, ga, g.ginst_rows);
+    gather_inst_grads_wave(g.ginst, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
     if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     bool bad = false;

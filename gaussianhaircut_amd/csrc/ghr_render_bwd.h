@@ -46,7 +46,7 @@ struct PixBwd {
 // (backward.cu:490-492).  Always writes the 16 per-pair gradient terms to g[] (exact zeros when the pair does not
 // contribute) and returns whether it contributed.
 GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, const f4& r1, const f4& r2,
-                     const f4& r3, float ddelx_dx, float ddely_dy, float* g)
+                     const f4& r3, float u, float v, float* g)
 {
     const float dx = r0.x - pxf, dy = r0.y - pyf;
     const float power = -0.5f * (r0.z * dx * dx + r1.x * dy * dy) - r0.w * dx * dy;  // unfused (decision input)
@@ -76,19 +76,18 @@ GHR_HD bool bwd_step(PixBwd& s, bool live, float pxf, float pyf, const f4& r0, c
     float dL_dalpha = (cdot - s.S) * s.T;                                 // :523,:529
     dL_dalpha = fma_(-s.T_final * inv1ma, s.bgdot, dL_dalpha);            // :535-538
 
-    const float dL_dG = o * dL_dalpha;  // :542
-    const float gdx = G * dx, gdy = G * dy;
-    // the products below share factors and use explicit fma (the TU is compiled without contraction): 5 VALU fewer per
-    // pass than the reference's expression order, same values to fp32 rounding
-    const float dG_ddelx = fma_(-gdx, r0.z, -(gdy * r0.w));
-    const float dG_ddely = fma_(-gdy, r1.x, -(gdx * r0.w));
-    g[0] = dL_dG * dG_ddelx * ddelx_dx;  // :549
-    g[1] = dL_dG * dG_ddely * ddely_dy;  // :550
-    const float hG = -0.5f * dL_dG, hgx = hG * gdx;
-    g[2] = hgx * dx;                     // :553
-    g[3] = hgx * dy;                     // :554 (half of d/db; the Python wrapper doubles it)
-    g[4] = hG * gdy * dy;                // :555
-    g[5] = G * dL_dalpha;                // :558
+    // The six geometric terms of backward.cu:542-558 are linear in the pixel sums of Q, Q dx, Q dy, Q dx u, Q dx v,
+    // Q dy v (Q = G dL/dalpha; (u, v) = pixel - tile origin): the line carries those sums and the per-Gaussian gather
+    // recovers the reference's terms (ghr_device.h, LineAcc) -- 6 VALU here instead of 18.
+    (void)o;
+    const float Q = G * dL_dalpha;       // :558 (dL/dopacity term)
+    const float qx = Q * dx, qy = Q * dy;
+    g[0] = qx;
+    g[1] = qy;
+    g[2] = qx * u;
+    g[3] = qx * v;
+    g[4] = qy * v;
+    g[5] = Q;
 #pragma unroll
     for (int i = 0; i < GHR_C / 2; i++) {  // :508,:527
         const f2 gc = s.dL[i] * w;
@@ -237,7 +236,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         if (c & 1) st.dL[c / 2].y = d; else st.dL[c / 2].x = d;
         st.bgdot = fma_(bg[c], d, st.bgdot);
     }
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;  // backward.cu:464-465
+    const float pu = (float)(4 * grp + (l & 3)), pv = (float)(4 * wave + (l >> 2));  // pixel - tile origin
 
     // Entries at list positions >= max(n_contrib) are skipped by every pixel concerned (backward.cu:490-492):
     // the tile starts its walk at the tile maximum, and every cell drops the entries above its own maximum.
@@ -293,7 +292,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
         auto cell_pass = [&](uint32_t j) {  // one entry, one cell (16 lanes)
             const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == reference's `contributor`
             float g[16];
-            bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy, g);
+            bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], pu, pv, g);
             const float v = row_reduce16(g, l);
             // lane l adds component l of the cell's total: 16 lanes -> one 64-B line, resolved in this XCD's L2
             __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] + l, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -337,8 +336,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
                     const uint32_t j = sub + (uint32_t)nc;  // wave-uniform
                     const uint32_t pos = n_eff - 1 - (base + j);
                     float g[16];
-                    bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], ddelx_dx, ddely_dy,
-                             g);
+                    bwd_step(st, pos < last_contributor, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], pu, pv, g);
                     const float v = wave_reduce16(g, lane);
                     if ((lane & 3) == 0)
                         __hip_atomic_fetch_add(ginst + 16 * (size_t)s_slot[j] +

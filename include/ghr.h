@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 9
+#define GHR_ABI_VERSION 10
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
@@ -249,6 +249,11 @@ int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float*
  * autograd runs backward on a worker thread) record on the caller's stream immediately before / after the compositing kernel (ghr_forward_stage2: k_render_fwd) and the
  * gradient-walk kernel (ghr_backward: k_render_bwd).  NULL disables a pair.  Sticky until changed. */
 int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop);
+
+/* Self test of the wave-level primitives the scan form of the gradient walk is built from (16-lane DPP row scans,
+ * row broadcast, v_mfma_f32_16x16x4_f32 operand / result layout): in[8][64] floats -> out[12][64] floats (device
+ * pointers); tests/test_gpu_wave_primitives.py states the expected values. */
+int ghr_selftest_wave(void* stream, const float* in, float* out);
 
 /* Introspection for tests (device pointers into the workspaces; layout is otherwise private). */
 typedef struct ghr_ws_view {

@@ -1,0 +1,123 @@
+"""Generates tests/golden/reference_cuda_golden.npz by RUNNING THE REFERENCE'S OWN RASTERIZER on an MI355X.
+
+The reference's CUDA sources (ext/diff_gaussian_rasterization_hair/cuda_rasterizer/*) are hipified and compiled for
+gfx950 by ``make -C oracle -f Makefile.ref`` in the build container (where /root/reference exists); the resulting
+``oracle/_ref/libghr_ref.so`` travels to the GPU box with the snapshot, and this script drives it there:
+
+    gpurun -- 'python tests/golden/make_reference_cuda_golden.py'      # writes gpurun_out/reference_cuda_golden.npz
+
+The file is then copied to tests/golden/ and committed.  It pins oracle/ghr_oracle.c (tests/test_reference_cuda_golden.py,
+CPU) and is replayed against the HIP product on the GPU (tests/test_gpu_reference_golden.py).
+
+Per case the file holds the INPUTS (so consumers do not depend on bit-reproducible host maths), the forward outputs
+(out_color, radii), the reference's internal state (depths, means2D, conic_opacity, tiles_touched, point_list, ranges,
+accum_alpha, n_contrib; R:rasterizer_impl.h:29-65) and the eight gradient tensors of
+R:rasterize_points.cu:125-206 for a seeded dL/dout.  dL/dout is zeroed on the oracle's "fragile" pixels (decisions
+within 2e-5 of a threshold, where a 1-ulp different exp() may legitimately decide otherwise; tests/helpers.py); the
+mask is stored as an input.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+CASES = [("tiny", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"), ("ragged", "A"), ("tiny_strands", "A_sr"),
+         ("cfg1", "A")]
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr() if t is not None else 0)
+
+
+def run_reference(L, ri, mode, dL, dev):
+    """ri: dict of CPU tensors (synthetic.raster_inputs).  Returns dict of numpy arrays."""
+    from tests.gpu_helpers import mode_tensors, to_dev
+    rd = to_dev(ri, dev)
+    mt = mode_tensors(rd, mode)
+    P, W, H = rd["means3D"].shape[0], ri["W"], ri["H"]
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    f = dict(dtype=torch.float32, device=dev)
+    out = torch.zeros(10, H, W, **f)
+    radii = torch.zeros(P, dtype=torch.int32, device=dev)
+    opac = rd["opacities"].reshape(-1).contiguous()
+    view, proj = rd["viewmatrix"].contiguous(), rd["projmatrix"].contiguous()
+    campos = rd["campos"].contiguous()
+    R = L.ghr_ref_forward(P, W, H, _ptr(rd["bg"]), _ptr(rd["means3D"]), _ptr(rd["colors"]), _ptr(opac),
+                          _ptr(mt["scales"]), ctypes.c_float(1.0), _ptr(mt["rotations"]), _ptr(mt["cov3D"]),
+                          _ptr(mt["conic"]), _ptr(view), _ptr(proj), _ptr(campos), ctypes.c_float(ri["tanfovx"]),
+                          ctypes.c_float(ri["tanfovy"]), 1, _ptr(out), _ptr(radii))
+    assert R >= 0, L.ghr_ref_last_error()
+    i32 = dict(dtype=torch.int32, device=dev)
+    st = dict(depths=torch.zeros(P, **f), means2D=torch.zeros(P, 2, **f), conic_opacity=torch.zeros(P, 4, **f),
+              tiles_touched=torch.zeros(P, **i32), point_offsets=torch.zeros(P, **i32), final_T=torch.zeros(N, **f),
+              n_contrib=torch.zeros(N, **i32), ranges=torch.zeros(T, 2, **i32), point_list=torch.zeros(max(R, 1), **i32),
+              keys=torch.zeros(max(R, 1), dtype=torch.int64, device=dev))
+    rc = L.ghr_ref_state(*[_ptr(st[k]) for k in ("depths", "means2D", "conic_opacity", "tiles_touched",
+                                                 "point_offsets", "final_T", "n_contrib", "ranges", "point_list",
+                                                 "keys")])
+    assert rc == 0, L.ghr_ref_last_error()
+    g = dict(dL_dmeans2D=torch.zeros(P, 3, **f), dL_dconic=torch.zeros(P, 2, 2, **f), dL_dopacity=torch.zeros(P, 1, **f),
+             dL_dcolors=torch.zeros(P, 10, **f), dL_dmeans3D=torch.zeros(P, 3, **f), dL_dcov3D=torch.zeros(P, 6, **f),
+             dL_dscales=torch.zeros(P, 3, **f), dL_drotations=torch.zeros(P, 4, **f))
+    dLd = dL.to(dev).contiguous()
+    rc = L.ghr_ref_backward(_ptr(rd["bg"]), _ptr(rd["means3D"]), _ptr(radii), _ptr(rd["colors"]), _ptr(mt["scales"]),
+                            ctypes.c_float(1.0), _ptr(mt["rotations"]), _ptr(mt["cov3D"]), _ptr(mt["conic"]), _ptr(view),
+                            _ptr(proj), _ptr(campos), ctypes.c_float(ri["tanfovx"]), ctypes.c_float(ri["tanfovy"]),
+                            _ptr(dLd), _ptr(g["dL_dmeans2D"]), _ptr(g["dL_dconic"]), _ptr(g["dL_dopacity"]),
+                            _ptr(g["dL_dcolors"]), _ptr(g["dL_dmeans3D"]), _ptr(g["dL_dcov3D"]), _ptr(g["dL_dscales"]),
+                            _ptr(g["dL_drotations"]))
+    assert rc == 0, L.ghr_ref_last_error()
+    res = dict(num_rendered=np.int64(R), out_color=out.cpu().numpy(), radii=radii.cpu().numpy())
+    for k, v in st.items():
+        a = v.cpu().numpy()
+        if k in ("point_list", "keys"):
+            a = a[:R]
+        res["st_" + k] = a
+    for k, v in g.items():
+        res[k] = v.cpu().numpy()
+    return res
+
+
+def main():
+    assert torch.cuda.is_available(), "needs the MI355X box"
+    so = os.path.join(ROOT, "oracle", "_ref", "libghr_ref.so")
+    assert os.path.exists(so), "build it first in the build container: make -C oracle -f Makefile.ref"
+    L = ctypes.CDLL(so)
+    L.ghr_ref_last_error.restype = ctypes.c_char_p
+    import oracle
+    from gaussianhaircut_amd.utils import synthetic as syn
+    from tests import helpers as hp
+    dev = torch.device("cuda:0")
+    out = {}
+    for cfg, mode in CASES:
+        spec = syn.CONFIGS[cfg]
+        ri = syn.raster_inputs(spec)
+        _, _, st_o = hp.oracle_forward(oracle, ri, mode)
+        frag = st_o.fragile.astype(bool)
+        dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
+        dL[:, torch.from_numpy(frag)] = 0.0
+        res = run_reference(L, ri, mode, dL, dev)
+        tag = "%s/%s/" % (cfg, mode)
+        for k in ("means3D", "colors", "opacities", "cov3D", "conic", "scales", "rotations", "bg", "viewmatrix",
+                  "projmatrix", "campos"):
+            out[tag + "in_" + k] = ri[k].numpy()
+        out[tag + "in_scalars"] = np.array([ri["W"], ri["H"], ri["tanfovx"], ri["tanfovy"]], np.float64)
+        out[tag + "in_dL_mask"] = np.packbits(frag.reshape(-1))
+        out[tag + "in_dL_seed_abs_sum"] = np.float64(dL.double().abs().sum().item())
+        for k, v in res.items():
+            out[tag + k] = v
+        print(tag, "P", ri["P"], "R", int(res["num_rendered"]), "fragile px", int(frag.sum()), flush=True)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    dst = os.path.join(ROOT, "gpurun_out", "reference_cuda_golden.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

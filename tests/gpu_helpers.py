@@ -107,3 +107,24 @@ class GpuRun:
                                        _ptr(o["dL_dscales"]), _ptr(o["dL_drotations"])))
         torch.cuda.synchronize()
         return {k: v.cpu().numpy() for k, v in o.items()}
+
+
+def inspect_fused(renders_packed, P, W, H, R):
+    """Workspaces of the FUSED render() path (k_project -> ... -> k_render_fwd), read through ghr_ws_inspect from the
+    tensors its autograd node saved (gaussian_renderer/fused.py: ..., radii, geom, img, binb)."""
+    saved = renders_packed.grad_fn.saved_tensors
+    radii, geom, img, binb = saved[-4], saved[-3], saved[-2], saved[-1]
+    v = _lib.WsView()
+    _lib.check(_lib.lib().ghr_ws_inspect(P, W, H, 0, R, _ptr(geom), _ptr(img), _ptr(binb) if R else None,
+                                         ctypes.byref(v)))
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    return dict(
+        radii=radii.cpu().numpy(),
+        rec=_slice(geom, v.rec, 64 * P, torch.float32).numpy().reshape(P, 16),
+        depths=_slice(geom, v.depths, 4 * P, torch.float32).numpy(),
+        rects=_slice(geom, v.rects, 16 * P, torch.int32).numpy().view(np.uint32).reshape(P, 4),
+        final_T=_slice(img, v.final_T, 4 * N, torch.float32).numpy(),
+        n_contrib=_slice(img, v.n_contrib, 4 * N, torch.int32).numpy().view(np.uint32),
+        tile_start=_slice(img, v.tile_start, 4 * (T + 1), torch.int32).numpy().view(np.uint32),
+        point_list=_slice(binb, v.point_list, 4 * R, torch.int32).numpy().view(np.uint32) if R else
+        np.zeros(0, np.uint32))

@@ -149,7 +149,6 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     // one 64-B line per Gaussian-tile instance (rect4_slot), as k_render_bwd writes them; the per-pixel sum inside
     // an instance is order-free on the GPU (wave butterfly + ds_add), so it is accumulated in double here
     std::vector<double> acc((size_t)16 * s->R, 0.0);
-    const float ddelx_dx = 0.5f * a->W, ddely_dy = 0.5f * a->H;
     for (int t = 0; t < T; t++) {
         const int tx = t % s->gx, ty = t / s->gx;
         const uint32_t beg = s->tile_start[t], n = s->tile_start[t + 1] - beg;
@@ -183,7 +182,7 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                 }
                 float g[16];
                 // branch-free step: non-contributing visits (pos >= n_contrib of THIS pixel included) run with alpha = 0
-                if (ghr::bwd_step(st, pos < last, (float)px, (float)py, r[0], r[1], r[2], r[3], ddelx_dx, ddely_dy, g)) {
+                if (ghr::bwd_step(st, pos < last, (float)px, (float)py, r[0], r[1], r[2], r[3], (float)(tid & 15), (float)(tid >> 4), g)) {
                     const size_t slot = ghr::rect4_slot(s->rects[id], tx, ty);
                     for (int i = 0; i < 16; i++) acc[16 * slot + i] += (double)g[i];
                 }
@@ -198,12 +197,14 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.ginst = ginst.data(); ga.rects = s->rects.data();
+    ga.ginst = ginst.data(); ga.rects = s->rects.data(); ga.rec = s->rec.data();
+    ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     for (int idx = 0; idx < P; idx++) {
         float g16[16];
-        ghr::gather_inst_grads(ga.ginst, ga.rects[idx], g16);
+        ghr::gather_inst_grads(ga.ginst, ga.rects[idx], ga.rec[4 * (size_t)idx], ga.rec[4 * (size_t)idx + 1], ga.half_w,
+                               ga.half_h, g16);
         ghr::geom_bwd_one(ga, idx, g16);
     }
 }

@@ -18,6 +18,9 @@ def _np(t):
     return np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32)
 
 
+LAST = {}
+
+
 class _OracleRasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, conic, rs):
@@ -27,6 +30,7 @@ class _OracleRasterize(torch.autograd.Function):
                                                   _np(rs.viewmatrix), _np(rs.projmatrix), rs.tanfovx, rs.tanfovy,
                                                   rs.image_height, rs.image_width, **kw)
         ctx.st, ctx.rs, ctx.kw = st, rs, kw
+        LAST["state"] = st  # tests that compare stage by stage read the oracle's K1 / binning / K7 state here
         ctx.save_for_backward(means3D, colors, scales, rotations, cov3D, conic)
         r = torch.from_numpy(radii)
         ctx.mark_non_differentiable(r)

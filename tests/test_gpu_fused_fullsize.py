@@ -1,0 +1,201 @@
+"""`-m gpu`: the path bench.py times -- the FUSED render() (k_project -> binning -> k_render_fwd) -> loss -> backward
+(k_render_bwd -> k_project_bwd) -- against the ORACLE CHAIN at BASELINE.json's full sizes (cfg2 100k blobs, cfg3 500k
+strands, cfg5 2M strands, 1920x1080):
+
+    CPU fp32 PyTorch projection of gaussianhaircut_amd.scene (pinned to outputs of the reference's own Python,
+    tests/test_reference_golden.py)  ->  oracle.rasterize_forward / backward (tests/oracle_backend.py; pinned to the
+    reference's CUDA, tests/test_reference_cuda_golden.py)  ->  PyTorch autograd to the raw parameters.
+
+No quantile acceptance.  Differently rounded projection arithmetic may flip a discrete decision of K1 (radius ceil,
+tile rect, cull): those Gaussians are COUNTED (bound 1e-4 of P) and the pixels of the tiles they touch are masked
+together with the oracle's fragile pixels (alpha / T within 2e-5 of a threshold); the mask is applied by giving those
+pixels zero weight in the loss on BOTH sides, which removes them exactly.  Everything else must agree:
+K1 state bit for bit (depth keys, pixel means) or to 1e-5 (conic, opacity), the sorted tile lists exactly, the image to
+1e-4, every raw-parameter gradient to 1e-4 * (|ref| + largest |ref| of its row) plus a floor for cancellation noise.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from gaussianhaircut_amd.gaussian_renderer import _package, render
+from gaussianhaircut_amd.utils import synthetic as syn
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+FUSED = SimpleNamespace(debug=False, fused_projection=True)
+GENERIC = SimpleNamespace(debug=False, fused_projection=False)
+PARAMS = ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest")
+FLOOR = 2e-6  # of the tensor's largest |ref|: fp32 cancellation noise of rows whose own gradient is ~0
+
+
+def _row_close(a, b, tol=hp.TOL, floor=FLOOR):
+    a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+    rows = np.abs(b).max(axis=1, keepdims=True)
+    return np.abs(a - b) <= tol * (np.abs(b) + rows) + floor * np.abs(b).max()
+
+
+def _assert_rows(name, a, b, tol=hp.TOL, floor=FLOOR):
+    assert np.isfinite(a).all(), name
+    ok = _row_close(a, b, tol, floor)
+    if not ok.all():
+        a2, b2 = a.reshape(len(a), -1), b.reshape(len(b), -1)
+        r, c = np.unravel_index(np.argmax(np.abs(a2 - b2) * ~ok), ok.shape)
+        raise AssertionError("%s: %d of %d elements off; worst row %d col %d got %g ref %g (row max %g, tensor max %g)" %
+                             (name, (~ok).sum(), ok.size, r, c, a2[r, c], b2[r, c], np.abs(b2[r]).max(), np.abs(b2).max()))
+
+
+def _chains(cfg, dev, deg=3):
+    """Forward of both chains + the stage-by-stage comparison.  Returns what the loss legs need."""
+    from tests import oracle_backend as ob
+    from tests.gpu_helpers import inspect_fused
+    spec = syn.CONFIGS[cfg]
+    W, H = spec.W, spec.H
+    mc, mg = syn.make_model(spec, "cpu"), syn.make_model(spec, dev)
+    mc.active_sh_degree = mg.active_sh_degree = deg
+    cc, cg = syn.make_view(spec, "cpu"), syn.make_view(spec, dev)
+    with ob.oracle_rasterizer():
+        pc = render(cc, mc, GENERIC, syn.background("cpu"))
+    st = ob.LAST["state"]
+    keep = mc.filter_points(cc).numpy()
+    idx = np.nonzero(keep)[0]
+    pg = render(cg, mg, FUSED, syn.background(dev))
+    torch.cuda.synchronize()
+    P = spec.P
+    R = int(pg.count)
+    ins = inspect_fused(pg.renders_packed, P, W, H, R)
+
+    # ---- K1 state: radii, and for every Gaussian both chains rasterize identically: depth key bits, pixel mean bits,
+    # conic / opacity values
+    radii_c, radii_g = pc["radii"].numpy(), ins["radii"]
+    assert np.array_equal(radii_g, pg["radii"].cpu().numpy())
+    rect_c = np.zeros((P, 4), np.int64)  # x0, y0, x1, y1 of the oracle chain (auxiliary.h:46-56), recomputed from its state
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    xy, rad = st.xy.astype(np.float32), st.radii.astype(np.int64)
+    def tile(v, g):
+        return np.clip(np.trunc(v / np.float32(16)).astype(np.int64), 0, g)
+    rect_c[idx, 0] = tile(xy[:, 0] - rad.astype(np.float32), gx)
+    rect_c[idx, 1] = tile(xy[:, 1] - rad.astype(np.float32), gy)
+    rect_c[idx, 2] = tile(xy[:, 0] + rad.astype(np.float32) + np.float32(16) - np.float32(1), gx)
+    rect_c[idx, 3] = tile(xy[:, 1] + rad.astype(np.float32) + np.float32(16) - np.float32(1), gy)
+    rect_c[radii_c == 0] = 0
+    area_c = (rect_c[:, 2] - rect_c[:, 0]) * (rect_c[:, 3] - rect_c[:, 1])
+    assert np.array_equal(area_c[idx], st.tiles_touched.astype(np.int64))
+    rg = ins["rects"]
+    rect_g = np.stack([rg[:, 0] & 0xffff, rg[:, 1] & 0xffff, rg[:, 0] >> 16, rg[:, 1] >> 16], axis=1).astype(np.int64)
+    rect_g[radii_g == 0] = 0
+    flipped = (radii_c != radii_g) | (rect_c != rect_g).any(axis=1)
+    n_flip = int(flipped.sum())
+    assert n_flip <= max(2, int(1e-4 * P)), "K1 decisions differ for %d of %d Gaussians" % (n_flip, P)
+    same = (radii_c > 0) & ~flipped
+    kept_pos = np.full(P, -1, np.int64)
+    kept_pos[idx] = np.arange(idx.size)
+    j = kept_pos[same]
+    assert (j >= 0).all()
+    np.testing.assert_array_equal(ins["depths"][same].view(np.uint32), st.depths[j].view(np.uint32))
+    np.testing.assert_array_equal(ins["rec"][same, 0:2].view(np.uint32), st.xy[j].view(np.uint32))
+    co_g, co_c = ins["rec"][same, 2:6], st.conic_opacity[j]
+    rel = np.abs(co_g - co_c) / (np.abs(co_c).max(axis=1, keepdims=True) + 1e-30)
+    assert rel.max() < 1e-5, "conic / opacity of k_project vs the host projection: %g" % rel.max()
+
+    # ---- binning: the tile lists are identical once the flipped Gaussians are taken out of both
+    pl_c = idx[st.point_list.astype(np.int64)]
+    pl_g = ins["point_list"].astype(np.int64)
+    np.testing.assert_array_equal(pl_g[~flipped[pl_g]], pl_c[~flipped[pl_c]])
+    if n_flip == 0:
+        assert R == st.num_rendered
+        ts = ins["tile_start"]
+        r = np.stack([ts[:-1], ts[1:]], axis=1).astype(np.uint32)
+        r[ts[:-1] == ts[1:]] = 0
+        np.testing.assert_array_equal(r, st.ranges)
+
+    # ---- pixel mask: oracle-fragile pixels + every pixel of a tile a flipped Gaussian touches in either chain
+    mask = st.fragile.reshape(H, W).astype(bool).copy()
+    assert mask.mean() < 2e-3
+    for g_ in np.nonzero(flipped)[0]:
+        for rc in (rect_c[g_], rect_g[g_]):
+            mask[16 * rc[1]:16 * rc[3], 16 * rc[0]:16 * rc[2]] = True
+    assert mask.mean() < 5e-3, "masked fraction %g" % mask.mean()
+    ok = ~mask.reshape(-1)
+    if n_flip == 0:
+        np.testing.assert_array_equal(ins["n_contrib"][ok], st.n_contrib[ok])
+
+    # ---- image (all 10 channels of the packed output, and the derived orientation angle), tolerance 1e-4
+    img_c = pc.renders_packed.detach().numpy().reshape(10, -1)[:, ok]
+    img_g = pg.renders_packed.detach().cpu().numpy().reshape(10, -1)[:, ok]
+    assert np.isfinite(img_g).all()
+    close = hp.image_close(img_g, img_c)
+    assert close.all(), "%d px-channels off, max err %g" % ((~close).sum(), np.abs(img_g - img_c).max())
+    ang_c = pc["orient_angle"].detach().numpy().reshape(-1)[ok]
+    ang_g = pg["orient_angle"].detach().cpu().numpy().reshape(-1)[ok]
+    # |d acos| <= 22.4 |dx| inside the clamp; only compare where the 2D direction is not ~0 (normalize of a null vector)
+    nrm = np.linalg.norm(pc.renders_packed.detach().numpy().reshape(10, -1)[5:7, :][:, ok], axis=0)
+    assert (np.abs(ang_g - ang_c)[nrm > 1e-2] < 1e-3).all()
+    vs_c, vs_g = pc["viewspace_points"].detach().numpy(), pg["viewspace_points"].detach().cpu().numpy()
+    assert np.abs(vs_g[keep][:, :2] - vs_c[keep][:, :2]).max() < 1e-5
+    stats = dict(n_flip=n_flip, masked=float(mask.mean()), R=R, img_err=float(np.abs(img_g - img_c).max()))
+    return spec, (mc, cc, pc), (mg, cg, pg), torch.from_numpy(mask), stats
+
+
+def _grads(model, pkg):
+    g = {n: getattr(model, n).grad.detach().cpu().numpy().copy() for n in PARAMS}
+    g["viewspace"] = pkg["viewspace_points"].grad.detach().cpu().numpy().copy()
+    for n in PARAMS:
+        getattr(model, n).grad = None
+    pkg["viewspace_points"].grad = None
+    return g
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
+def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg):
+    from gaussianhaircut_amd.fused_loss import stage1_loss
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import view_loss
+    dev = torch.device("cuda:0")
+    spec, (mc, cc, pc), (mg, cg, pg), mask, stats = _chains(cfg, dev)
+    H, W = spec.H, spec.W
+
+    # ---- leg A: a seeded linear functional of the 10 output planes (dL/dout ~ N(0,1), SURVEY 8(d) cfg 2), zero on the
+    # masked pixels.  Exercises k_render_bwd + k_project_bwd alone.
+    w = syn.grad_image(spec, 101) * (H * W)
+    w[:, mask] = 0.0
+    (pc.renders_packed * w).sum().backward(retain_graph=True)
+    (pg.renders_packed * w.to(dev)).sum().backward(retain_graph=True)
+    gc, gg = _grads(mc, pc), _grads(mg, pg)
+    for k in gc:
+        _assert_rows("legA " + k, gg[k], gc[k])
+
+    # ---- leg B: the stage-1 loss of train_gaussians.py:126-140 (masked L1 + SSIM + mask L1 + orientation, run.sh
+    # weights) towards the render of a perturbed model.  The SSIM window couples neighbouring pixels, so the masked
+    # pixels are neutralised by VALUE as well: both chains see the oracle chain's numbers there, without gradient.
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+        gt._xyz.add_(0.002 * torch.randn(gt._xyz.shape, generator=torch.Generator().manual_seed(202)).to(dev))
+        pgt = render(cg, gt, FUSED, syn.background(dev))
+        maps = dict(original_image=pgt["render"].clamp(0, 1), original_mask=pgt["mask"].clamp(0, 1),
+                    original_orient_angle=pgt["orient_angle"].clone(),
+                    original_orient_conf=torch.ones_like(pgt["orient_conf"]))
+    for k, v in maps.items():
+        setattr(cg, k, v.detach().contiguous())
+        setattr(cc, k, v.detach().cpu().contiguous())
+    del gt, pgt
+    frozen = pc.renders_packed.detach()
+    packed_c = torch.where(mask[None], frozen, pc.renders_packed)
+    packed_g = torch.where(mask[None].to(dev), frozen.to(dev), pg.renders_packed)
+    loss_c = view_loss(_package(packed_c, pc["viewspace_points"], pc["radii"]), cc, opt, fused=False)
+    loss_g = stage1_loss(packed_g, cg.original_image, cg.original_mask, cg.original_orient_angle,
+                         cg.original_orient_conf, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask,
+                         opt.lambda_dorient)
+    assert abs(float(loss_g) - float(loss_c)) <= 2e-5 * abs(float(loss_c)), (float(loss_g), float(loss_c))
+    loss_c.backward()
+    loss_g.backward()
+    gc, gg = _grads(mc, pc), _grads(mg, pg)
+    for k in gc:
+        _assert_rows("legB " + k, gg[k], gc[k])
+    print("fullsize", cfg, stats, "loss", float(loss_c))

@@ -1,5 +1,5 @@
 """Strand-stage (render_hair) step timing on the GPU box: fused segmented projection vs the generic PyTorch path.
-    python tools_bench_hair.py [n_strands] [n_head]"""
+    python tools/bench_hair.py [n_strands] [n_head]"""
 import sys
 import time
 from types import SimpleNamespace

@@ -1,5 +1,5 @@
 """Non-asserting stage-by-stage GPU diagnostic (prints mismatch statistics vs the oracle).  Used on the GPU box to
-get maximum information out of one gpurun call: python tools_gpu_diag.py [cfg ...]"""
+get maximum information out of one gpurun call: python tools/gpu_diag.py [cfg ...]"""
 import sys
 import time
 import traceback

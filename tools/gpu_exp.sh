@@ -3,10 +3,10 @@
 mkdir -p gpurun_out; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 for so in $R/gaussianhaircut_amd/csrc/variants/*.so; do
-  GHR_LIB_PATH=$so timeout 90 python tools_kbench.py ${CFG:-cfg3} 20 2>&1 | grep -E "KBENCH|Error|error"
+  GHR_LIB_PATH=$so timeout 90 python tools/kbench.py ${CFG:-cfg3} 20 2>&1 | grep -E "KBENCH|Error|error"
 done | tee gpurun_out/kbench.log
 if [ -n "$KT" ]; then
-  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/tools_kbench.py ${CFG:-cfg3} 10 ) > gpurun_out/kt.log 2>&1
+  ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- python $R/tools/kbench.py ${CFG:-cfg3} 10 ) > gpurun_out/kt.log 2>&1
   python - <<PY | tee gpurun_out/kt_stats.log
 import csv,glob
 for f in glob.glob('/tmp/kt/**/*kernel_stats.csv', recursive=True):
@@ -21,7 +21,7 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_WR" \
            "GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_LDS_ATOMIC_RETURN SQ_INSTS_FLAT"; do
   i=$((i+1))
-  ( cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $R/tools_kbench.py ${CFG:-cfg3} 5 ) > gpurun_out/pmc$i.log 2>&1
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pmc$i -o p -- python $R/tools/kbench.py ${CFG:-cfg3} 5 ) > gpurun_out/pmc$i.log 2>&1
   python - <<PY
 import csv,glob,collections
 f=glob.glob('/tmp/pmc$i/**/*counter_collection.csv',recursive=True)

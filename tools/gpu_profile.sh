@@ -10,4 +10,4 @@ B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-op-only --stre
 ( cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_write -o w -- $B ) > gpurun_out/rocprof_write.log 2>&1; echo "write rc=$?"
 mkdir -p /tmp/prof_all && cp -r /tmp/prof_kt /tmp/prof_fetch /tmp/prof_write /tmp/prof_all/ 2>/dev/null
 find /tmp/prof_all -name "*.csv" | head -20
-python tools_parse_prof.py /tmp/prof_all gpurun_out/profiles $TAG
+python tools/parse_prof.py /tmp/prof_all gpurun_out/profiles $TAG

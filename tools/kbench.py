@@ -1,7 +1,7 @@
 """Kernel micro-bench on the GPU box: one forward of a raster config through the C ABI, then the render kernels
 timed alone (HIP events the library records around K7 / K8 on the launch stream).
 
-    GHR_LIB_PATH=<variant .so> python tools_kbench.py [cfg] [iters]
+    GHR_LIB_PATH=<variant .so> python tools/kbench.py [cfg] [iters]
 """
 import ctypes
 import sys
