@@ -50,9 +50,12 @@ int ghr_ref_forward(int P, int W, int H, const float* bg, const float* means3D, 
 {
     g.P = P; g.W = W; g.H = H; g.R = 0;
     if (P == 0) return 0;
+    // means2D_precomp: the reference's Python always passes a tensor (screenspace_points) and preprocessCUDA projects the
+    // mean itself exactly when the pointer is NON-null (forward.cu:203-212: the other branch would read through it), so
+    // any non-null pointer reproduces what the reference runs; its values are never read.
     try {
         g.R = CudaRasterizer::Rasterizer::forward(grower(g.geom), grower(g.binning), grower(g.img), P, /*D*/ 0, /*M*/ 0, bg,
-                                                  W, H, means3D, /*means2D_precomp*/ nullptr, /*shs*/ nullptr, colors,
+                                                  W, H, means3D, /*means2D_precomp*/ means3D, /*shs*/ nullptr, colors,
                                                   opacity, scales, scale_modifier, rotations, cov3D_precomp,
                                                   conic_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy,
                                                   prefiltered != 0, out_color, radii, /*debug*/ false);
@@ -72,9 +75,10 @@ int ghr_ref_state(float* depths, float* means2D /*[P,2]*/, float* conic_opacity 
     using namespace CudaRasterizer;
     const int P = g.P, N = g.W * g.H;
     if (P == 0) return 0;
-    GeometryState geom = GeometryState::fromChunk(g.geom.p, P);
-    ImageState img = ImageState::fromChunk(g.img.p, N);
-    BinningState bin = BinningState::fromChunk(g.binning.p, g.R);
+    char *gp = g.geom.p, *ip = g.img.p, *bp = g.binning.p;  // fromChunk advances the pointer it is handed (char*&)
+    GeometryState geom = GeometryState::fromChunk(gp, P);
+    ImageState img = ImageState::fromChunk(ip, N);
+    BinningState bin = BinningState::fromChunk(bp, g.R);
     const int T = ((g.W + 15) / 16) * ((g.H + 15) / 16);
     auto cp = [](void* d, const void* s, size_t n) { return !d || n == 0 || hipMemcpy(d, s, n, hipMemcpyDeviceToDevice) == hipSuccess; };
     bool ok = cp(depths, geom.depths, 4u * P) && cp(means2D, geom.means2D, 8u * P) &&

@@ -140,6 +140,11 @@ def _chains(cfg, dev, deg=3):
     return spec, (mc, cc, pc), (mg, cg, pg), torch.from_numpy(mask), stats
 
 
+def ob_state_n_contrib(pkg):
+    from tests import oracle_backend as ob
+    return ob.LAST["state"].n_contrib
+
+
 def _grads(model, pkg):
     g = {n: getattr(model, n).grad.detach().cpu().numpy().copy() for n in PARAMS}
     g["viewspace"] = pkg["viewspace_points"].grad.detach().cpu().numpy().copy()
@@ -171,20 +176,45 @@ def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg):
     # ---- leg B: the stage-1 loss of train_gaussians.py:126-140 (masked L1 + SSIM + mask L1 + orientation, run.sh
     # weights) towards the render of a perturbed model.  The SSIM window couples neighbouring pixels, so the masked
     # pixels are neutralised by VALUE as well: both chains see the oracle chain's numbers there, without gradient.
+    # The loss itself has kinks (|x - gt| at 0, the wrapped orientation difference at 0 and +-1/2, the mirror sign and
+    # the acos clamp of gaussian_renderer/__init__.py:102-105): pixels where the oracle chain sits within 2e-4 of one
+    # are "loss-fragile" -- the two chains may legitimately take different branches there -- and join the mask.
     opt = OptimizationParams()
     opt.lambda_dorient = 0.1
     gt = syn.make_model(spec, dev)
     with torch.no_grad():
+        gen = torch.Generator().manual_seed(202)
         gt._features_dc.add_(0.3)
-        gt._xyz.add_(0.002 * torch.randn(gt._xyz.shape, generator=torch.Generator().manual_seed(202)).to(dev))
+        gt._xyz.add_(0.002 * torch.randn(gt._xyz.shape, generator=gen).to(dev))
+        gt._rotation.add_(0.05 * torch.randn(gt._rotation.shape, generator=gen).to(dev))
         pgt = render(cg, gt, FUSED, syn.background(dev))
-        maps = dict(original_image=pgt["render"].clamp(0, 1), original_mask=pgt["mask"].clamp(0, 1),
-                    original_orient_angle=pgt["orient_angle"].clone(),
+        # the maps are pushed away from the model's own render (scale + offset) so that |x - gt| and the wrapped
+        # orientation difference sit at a kink only by coincidence, as with real photographs
+        maps = dict(original_image=(pgt["render"] * 0.85 + 0.03).clamp(0, 1),
+                    original_mask=(pgt["mask"] * 0.9 + 0.02).clamp(0, 1),
+                    original_orient_angle=torch.remainder(pgt["orient_angle"] + 0.013, 1.0),
                     original_orient_conf=torch.ones_like(pgt["orient_conf"]))
     for k, v in maps.items():
         setattr(cg, k, v.detach().contiguous())
         setattr(cc, k, v.detach().cpu().contiguous())
     del gt, pgt
+    with torch.no_grad():
+        eps = 2e-4  # twice the image tolerance: the chains' own values may differ by up to 1e-4
+        pk = pc.renders_packed.detach()
+        lf = ((pk[0:3] - cc.original_image).abs() < eps).any(dim=0) & (cc.original_mask[1] > 0)
+        lf |= ((pk[3:5] - cc.original_mask).abs() < eps).any(dim=0)
+        d2 = pk[5:7]
+        nrm = d2.norm(dim=0)
+        hair = cc.original_mask[0] > 0                       # weight of the orientation term (train_gaussians.py:130)
+        ydir = d2[1].abs() / nrm.clamp_min(1e-30)
+        dd = pc["orient_angle"].detach()[0] - cc.original_orient_angle[0]
+        kink = torch.stack([dd.abs(), (dd - 0.5).abs(), (dd + 0.5).abs(), (dd - 1).abs(), (dd + 1).abs()]).min(dim=0).values
+        lf |= hair & ((nrm < 1e-3) | (d2[0].abs() < 1e-4 * nrm) | ((ydir - (1 - 1e-3)).abs() < eps) | (kink < eps))
+        has_splats = torch.from_numpy((ob_state_n_contrib(pc) > 0).reshape(H, W))
+        stats["loss_fragile"] = float((lf & has_splats).float().mean())
+        print("fullsize", cfg, stats, flush=True)
+        assert stats["loss_fragile"] < 2e-2, stats
+        mask = mask | lf
     frozen = pc.renders_packed.detach()
     packed_c = torch.where(mask[None], frozen, pc.renders_packed)
     packed_g = torch.where(mask[None].to(dev), frozen.to(dev), pg.renders_packed)

@@ -8,7 +8,8 @@ import sys
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussianhaircut_amd import _lib  # noqa: E402
 from gaussianhaircut_amd.utils import synthetic as syn  # noqa: E402
 from tests.gpu_helpers import GpuRun, to_dev, _ptr, _stream  # noqa: E402
