@@ -94,7 +94,56 @@ __device__ __forceinline__ uint32_t lanes_below(unsigned long long m)  // set bi
 }
 #endif
 
-typedef float f2b __attribute__((ext_vector_type(2)));
+typedef float f2b __attribute__((ext_vector_type(2)));  // pairs of pixel rows: v_pk_mul / v_pk_add / v_pk_fma
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Which of the tile's 16 cells (c = 4 band + g: band = 4 pixel rows, g = 4 pixel columns) the alpha >= 1/255 region of a
+// splat can touch: alpha_bbox + ellipse_params + ellipse_band_extent of ghr_device.h (same formulas, same margins) with
+// the hardware log / sqrt / rcp instead of the correctly rounded library expansions -- the 1 % + 0.01 px (box) and
+// 2 % + 0.05 / 0.02 px (ellipse) margins exceed their 1-ulp errors by four orders of magnitude, and a cull only has
+// to be conservative: which pairs contribute is decided per pixel by the exact alpha test.
+__device__ __forceinline__ uint32_t cell_mask16(const f4& a0, const f4& a1, float wx0, float wy0)
+{
+    const float BIG = 3.0e38f;
+    const float o = a1.y, cx = a0.z, cy = a0.w, cz = a1.x;
+    if (o < 0.999f * (1.0f / 255.0f)) return 0u;  // alpha <= o < 1/255 everywhere
+    const float L = 0.6931471805599453f * __builtin_amdgcn_logf(255.0f * o);
+    const float det = cx * cz - cy * cy;
+    const bool pd = (L >= 1.0e-3f) && (cx > 0.0f) && (cz > 0.0f);
+    float bx0 = -BIG, bx1 = BIG, by0 = -BIG, by1 = BIG;
+    if (pd && det > 0.0f) {
+        const float kk = 2.0f * L * fast_rcp(det);
+        const float hx = 1.01f * fast_sqrt(kk * cz) + 0.01f, hy = 1.01f * fast_sqrt(kk * cx) + 0.01f;
+        if (hx < BIG && hy < BIG) { bx0 = a0.x - hx; bx1 = a0.x + hx; by0 = a0.y - hy; by1 = a0.y + hy; }
+    }
+    float e_x = 0.f, e_det = -1.f, e_icx = 0.f, e_k = 0.f;  // ellipse_params; e_det <= 0: box only
+    if (pd && det > 1.0e-4f * cx * cz && L < 100.0f) {
+        const float thr = 2.04f * L + 0.05f;
+        const float hx = fast_sqrt(thr * cz * fast_rcp(det));
+        const float kq = cy * hx * fast_rcp(cz);
+        if (hx < BIG && fabsf(kq) < BIG) { e_x = cx * thr; e_det = det; e_icx = fast_rcp(cx); e_k = kq; }
+    }
+    uint32_t cm = 0u;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const float cy0 = wy0 + 4.0f * b;
+        const bool yhit = !(by1 < cy0 || by0 > cy0 + 3.0f);
+        float lo = -BIG, hi = BIG;
+        if (e_det > 0.0f) {
+            const float ay = a0.y - (cy0 + 3.0f), by = a0.y - cy0;
+            const float dyr = fminf(by, fmaxf(ay, -e_k)), dyl = fminf(by, fmaxf(ay, e_k));
+            const float Dr = fmaxf(e_x - e_det * dyr * dyr, 0.0f), Dl = fmaxf(e_x - e_det * dyl * dyl, 0.0f);
+            hi = (-cy * dyr + fast_sqrt(Dr)) * e_icx + 0.02f;
+            lo = (-cy * dyl - fast_sqrt(Dl)) * e_icx - 0.02f;
+        }
+        const float xl = fmaxf(bx0, a0.x - hi), xr = fminf(bx1, a0.x - lo);
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if (yhit && !(xr < wx0 + 4.0f * g || xl > wx0 + 4.0f * g + 3.0f)) cm |= 1u << (4 * b + g);
+    }
+    return cm;
+}
+#endif
 
 __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, int gx, uint32_t T_tiles,
                                                                const uint32_t* __restrict__ tile_start,
@@ -116,6 +165,7 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
     __shared__ float s_T[GHR_BLOCK], s_PS[GHR_BLOCK];        // tile pixels: T and PS + T_final bg.dL carried over chunks
     __shared__ uint32_t s_last[GHR_BLOCK];                   // tile pixels: n_contrib
     __shared__ uint32_t s_gmax[16];                          // per cell: largest n_contrib
+    __shared__ uint32_t s_next;                              // next cell of the batch nobody has taken yet
 
     const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
     if (tile >= T_tiles) return;  // grid padding
@@ -125,6 +175,23 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
 
     const uint32_t beg = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - beg;  // see k_render_bwd for `cap`
+
+    // The list is walked back to front in batches of 256 from its END: batch entry j of the batch at `base` is list
+    // position n-1-(base+j).  Which positions are dead (>= the largest n_contrib of the tile / of a cell,
+    // backward.cu:490-492) is only known once the pixels are in, but the entries of the first batch do not depend on
+    // it: they are requested together with the pixel data (one memory round trip for both).
+    uint32_t e_id = 0u;
+    f4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0, e3 = e0;
+    rect4 e_rc = make_rect4(0, 0, 0, 0, 0u);
+    auto fetch_entry = [&](uint32_t base) {
+        if (base + (uint32_t)tid < n) {
+            e_id = point_list[beg + (n - 1 - (base + tid))];
+            const f4* r = rec + 4 * (size_t)e_id;
+            e0 = r[0]; e1 = r[1]; e2 = r[2]; e3 = r[3];
+            e_rc = rects[e_id];
+        }
+    };
+    fetch_entry(0u);
 
     if (tid < 16) s_gmax[tid] = 0u;
     __syncthreads();
@@ -151,51 +218,45 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
     uint32_t n_eff = 0;
 #pragma unroll
     for (int c = 0; c < 16; c++) n_eff = max(n_eff, s_gmax[c]);
-    n_eff = min(n, n_eff);  // entries at list positions >= max n_contrib are skipped by every pixel (backward.cu:490-492)
+    n_eff = min(n, n_eff);  // positions >= the tile's largest n_contrib are skipped by every pixel (backward.cu:490-492)
 
-    for (uint32_t base = 0; base < n_eff; base += GHR_BLOCK) {
-        const uint32_t cnt = min((uint32_t)GHR_BLOCK, n_eff - base);
-        __syncthreads();  // previous batch fully consumed
-        uint32_t cm = 0;
+    for (uint32_t base = 0; base < n; base += GHR_BLOCK) {
+        const uint32_t cnt = min((uint32_t)GHR_BLOCK, n - base);
+        if (base > 0) fetch_entry(base);
+        const bool live_batch = n - base - cnt < n_eff;  // its lowest position lies below n_eff (workgroup-uniform)
+        if (live_batch) __syncthreads();                 // previous batch fully consumed
+        uint32_t cm = 0u;
         if ((uint32_t)tid < cnt) {
-            // walk back to front: batch entry j is list position n_eff-1-(base+j)
-            const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
-            const f4* r = rec + 4 * (size_t)id;
-            const f4 a0 = r[0], a1 = r[1], a2 = r[2], a3 = r[3];
-            const uint32_t slot = min(rect4_slot(rects[id], tx, ty), cap - 1u);
+            const uint32_t slot = min(rect4_slot(e_rc, tx, ty), cap - 1u);
             f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)slot;  // zero the instance's gradient line
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
             dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
-            s_slot[tid] = slot;
-            s_r0[tid] = a0; s_r1[tid] = a1;
-            s_col[0][tid] = a1.z; s_col[1][tid] = a1.w;
-            s_col[2][tid] = a2.x; s_col[3][tid] = a2.y; s_col[4][tid] = a2.z; s_col[5][tid] = a2.w;
-            s_col[6][tid] = a3.x; s_col[7][tid] = a3.y; s_col[8][tid] = a3.z; s_col[9][tid] = a3.w;
-            // cells of the tile (c = 4 band + g, band = 4 pixel rows, g = 4 pixel columns) whose pixels the alpha >= 1/255
-            // region can touch: box, then x-extent of the ellipse restricted to the band (ghr_device.h, cell_masks)
-            const f4 bb = alpha_bbox(a0, a1), ep = ellipse_params(a0, a1);
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const float cy0 = wy0 + 4.0f * b;
-                const bool yhit = !(bb.w < cy0 || bb.z > cy0 + 3.0f);
-                float lo, hi;
-                ellipse_band_extent(a0.w, ep, a0.y - (cy0 + 3.0f), a0.y - cy0, lo, hi);
-                const float xl = fmaxf(bb.x, a0.x - hi), xr = fminf(bb.y, a0.x - lo);
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                    if (yhit && !(xr < wx0 + 4.0f * g || xl > wx0 + 4.0f * g + 3.0f)) cm |= 1u << (4 * b + g);
+            if (live_batch) {
+                s_slot[tid] = slot;
+                s_r0[tid] = e0; s_r1[tid] = e1;
+                s_col[0][tid] = e1.z; s_col[1][tid] = e1.w;
+                s_col[2][tid] = e2.x; s_col[3][tid] = e2.y; s_col[4][tid] = e2.z; s_col[5][tid] = e2.w;
+                s_col[6][tid] = e3.x; s_col[7][tid] = e3.y; s_col[8][tid] = e3.z; s_col[9][tid] = e3.w;
+                if (n - 1 - (base + tid) < n_eff) cm = cell_mask16(e0, e1, wx0, wy0);
             }
         }
+        if (!live_batch) continue;  // every entry of the batch is dead: its lines read as zero, nothing else to do
         s_cmask[tid] = (uint16_t)cm;
+        if (tid == 0) s_next = 0u;
         __syncthreads();  // also orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
 
-        // wave `wave` owns the band of cells 4 wave .. 4 wave + 3, one cell at a time
-        for (int g = 0; g < 4; g++) {
-            const int cell = 4 * wave + g;
+        // The 16 cells of the batch are dealt to the four waves as they become free (needle lists differ a lot between
+        // the cells of a tile; a static band per wave left three waves waiting at the barrier for the longest one).
+        for (;;) {
+            uint32_t cell = 0u;
+            if (lane == 0) cell = atomicAdd(&s_next, 1u);
+            cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
+            if (cell >= 16u) break;
+            const int band = (int)(cell >> 2), g = (int)(cell & 3u);
             // ---- this cell's entries of the batch, in list order, compacted into s_list[wave][0 .. n_c)
             uint32_t n_c = 0;
-            // entry j sits at list position n_eff-1-(base+j); positions >= the cell's max n_contrib are dead for it
-            const long long jmin = (long long)n_eff - (long long)s_gmax[cell] - (long long)base;
+            // entry j sits at list position n-1-(base+j); positions >= the cell's max n_contrib are dead for it
+            const long long jmin = (long long)n - (long long)s_gmax[cell] - (long long)base;
 #pragma unroll
             for (int sub = 0; sub < 4; sub++) {
                 if (64u * sub < cnt) {  // wave-uniform
@@ -210,25 +271,21 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
             __builtin_amdgcn_wave_barrier();
 
             // ---- the cell's pixels: lane (k, m) evaluates the pixels (k, q), q = 0..3; p = 16 y + x inside the tile
-            const int p0 = (16 * wave) * 4 + 4 * g + k;  // (x = 4g + k, y = 4 wave): + 16 q
-            float Tin[4], PS[4];
-            uint32_t last[4];
-            float phiW[4];  // B operand of the colour MFMAs: dL/dpixel[m - 6] of pixel q (components 6..15 of the line)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                Tin[q] = s_T[p0 + 16 * q];
-                PS[q] = s_PS[p0 + 16 * q];
-                last[q] = s_last[p0 + 16 * q];
-                phiW[q] = m >= 6 ? s_dL[m >= 6 ? m - 6 : 0][p0 + 16 * q] : 0.f;
-            }
+            const int p0 = 64 * band + 4 * g + k;  // (x = 4g + k, y = 4 band): + 16 q
+            f2b TinA = {s_T[p0], s_T[p0 + 16]}, TinB = {s_T[p0 + 32], s_T[p0 + 48]};
+            f2b PSA = {s_PS[p0], s_PS[p0 + 16]}, PSB = {s_PS[p0 + 32], s_PS[p0 + 48]};
+            const uint32_t last0 = s_last[p0], last1 = s_last[p0 + 16], last2 = s_last[p0 + 32], last3 = s_last[p0 + 48];
+            // B operand of the colour MFMAs: dL/dpixel[m - 6] of pixel q (components 6..15 of the line)
+            const int mc = m >= 6 ? m - 6 : 0;
+            const float phiW0 = m >= 6 ? s_dL[mc][p0] : 0.f, phiW1 = m >= 6 ? s_dL[mc][p0 + 16] : 0.f;
+            const float phiW2 = m >= 6 ? s_dL[mc][p0 + 32] : 0.f, phiW3 = m >= 6 ? s_dL[mc][p0 + 48] : 0.f;
             // A operand of the colour-dot MFMAs: row i = m of the product is the cell pixel (x = m >> 2, y = m & 3), so
             // that lane (k, e) finds the dots of ITS pixels (k, 0..3) in its four result registers
-            const int pa = 16 * (4 * wave + (m & 3)) + 4 * g + (m >> 2);
-            float dLA[3];
-#pragma unroll
-            for (int s = 0; s < 3; s++) dLA[s] = (4 * s + k < GHR_C) ? s_dL[(4 * s + k < GHR_C) ? 4 * s + k : 0][pa] : 0.f;
+            const int pa = 16 * (4 * band + (m & 3)) + 4 * g + (m >> 2);
+            const float dLA0 = s_dL[k][pa], dLA1 = s_dL[4 + k][pa], dLA2 = k < 2 ? s_dL[k < 2 ? 8 + k : 0][pa] : 0.f;
             const float u = (float)(4 * g + k);                 // pixel - tile origin, x
-            const float v0 = (float)(4 * wave);                 // ... y of q = 0
+            const float v0 = (float)(4 * band);                 // ... y of q = 0
+            const f2b vA = {v0, v0 + 1.f}, vB = {v0 + 2.f, v0 + 3.f};
             // B operands of the geometry MFMAs: which line component a lane's column m receives
             const float phiSX = m == 0 ? 1.f : (m == 2 ? u : 0.f);   // a = sum_q Q dx      -> L0 (x1), L2 (x u)
             const float phi1 = m == 1 ? 1.f : 0.f;                   // a = sum_q Q dy      -> L1
@@ -236,72 +293,75 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
             const float phi4 = m == 4 ? 1.f : 0.f;                   // a = sum_q Q dy v_q  -> L4
             const float phi5 = m == 5 ? 1.f : 0.f;                   // a = sum_q Q         -> L5
             const float pxf = wx0 + u;
-            const float pyf0 = wy0 + v0;
+            const f2b pyA = {wy0 + v0, wy0 + v0 + 1.f}, pyB = {wy0 + v0 + 2.f, wy0 + v0 + 3.f};
+            const int kc2 = k < 2 ? 8 + k : 0;
 
+            // entry of the next chunk, requested one chunk ahead (its LDS round trips hide behind the arithmetic)
+            bool nv = m < n_c;
+            uint32_t nj = nv ? (uint32_t)s_list[wave][m] : 0u;
+            f4 nr0 = s_r0[nj], nr1 = s_r1[nj];
+            float nc0 = s_col[k][nj], nc1 = s_col[4 + k][nj], nc2 = k < 2 ? s_col[kc2][nj] : 0.f;
             for (uint32_t c0 = 0; c0 < n_c; c0 += 16) {
-                const bool valid = c0 + m < n_c;
-                const uint32_t j = valid ? (uint32_t)s_list[wave][c0 + m] : 0u;
-                const f4 r0 = s_r0[j], r1 = s_r1[j];
-                float col[3];
-#pragma unroll
-                for (int s = 0; s < 3; s++) col[s] = (4 * s + k < GHR_C) ? s_col[(4 * s + k < GHR_C) ? 4 * s + k : 0][j] : 0.f;
+                const bool valid = nv;
+                const uint32_t j = nj;
+                const f4 r0 = nr0, r1 = nr1;
+                const float col0 = nc0, col1 = nc1, col2 = nc2;
+                if (c0 + 16 < n_c) {  // wave-uniform
+                    nv = c0 + 16 + m < n_c;
+                    nj = nv ? (uint32_t)s_list[wave][c0 + 16 + m] : 0u;
+                    nr0 = s_r0[nj]; nr1 = s_r1[nj];
+                    nc0 = s_col[k][nj]; nc1 = s_col[4 + k][nj]; nc2 = k < 2 ? s_col[kc2][nj] : 0.f;
+                }
                 // colour . dL/dpixel for the lane's four pixels
                 f4 cd = {0.f, 0.f, 0.f, 0.f};
-                cd = mfma16(dLA[0], col[0], cd);
-                cd = mfma16(dLA[1], col[1], cd);
-                cd = mfma16(dLA[2], col[2], cd);
+                cd = mfma16(dLA0, col0, cd);
+                cd = mfma16(dLA1, col1, cd);
+                cd = mfma16(dLA2, col2, cd);
 
-                const uint32_t pos = n_eff - 1 - (base + j);  // 0-based list position == the reference's `contributor`
+                const uint32_t pos = n - 1 - (base + j);  // 0-based list position == the reference's `contributor`
                 const float o = r1.y;
                 const float dx = r0.x - pxf;
                 const float t1 = r0.z * dx * dx;   // unfused, source order: feeds the same discrete decisions as K7
                 const float t3 = r0.w * dx;
-                float alpha[4], G[4], dy[4], om[4];
-                bool ct[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    dy[q] = r0.y - (pyf0 + (float)q);
-                    const float power = -0.5f * (t1 + r1.x * dy[q] * dy[q]) - t3 * dy[q];
-                    const float G_raw = fast_exp(power);
-                    const float alpha_raw = fminf(0.99f, o * G_raw);
-                    ct[q] = valid && pos < last[q] && !(power > 0.0f) && !(alpha_raw < 1.0f / 255.0f);
-                    alpha[q] = ct[q] ? alpha_raw : 0.0f;
-                    G[q] = ct[q] ? G_raw : 0.0f;
-                    om[q] = 1.f - alpha[q];
-                }
-                float A0 = om[0], A1 = om[1], A2 = om[2], A3 = om[3];
+                const f2b dyA = r0.y - pyA, dyB = r0.y - pyB;
+                const f2b pwA = -0.5f * (t1 + r1.x * dyA * dyA) - t3 * dyA, pwB = -0.5f * (t1 + r1.x * dyB * dyB) - t3 * dyB;
+                const f2b eA = pwA * 1.4426950408889634f, eB = pwB * 1.4426950408889634f;
+                const f2b GrA = {__builtin_amdgcn_exp2f(eA.x), __builtin_amdgcn_exp2f(eA.y)};
+                const f2b GrB = {__builtin_amdgcn_exp2f(eB.x), __builtin_amdgcn_exp2f(eB.y)};
+                const f2b oA = o * GrA, oB = o * GrB;
+                const float ar0 = fminf(0.99f, oA.x), ar1 = fminf(0.99f, oA.y), ar2 = fminf(0.99f, oB.x), ar3 = fminf(0.99f, oB.y);
+                const bool ct0 = valid && pos < last0 && !(pwA.x > 0.0f) && !(ar0 < 1.0f / 255.0f);
+                const bool ct1 = valid && pos < last1 && !(pwA.y > 0.0f) && !(ar1 < 1.0f / 255.0f);
+                const bool ct2 = valid && pos < last2 && !(pwB.x > 0.0f) && !(ar2 < 1.0f / 255.0f);
+                const bool ct3 = valid && pos < last3 && !(pwB.y > 0.0f) && !(ar3 < 1.0f / 255.0f);
+                const f2b alA = {ct0 ? ar0 : 0.f, ct1 ? ar1 : 0.f}, alB = {ct2 ? ar2 : 0.f, ct3 ? ar3 : 0.f};
+                const f2b GA = {ct0 ? GrA.x : 0.f, ct1 ? GrA.y : 0.f}, GB = {ct2 ? GrB.x : 0.f, ct3 ? GrB.y : 0.f};
+                const f2b omA = 1.f - alA, omB = 1.f - alB;
+                // 1 / (1 - alpha), and its running product over the row: T_i = T_in prod_{j<=i} 1/(1 - alpha_j)  (:507)
+                const f2b invA = {fast_rcp(omA.x), fast_rcp(omA.y)}, invB = {fast_rcp(omB.x), fast_rcp(omB.y)};
+                float A0 = invA.x, A1 = invA.y, A2 = invB.x, A3 = invB.y;
                 row_scan_mul4(A0, A1, A2, A3);
-                const float Acum[4] = {A0, A1, A2, A3};
-                float T[4], Wq[4], cdot[4], inv[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    T[q] = Tin[q] * fast_rcp(Acum[q]);           // backward.cu:507, as a product over the row
-                    inv[q] = fast_rcp(om[q]);
-                    // a pair that does not contribute must not leak a non-finite colour of its Gaussian (0 * inf)
-                    cdot[q] = ct[q] ? (q == 0 ? cd.x : (q == 1 ? cd.y : (q == 2 ? cd.z : cd.w))) : 0.0f;
-                    Wq[q] = alpha[q] * T[q] * cdot[q];
-                }
-                float S0 = Wq[0], S1 = Wq[1], S2 = Wq[2], S3 = Wq[3], E0, E1, E2, E3, R0, R1, R2, R3;
+                const f2b TA = TinA * f2b{A0, A1}, TB = TinB * f2b{A2, A3};
+                // a pair that does not contribute must not leak a non-finite colour of its Gaussian (0 * inf)
+                const f2b cdA = {ct0 ? cd.x : 0.f, ct1 ? cd.y : 0.f}, cdB = {ct2 ? cd.z : 0.f, ct3 ? cd.w : 0.f};
+                const f2b wA = alA * TA, wB = alB * TB;       // backward.cu:508,527
+                const f2b WA = wA * cdA, WB = wB * cdB;
+                float S0 = WA.x, S1 = WA.y, S2 = WB.x, S3 = WB.y, E0, E1, E2, E3, R0, R1, R2, R3;
                 row_scan_add4(S0, S1, S2, S3, E0, E1, E2, E3, R0, R1, R2, R3);
-                const float Ex[4] = {E0, E1, E2, E3}, Rt[4] = {R0, R1, R2, R3};
-                float SQ = 0.f, SX = 0.f, SXv = 0.f, SY = 0.f, SYv = 0.f, w[4];
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    // (cdot - accum_rec . dL) T  -  T_final bg.dL / (1 - alpha)   (backward.cu:523-538)
-                    const float dL_dalpha = fma_(-inv[q], PS[q] + Ex[q], cdot[q] * T[q]);
-                    const float Q = G[q] * dL_dalpha;
-                    const float qx = Q * dx, qy = Q * dy[q], vq = v0 + (float)q;
-                    SQ += Q;
-                    SX += qx;
-                    SXv = fma_(qx, vq, SXv);
-                    SY += qy;
-                    SYv = fma_(qy, vq, SYv);
-                    w[q] = alpha[q] * T[q];       // backward.cu:508,527
-                    PS[q] += Rt[q];               // carried to the next chunk
-                }
-                float TL0 = T[0], TL1 = T[1], TL2 = T[2], TL3 = T[3];
+                // (cdot - accum_rec . dL) T  -  T_final bg.dL / (1 - alpha)   (backward.cu:523-538)
+                const f2b dLdaA = __builtin_elementwise_fma(-invA, PSA + f2b{E0, E1}, cdA * TA);
+                const f2b dLdaB = __builtin_elementwise_fma(-invB, PSB + f2b{E2, E3}, cdB * TB);
+                const f2b QA = GA * dLdaA, QB = GB * dLdaB;
+                const f2b qxA = QA * dx, qxB = QB * dx, qyA = QA * dyA, qyB = QB * dyB;
+                const f2b sq = QA + QB, sx = qxA + qxB, sy = qyA + qyB;
+                const f2b sxv = __builtin_elementwise_fma(qxA, vA, qxB * vB), syv = __builtin_elementwise_fma(qyA, vA, qyB * vB);
+                const float SQ = sq.x + sq.y, SX = sx.x + sx.y, SY = sy.x + sy.y, SXv = sxv.x + sxv.y, SYv = syv.x + syv.y;
+                PSA += f2b{R0, R1};  // carried to the next chunk
+                PSB += f2b{R2, R3};
+                float TL0 = TA.x, TL1 = TA.y, TL2 = TB.x, TL3 = TB.y;
                 row_last4(TL0, TL1, TL2, TL3);
-                Tin[0] = TL0; Tin[1] = TL1; Tin[2] = TL2; Tin[3] = TL3;
+                TinA = f2b{TL0, TL1};
+                TinB = f2b{TL2, TL3};
 
                 // line components of the chunk's 16 entries: lane (k', c) gets component c of the entries 4k' + r
                 f4 da = {0.f, 0.f, 0.f, 0.f}, db = da;
@@ -310,10 +370,10 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
                 da = mfma16(SY, phi1, da);
                 db = mfma16(SYv, phi4, db);
                 da = mfma16(SQ, phi5, da);
-                db = mfma16(w[0], phiW[0], db);
-                da = mfma16(w[1], phiW[1], da);
-                db = mfma16(w[2], phiW[2], db);
-                da = mfma16(w[3], phiW[3], da);
+                db = mfma16(wA.x, phiW0, db);
+                da = mfma16(wA.y, phiW1, da);
+                db = mfma16(wB.x, phiW2, db);
+                da = mfma16(wB.y, phiW3, da);
                 const f4 d = da + db;
                 // a DPP row adds one whole 64-B line per register: resolved in this XCD's L2 (only this workgroup ever
                 // touches the instance's line)
@@ -328,18 +388,11 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
                 }
             }
             if (m == 0) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) { s_T[p0 + 16 * q] = Tin[q]; s_PS[p0 + 16 * q] = PS[q]; }
+                s_T[p0] = TinA.x; s_T[p0 + 16] = TinA.y; s_T[p0 + 32] = TinB.x; s_T[p0 + 48] = TinB.y;
+                s_PS[p0] = PSA.x; s_PS[p0 + 16] = PSA.y; s_PS[p0 + 32] = PSB.x; s_PS[p0 + 48] = PSB.y;
             }
             __builtin_amdgcn_wave_barrier();
         }
-    }
-    // list entries no pixel of the tile ever reached (positions >= n_eff): their slots must read as zero
-    for (uint32_t i = n_eff + tid; i < n; i += GHR_BLOCK) {
-        const uint32_t id = point_list[beg + i];
-        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)min(rect4_slot(rects[id], tx, ty), cap - 1u);
-        const f4 zero = {0.f, 0.f, 0.f, 0.f};
-        dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
     }
 #endif
 }
