@@ -27,14 +27,15 @@ thread_local char g_err[512] = "";
 // Process-wide (NOT thread_local): torch's autograd engine calls ghr_backward from its own worker thread.
 hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
 
-// K8 variant: 1 = scan form (k_render_bwd_scan, lanes bound to pairs, MFMA reduction; default), 0 = cell-group form
-// (k_render_bwd).  GHR_K8=cell|scan overrides (kernel experiments, A/B timing); both leave the same line format.
+// K8 variant: 0 = cell-group form (k_render_bwd; default: 0.24 ms on 500k strands), 1 = scan form (k_render_bwd_scan:
+// lanes bound to pairs, MFMA reduction; half the VALU instructions but 0.26-0.28 ms -- at four waves per SIMD its
+// load / staging phases do not overlap with the arithmetic).  GHR_K8=cell|scan selects; same line format.
 int k8_variant()
 {
     static int v = -1;
     if (v < 0) {
         const char* e = std::getenv("GHR_K8");
-        v = (e && std::strcmp(e, "cell") == 0) ? 0 : 1;
+        v = (e && std::strcmp(e, "scan") == 0) ? 1 : 0;
     }
     return v;
 }

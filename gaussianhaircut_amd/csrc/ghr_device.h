@@ -320,6 +320,15 @@ GHR_HD float fast_rcp(float x)
 #endif
 }
 GHR_HD float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// v_log_f32 (log2, 1 ulp) * ln 2 instead of the correctly rounded logf expansion (~25 VALU)
+GHR_HD float fast_log(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 0.6931471805599453f * __builtin_amdgcn_logf(x);
+#else
+    return logf(x);
+#endif
+}
 
 // ---- exact culling of list entries per pixel strip ---------------------------------------------------------------------
 // A splat only contributes to pixels where alpha = min(.99, o*exp(power)) >= 1/255 (forward.cu:369-371), i.e. inside the
@@ -334,11 +343,13 @@ GHR_HD f4 alpha_bbox(const f4& r0, const f4& r1)
     const float BIG = 3.0e38f;
     const float o = r1.y, cx = r0.z, cy = r0.w, cz = r1.x;
     if (o < 0.999f * (1.0f / 255.0f)) return f4{BIG, -BIG, BIG, -BIG};  // alpha <= o < 1/255 everywhere: empty
-    const float L = logf(255.0f * o);
+    // hardware log / rcp / sqrt (1 ulp each) on the device: the margins below exceed their error by four orders of
+    // magnitude, and a cull only has to be conservative
+    const float L = fast_log(255.0f * o);
     const float det = cx * cz - cy * cy;
     if (!(L >= 1.0e-3f) || !(det > 0.0f) || !(cx > 0.0f) || !(cz > 0.0f)) return f4{-BIG, BIG, -BIG, BIG};
-    const float k = 2.0f * L / det;
-    const float hx = 1.01f * sqrtf(k * cz) + 0.01f, hy = 1.01f * sqrtf(k * cx) + 0.01f;
+    const float k = 2.0f * L * fast_rcp(det);
+    const float hx = 1.01f * fast_sqrt(k * cz) + 0.01f, hy = 1.01f * fast_sqrt(k * cx) + 0.01f;
     if (!(hx < BIG) || !(hy < BIG)) return f4{-BIG, BIG, -BIG, BIG};
     return f4{r0.x - hx, r0.x + hx, r0.y - hy, r0.y + hy};
 }
@@ -360,14 +371,14 @@ GHR_HD f4 ellipse_params(const f4& r0, const f4& r1)
 {
     const float o = r1.y, cx = r0.z, cy = r0.w, cz = r1.x;
     const float det = cx * cz - cy * cy;
-    const float L = logf(255.0f * fmaxf(o, 1.0e-30f));
+    const float L = fast_log(255.0f * fmaxf(o, 1.0e-30f));
     if (!(L >= 1.0e-3f) || !(cx > 0.0f) || !(cz > 0.0f) || !(det > 1.0e-4f * cx * cz) || !(L < 100.0f))
         return f4{0.f, -1.f, 0.f, 0.f};
     const float thr = 2.04f * L + 0.05f;
-    const float hx = sqrtf(thr * cz / det);
-    const float k = cy * hx / cz;
+    const float hx = fast_sqrt(thr * cz * fast_rcp(det));
+    const float k = cy * hx * fast_rcp(cz);
     if (!(hx < 3.0e38f) || !(fabsf(k) < 3.0e38f)) return f4{0.f, -1.f, 0.f, 0.f};
-    return f4{cx * thr, det, 1.0f / cx, k};
+    return f4{cx * thr, det, fast_rcp(cx), k};
 }
 // x-extent [lo, hi] (in d = mean - pixel) of the ellipse restricted to the band dy in [ay, by]; the band must
 // intersect the ellipse's y-extent (the box test guarantees it).  Degenerate conics: the whole axis.
@@ -376,8 +387,8 @@ GHR_HD void ellipse_band_extent(float cy, const f4& ep, float ay, float by, floa
     if (!(ep.y > 0.0f)) { lo = -3.0e38f; hi = 3.0e38f; return; }
     const float dyr = fminf(by, fmaxf(ay, -ep.w)), dyl = fminf(by, fmaxf(ay, ep.w));
     const float Dr = fmaxf(ep.x - ep.y * dyr * dyr, 0.0f), Dl = fmaxf(ep.x - ep.y * dyl * dyl, 0.0f);
-    hi = (-cy * dyr + sqrtf(Dr)) * ep.z + 0.02f;
-    lo = (-cy * dyl - sqrtf(Dl)) * ep.z - 0.02f;
+    hi = (-cy * dyr + fast_sqrt(Dr)) * ep.z + 0.02f;
+    lo = (-cy * dyl - fast_sqrt(Dl)) * ep.z - 0.02f;
 }
 // Full per-cell test used by the render kernels (and, pixel by pixel, by tests/hostsim): box, then ellipse extent.
 // (X0, Y0) = pixel coordinates of the cell's first pixel; the cell spans X0..X0+3, Y0..Y0+3.

@@ -32,10 +32,24 @@ PARAMS = ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf",
 FLOOR = 2e-6  # of the tensor's largest |ref|: fp32 cancellation noise of rows whose own gradient is ~0
 
 
-def _row_close(a, b, tol=hp.TOL, floor=FLOOR):
+def _row_close(a, b, tol=hp.TOL, floor=FLOOR, row_tol=None):
     a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
     rows = np.abs(b).max(axis=1, keepdims=True)
-    return np.abs(a - b) <= tol * (np.abs(b) + rows) + floor * np.abs(b).max()
+    t = tol if row_tol is None else row_tol.reshape(-1, 1)
+    return np.abs(a - b) <= t * (np.abs(b) + rows) + floor * np.abs(b).max()
+
+
+def _row_tolerance(model, conic_rel):
+    """Per-Gaussian tolerance for the smooth-loss leg.  The reference walks T <- T / (1 - alpha) (backward.cu:507) and
+    divides by (1 - alpha) again in dL/dalpha (:535-538): a relative difference eps in alpha comes out as
+    eps alpha / (1 - alpha) in every term the splat's brightest pixels contribute, up to 99 eps at the 0.99 clamp.  The
+    two chains' fp32 projections agree in the conic to `conic_rel` (measured above, ~2e-6), i.e. in alpha = o exp(power)
+    to |power| conic_rel <= ln(255) conic_rel inside the 1/255 contour.  With a random dL/dpixel (leg A) these errors
+    have random signs and vanish in the row sum; under a smooth loss they add up.  The bound is therefore
+    1e-4 + ln(255) conic_rel / (1 - min(0.99, opacity)): 1e-4 for faint splats, ~1.5e-3 for the opaque strand Gaussians
+    (opacity 0.999) -- the conditioning of the fp32 algorithm, not a property of either implementation."""
+    op = model.get_opacity.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    return hp.TOL + math.log(255.0) * conic_rel / (1.0 - np.minimum(0.99, op))
 
 
 def _assert_rows(name, a, b, tol=hp.TOL, floor=FLOOR):
@@ -99,7 +113,7 @@ def _chains(cfg, dev, deg=3):
     np.testing.assert_array_equal(ins["rec"][same, 0:2].view(np.uint32), st.xy[j].view(np.uint32))
     co_g, co_c = ins["rec"][same, 2:6], st.conic_opacity[j]
     rel = np.abs(co_g - co_c) / (np.abs(co_c).max(axis=1, keepdims=True) + 1e-30)
-    assert rel.max() < 1e-5, "conic / opacity of k_project vs the host projection: %g" % rel.max()
+    assert rel.max() < 5e-6, "conic / opacity of k_project vs the host projection: %g" % rel.max()
 
     # ---- binning: the tile lists are identical once the flipped Gaussians are taken out of both
     pl_c = idx[st.point_list.astype(np.int64)]
@@ -136,7 +150,8 @@ def _chains(cfg, dev, deg=3):
     assert (np.abs(ang_g - ang_c)[nrm > 1e-2] < 1e-3).all()
     vs_c, vs_g = pc["viewspace_points"].detach().numpy(), pg["viewspace_points"].detach().cpu().numpy()
     assert np.abs(vs_g[keep][:, :2] - vs_c[keep][:, :2]).max() < 1e-5
-    stats = dict(n_flip=n_flip, masked=float(mask.mean()), R=R, img_err=float(np.abs(img_g - img_c).max()))
+    stats = dict(n_flip=n_flip, masked=float(mask.mean()), R=R, img_err=float(np.abs(img_g - img_c).max()),
+                 conic_rel=float(rel.max()))
     return spec, (mc, cc, pc), (mg, cg, pg), torch.from_numpy(mask), stats
 
 
@@ -213,19 +228,49 @@ def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg):
         has_splats = torch.from_numpy((ob_state_n_contrib(pc) > 0).reshape(H, W))
         stats["loss_fragile"] = float((lf & has_splats).float().mean())
         print("fullsize", cfg, stats, flush=True)
-        assert stats["loss_fragile"] < 2e-2, stats
+        assert stats["loss_fragile"] < 4e-2, stats
         mask = mask | lf
     frozen = pc.renders_packed.detach()
     packed_c = torch.where(mask[None], frozen, pc.renders_packed)
     packed_g = torch.where(mask[None].to(dev), frozen.to(dev), pg.renders_packed)
+    packed_c.retain_grad()
+    packed_g.retain_grad()
     loss_c = view_loss(_package(packed_c, pc["viewspace_points"], pc["radii"]), cc, opt, fused=False)
     loss_g = stage1_loss(packed_g, cg.original_image, cg.original_mask, cg.original_orient_angle,
                          cg.original_orient_conf, opt.lambda_dl1, opt.lambda_dssim, opt.lambda_dmask,
                          opt.lambda_dorient)
-    assert abs(float(loss_g) - float(loss_c)) <= 2e-5 * abs(float(loss_c)), (float(loss_g), float(loss_c))
+    assert abs(float(loss_g.detach()) - float(loss_c.detach())) <= 2e-5 * abs(float(loss_c.detach())), (float(loss_g), float(loss_c))
     loss_c.backward()
     loss_g.backward()
+    # dL/d(packed output) of the two loss implementations on the unmasked pixels (the fused loss has its own parity
+    # tests against PyTorch, tests/test_gpu_loss_adam.py; here it locates a disagreement, should one appear)
+    dc = packed_c.grad.numpy().reshape(10, -1)
+    dg = packed_g.grad.cpu().numpy().reshape(10, -1)
+    keep_px = ~mask.numpy().reshape(-1)
+    dd = np.abs(dg - dc)[:, keep_px]
+    ch, px = np.unravel_index(np.argmax(dd), dd.shape)
+    stats["dL_err_of_max"] = float(dd.max() / np.abs(dc).max())
+    stats["dL_worst"] = (int(ch), int(np.nonzero(keep_px)[0][px]), float(dg[:, keep_px][ch, px]), float(dc[:, keep_px][ch, px]))
+    print("fullsize", cfg, stats, flush=True)
+    assert stats["dL_err_of_max"] < 1e-4, stats
     gc, gg = _grads(mc, pc), _grads(mg, pg)
+    # Primary criterion: the conditioning-aware per-row tolerance.  It accounts for a Gaussian's OWN opacity only; the
+    # transmittance in front of it is a product over the other splats of its rays, each contributing its own
+    # eps alpha / (1 - alpha).  Elements beyond the row tolerance are therefore counted, not ignored: at most 1e-5 of a
+    # tensor, none further than 20 x the row tolerance (+ the cancellation floor).
+    bad, outliers = {}, {}
+    row_tol = _row_tolerance(mc, stats["conic_rel"])
     for k in gc:
-        _assert_rows("legB " + k, gg[k], gc[k])
+        ok = _row_close(gg[k], gc[k], row_tol=row_tol)
+        if not ok.all():
+            ok20 = _row_close(gg[k], gc[k], row_tol=20 * row_tol, floor=20 * FLOOR)
+            a2, b2 = gg[k].reshape(len(gg[k]), -1), gc[k].reshape(len(gc[k]), -1)
+            r, c = np.unravel_index(np.argmax(np.abs(a2 - b2) * ~ok), ok.shape)
+            rec = (int((~ok).sum()), int(r), int(c), float(a2[r, c]), float(b2[r, c]), float(np.abs(b2[r]).max()),
+                   float(np.abs(b2).max()))
+            outliers[k] = rec
+            if (~ok).sum() > max(1, int(1e-5 * ok.size)) or not ok20.all():
+                bad[k] = rec
+    print("fullsize", cfg, "legB outliers (count, row, col, got, ref, row max, tensor max):", outliers, flush=True)
+    assert not bad, bad
     print("fullsize", cfg, stats, "loss", float(loss_c))
