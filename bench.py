@@ -5,21 +5,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
-A *step* is one global gradient step of the reference's stage-1 loop shape (src/train_gaussians.py:96-181, no
-densification) over the whole view batch: per rank ``views_per_gpu`` views (default 4 = the per-GPU shard
-of BASELINE.json configs[3], "32 views sharded 4-per-GPU on 8 GPUs"; the same 4 views per GPU at every N, so the series
-is weak scaling) of the 500k strand-aligned model at 1920x1080 -- render() (fused HIP
-projection + rasterizer forward), the four stage-1 losses incl. the orientation term (lambda_dorient = 0.1 as in
-run.sh:112-115), backward (HIP loss / rasterizer / projection backward), one flat all-reduce of the
-Gaussian gradients when N > 1 (RCCL), Adam.  Weak scaling: per-GPU work is fixed as N grows.  At N = 1 the line also
-carries ``single_view_step``: the same loop with ONE view per step (BASELINE.json configs[2]).
-
-One JSON line on rank 0:  value = Gaussians rasterized per second over the whole job = N * views_per_gpu * P / t_step
-(inputs resident in HBM; P = Gaussians of the model, every one of them goes through projection, cull and -- if
-visible -- the rasterizer, forward and backward, each step).
-  roofline     : k_render_bwd (the dominant kernel), algorithmic bytes / HIP-event duration recorded around the kernel
-                 inside the timed steps on the launch stream, against 8 TB/s HBM.
-  cpu_baseline : the CPU oracle (oracle/ghr_oracle.c, OpenMP) on ONE view of the same workload, rasterizer fwd+bwd only.
+HEADLINE (the one JSON line, rank 0): BASELINE.json configs[2] exactly -- one gradient step of the reference's stage-1
+loop shape (src/train_gaussians.py:96-181, no densification) on ONE 1920x1080 view of the 500k strand-aligned model per
+GPU: render() (fused HIP projection + rasterizer forward), the four stage-1 losses incl. the orientation term
+(lambda_dorient = 0.1, run.sh:112-115), backward (HIP loss / rasterizer / projection backward), [one flat all-reduce of
+the Gaussian gradients over RCCL when N > 1], Adam.  Inputs are resident in HBM.  Weak scaling: one view per GPU per
+step at every N (a global step covers N views).
+  value               = N * P_vis / t_step   Gaussians per second through the whole step, P_vis = Gaussians of the
+                        model that pass the cull of the view (radii > 0), NOT the model size
+  grad_steps_per_sec  = 1 / t_step
+  roofline            : k_render_bwd (the dominant kernel): SURVEY 8(d) algorithmic bytes / HIP-event duration on the
+                        launch stream over solo passes of the same view, against 8 TB/s HBM; `traffic` from the committed
+                        rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/).
+Further blocks of the same line (N = 1 unless noted), each named for the BASELINE config it measures:
+  config4_shard       : BASELINE configs[3]'s per-GPU shard -- 4 views per GPU per step, same model (every N)
+  op_only             : SURVEY 8(d)(i), the rasterizer op ALONE (GaussianRasterizer autograd op, mode A), cfg2
+                        (BASELINE configs[1], 100k blobs) and cfg3 (500k strands): Gaussians / (t_fwd + t_bwd), and the
+                        whole backward (K8 + per-Gaussian epilogue) against B_bwd = 140 P + 132 R + 48 N + 8 T
+  cpu_baseline        : the CPU oracle (oracle/ghr_oracle.c, OpenMP; pinned to the reference's CUDA) on the SAME scope as
+                        op_only.cfg3: rasterizer forward + backward of one view, Gaussians / (t_fwd + t_bwd)
 """
 from __future__ import annotations
 
@@ -47,8 +51,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3", choices=["cfg1", "cfg2", "cfg3", "cfg5", "tiny"])
-    ap.add_argument("--views-per-gpu", type=int, default=4,
-                    help="views per GPU per global step; 4 = the per-GPU shard of BASELINE.json configs[3] (32 views on 8 GPUs)")
+    ap.add_argument("--views-per-gpu", type=int, default=1,
+                    help="views per GPU per global step of the headline; 1 = BASELINE.json configs[2]")
+    ap.add_argument("--shard-views", type=int, default=4,
+                    help="views per GPU per step of the config4_shard block (BASELINE.json configs[3]: 32 views on 8 GPUs); 0 = skip")
     ap.add_argument("--streams", type=int, default=None,
                     help="HIP streams the views of a step alternate on (default: trainer's choice, 2; 1 = one stream, "
                          "the setting per-kernel rocprof averages should be taken with)")
@@ -80,21 +86,24 @@ def main():
 
     spec = syn.CONFIGS[args.workload]
     V = args.views_per_gpu
+    VS = max(args.shard_views, 0)
+    n_cams = max(V, VS)
     global_views = V * world
     opt = OptimizationParams()
     opt.lambda_dorient = 0.1  # the reference's stage-1 command line (run.sh:112-115)
 
     # ---- model replica (identical on every rank: CPU-seeded), per-rank views, synthetic ground truth ----------------
     model = syn.make_model(spec, dev)
-    all_cams = ring_cameras(global_views, spec.W, spec.H, device=dev)  # camera 0 == the SURVEY front camera
-    cams = all_cams[rank::world][:V]
+    all_cams = ring_cameras(n_cams * world, spec.W, spec.H, device=dev)  # camera 0 == the SURVEY front camera
+    shard_cams = all_cams[rank::world][:n_cams]
+    cams = shard_cams[:V]
     bg = syn.background(dev)
     with torch.no_grad():
         gt = syn.make_model(spec, dev)
         g = torch.Generator(device="cpu").manual_seed(202)
         gt._xyz.add_((0.002 * torch.randn(gt._xyz.shape, generator=g)).to(dev))
         gt._features_dc.add_((0.05 * torch.randn(gt._features_dc.shape, generator=g)).to(dev))
-        make_ground_truth(gt, cams, bg)
+        make_ground_truth(gt, shard_cams, bg)
         del gt
     model.training_setup(opt)  # FusedAdam on ROCm: flat params / grads / moments
     bucket = None
@@ -162,40 +171,53 @@ def main():
     stats = dict(dgr.LAST_STATS)
     P_model = spec.P
     ms_per_step = 1e3 * elapsed / K
-    value = world * V * P_model / (elapsed / K)
+    # Gaussians that pass the cull of this rank's views (radii > 0): what the rasterizer actually carries through forward
+    # and backward.  Outside the timed region.
+    with torch.no_grad():
+        P_vis = [int((_render(c, model, _tr.PIPE, bg)["radii"] > 0).sum().item()) for c in cams]
+    p_sum = torch.tensor([float(sum(P_vis))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(p_sum)
+    value = float(p_sum.item()) / (elapsed / K)
 
     fwd_ms = [q[0].elapsed_time(q[1]) for q in evs]
     bwd_ms = [q[2].elapsed_time(q[3]) for q in evs]
     fwd_avg, bwd_avg = sum(fwd_ms) / len(fwd_ms), sum(bwd_ms) / len(bwd_ms)
 
-    R, Pv = stats.get("num_rendered", 0), stats.get("P", 0)
+    R = stats.get("num_rendered", 0)
     N_pix = spec.W * spec.H
     T_tiles = ((spec.W + 15) // 16) * ((spec.H + 15) // 16)
     # K8's share of B_bwd = per instance 68 B read + 64 B gradient payload, per pixel 48 B, ranges 8 B/tile
     bytes_bwd_kernel = 132 * R + 48 * N_pix + 8 * T_tiles
     bytes_fwd_kernel = 68 * R + 48 * N_pix + 8 * T_tiles
     achieved = bytes_bwd_kernel / (bwd_avg * 1e-3) / 1e9 if bwd_avg > 0 else 0.0
-    traffic = None
+    traffic, traffic_src = None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_k_render_bwd.json")
-    if os.path.exists(pmc_file) and args.workload == "cfg3":  # the committed PMC passes were taken on this workload
+    if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc_file))
+            rec = rec.get(args.workload, rec if args.workload == "cfg3" and "hbm_bytes_per_launch" in rec else {})
+            traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
         except Exception:
             traffic = None
     roofline = {"kernel": "k_render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "VALU/LDS-bound gradient walk; algorithmic bytes per SURVEY.md 8(d); kernel duration from HIP "
-                        "events over %d solo passes of one view (in the timed steps two views share the GPU)" % n_ev}
+                "note": "VALU-bound gradient walk (SQ_ACTIVE_INST_VALU ~89 % of the SIMD cycles); algorithmic bytes "
+                        "132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured view; kernel duration from "
+                        "HIP events the library records around the kernel on its launch stream, %d solo passes" % n_ev}
 
     out = {
-        "metric": "gaussians_rasterized_per_sec_fwd_bwd_1080p", "value": round(value, 1), "unit": "Gaussians/s",
+        "metric": "gaussians_per_sec_grad_step_500k_strands_1080p", "value": round(value, 1), "unit": "Gaussians/s",
         "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d Gaussians (%s), %d view(s)/GPU/step at %dx%d, render + 4 stage-1 losses (L1, SSIM, mask, orientation 0.1) + backward%s + Adam" %
-                   (spec.name, P_model, spec.kind, V, spec.W, spec.H, "+RCCL grad all-reduce" if world > 1 else ""),
+        "config": {"workload": "BASELINE configs[2]: %s, %d Gaussians (%s) in the model, %d view(s) per GPU per gradient step "
+                               "at %dx%d: render + 4 stage-1 losses (L1, SSIM, mask, orientation 0.1) + backward%s + Adam" %
+                   (spec.name, P_model, spec.kind, V, spec.W, spec.H, " + RCCL grad all-reduce" if world > 1 else ""),
                    "views_per_gpu": V, "global_views": global_views, "parallelism": "view-dp%d" % world,
-                   "P_rasterized_per_view": Pv, "num_rendered_per_view": R},
+                   "P_model": P_model, "P_visible_per_view": P_vis, "num_rendered_per_view": R,
+                   "value_is": "sum over the step's views of the Gaussians that pass the cull / t_step"},
         "grad_steps_per_sec": round(K / elapsed, 3),
         "kernels_ms": {"k_render_fwd": round(fwd_avg, 4), "k_render_bwd": round(bwd_avg, 4),
                        "k_render_fwd_hbm_frac": round(bytes_fwd_kernel / (fwd_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
@@ -205,24 +227,43 @@ def main():
     if replicas_identical is not None:
         out["replicas_identical"] = replicas_identical
 
-    if rank == 0 and world == 1:
-        # BASELINE.json configs[2]: the same stage-1 step with ONE view per gradient step
-        K1 = max(10, K)
+    # ---- BASELINE configs[3]'s per-GPU shard: VS views per GPU per global step (every N; same model, continues training)
+    if VS > 0 and VS != V:
+        it0 = Wm + K
         for i in range(3):
-            training_step(model, cams[:1], bg, opt, Wm + K + i + 1, global_views=1, streams=args.streams)
+            training_step(model, shard_cams[:VS], bg, opt, it0 + i + 1, global_views=VS * world, streams=args.streams)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for i in range(K1):
-            training_step(model, cams[:1], bg, opt, Wm + K + 3 + i + 1, global_views=1, streams=args.streams)
+        K4 = max(5, K // 2)
+        for i in range(K4):
+            training_step(model, shard_cams[:VS], bg, opt, it0 + 3 + i + 1, global_views=VS * world, streams=args.streams)
         torch.cuda.synchronize()
-        dt1 = (time.perf_counter() - t1) / K1
-        out["single_view_step"] = {"workload": "BASELINE configs[2]: 1 view per gradient step", "steps": K1,
-                                   "ms_per_step": round(1e3 * dt1, 4), "gaussians_per_sec": round(P_model / dt1, 1),
-                                   "grad_steps_per_sec": round(1.0 / dt1, 2)}
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt4 = (time.perf_counter() - t1) / K4
+        if world > 1:
+            t = torch.tensor([dt4], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt4 = float(t.item())
+        with torch.no_grad():
+            pv4 = torch.tensor([float(sum(int((_render(c, model, _tr.PIPE, bg)["radii"] > 0).sum().item())
+                                          for c in shard_cams[:VS]))], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(pv4)
+        out["config4_shard"] = {"workload": "BASELINE configs[3] shard: %d views per GPU per gradient step (%d global)" %
+                                            (VS, VS * world), "steps": K4, "ms_per_step": round(1e3 * dt4, 4),
+                                "gaussians_per_sec": round(float(pv4.item()) / dt4, 1),
+                                "grad_steps_per_sec": round(1.0 / dt4, 3)}
+
+    if rank == 0 and world == 1:
         if not args.no_op_only:
-            out["op_only"] = op_only_bench(dev)
+            out["op_only"] = {c: op_only_bench(dev, c, iters=50 if c == "cfg2" else 30) for c in ("cfg2", "cfg3")}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, model, cams[0])
+            out["cpu_baseline"] = cpu_baseline("cfg3")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -263,33 +304,41 @@ def op_only_bench(dev, cfg="cfg2", iters=50, warm=10):  # 10 warm-u
     tf.sort(), tb.sort()
     mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
     pct = lambda v, q: round(v[min(len(v) - 1, int(q * len(v)))], 4)
-    return {"workload": spec.name, "P": ri["P"], "num_rendered": dgr.LAST_STATS["num_rendered"], "fwd_ms": round(mf, 4),
+    R = dgr.LAST_STATS["num_rendered"]
+    P, N, T = ri["P"], spec.W * spec.H, ((spec.W + 15) // 16) * ((spec.H + 15) // 16)
+    b_fwd, b_bwd = 92 * P + 112 * R + 48 * N + 16 * T, 140 * P + 132 * R + 48 * N + 8 * T
+    return {"workload": spec.name, "P": ri["P"], "num_rendered": R, "fwd_ms": round(mf, 4),
             "bwd_ms": round(mb, 4), "gaussians_per_sec_fwd_bwd": round(ri["P"] / ((mf + mb) * 1e-3), 1),
+            "whole_forward_hbm_frac": round(b_fwd / (mf * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "whole_backward_hbm_frac": round(b_bwd / (mb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes": {"B_fwd = 92 P + 112 R + 48 N + 16 T": b_fwd, "B_bwd = 140 P + 132 R + 48 N + 8 T": b_bwd},
             "fwd_ms_p10_p90": [pct(tf, 0.1), pct(tf, 0.9)], "bwd_ms_p10_p90": [pct(tb, 0.1), pct(tb, 0.9)],
             "iters": iters, "warmup": warm,
             "note": "GaussianRasterizer op (autograd, workspace allocation and the num_rendered read included)"}
 
 
-def cpu_baseline(spec, model, cam):
-    """The oracle (CPU restatement of the reference's CUDA semantics; 'port') on one view of the same workload."""
+def cpu_baseline(cfg="cfg3"):
+    """The oracle (CPU restatement of the reference's CUDA semantics, pinned to outputs of the reference's own rasterizer;
+    'port') on the same scope as op_only[cfg]: rasterizer forward + backward of one view, mode A."""
     import oracle
     from gaussianhaircut_amd.utils import synthetic as syn
     from tests import helpers as hp
-    cpu_model_inputs = syn.raster_inputs(spec, "cpu")
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec, "cpu")
     dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
     best = None
     for _ in range(3):  # bounded sample: three passes over one view (~1 s each on a 128-core host), best pass reported
         t0 = time.perf_counter()
-        out_o, radii_o, st = hp.oracle_forward(oracle, cpu_model_inputs, "A")
+        out_o, radii_o, st = hp.oracle_forward(oracle, ri, "A")
         t1 = time.perf_counter()
-        hp.oracle_backward(oracle, st, cpu_model_inputs, dL, "A")
+        hp.oracle_backward(oracle, st, ri, dL, "A")
         t2 = time.perf_counter()
         if best is None or t2 - t0 < best[2] - best[0]:
             best = (t0, t1, t2)
     t0, t1, t2 = best
-    return {"value": round(spec.P / (t2 - t0), 1), "unit": "Gaussians/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "1 view of %s, best of 3 passes, rasterizer fwd (%.2f s) + bwd (%.2f s) only; projection/loss/Adam not included" %
-                      (spec.name, t1 - t0, t2 - t1)}
+    return {"value": round(ri["P"] / (t2 - t0), 1), "unit": "Gaussians/s", "cores": oracle.num_threads(), "kind": "port",
+            "sample": "1 view of %s (P = %d Gaussians handed to the op), best of 3 passes, rasterizer fwd (%.2f s) + bwd "
+                      "(%.2f s): the scope of op_only.%s" % (spec.name, ri["P"], t1 - t0, t2 - t1, cfg)}
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 NUM_CHANNELS = 10
 GRAD_STRIDE = 16
+ADAM_STATE = 18  # GHR_ADAM_STATE
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -142,10 +143,10 @@ def lib() -> ctypes.CDLL:
     L.ghr_loss_gt_stats.argtypes = [vp, ctypes.POINTER(LossArgs), vp]
     L.ghr_loss_backward.argtypes = [vp, ctypes.POINTER(LossArgs)] + [vp] * 9
     L.ghr_adam_step.argtypes = [vp, ctypes.c_int64, vp, vp, vp, vp, vp, i32, ctypes.POINTER(ctypes.c_int64),
-                                ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, i32]
+                                ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, i32, u32]
     L.ghr_adam_step_range.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp, vp, i32,
                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double,
-                                      ctypes.c_double, f32, i32, i32, i32]
+                                      ctypes.c_double, f32, i32, i32, i32, u32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp]
     L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]

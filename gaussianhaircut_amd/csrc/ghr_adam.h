@@ -12,6 +12,7 @@
 namespace ghr {
 
 #define GHR_ADAM_MAX_GROUPS 16
+#define GHR_ADAM_STATE (2 + GHR_ADAM_MAX_GROUPS)
 
 struct AdamArgs {
     long long begin;      // first element of the range this launch updates
@@ -20,7 +21,10 @@ struct AdamArgs {
     float* g;             // flat gradients (zeroed on exit when zero_grad != 0)
     float* m;             // exp_avg
     float* v;             // exp_avg_sq
-    int* state;           // [0] = step count (incremented by the kernel's block 0 when not skipped), [1] = NaN flag
+    int* state;           // [0] = step count (advanced by k_adam_finish when not skipped), [1] = NaN flag,
+                          // [2 + g] = steps group g has sat out (GHR_ADAM_STATE ints in all)
+    unsigned skip_mask;   // bit g: group g takes no update in this step (its parameters were just replaced: the
+                          // reference's new nn.Parameters have grad None and optimizer.step() passes them by)
     int n_groups;
     long long end[GHR_ADAM_MAX_GROUPS];  // exclusive end offset of each group in the flat buffer
     float lr[GHR_ADAM_MAX_GROUPS];
@@ -52,28 +56,42 @@ GHR_HD void adam_update(float& p, float g, float& m, float& v, float step_size, 
 
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
 {
+    // per group: step size lr / (1 - beta1^t) and sqrt(1 - beta2^t) with t = the group's own step number (torch keeps a
+    // step counter per parameter: a group that sat out a step -- skip_mask -- lags the others from then on)
+    __shared__ float s_ss[GHR_ADAM_MAX_GROUPS], s_b2[GHR_ADAM_MAX_GROUPS];
     const int skip = a.state[1];
-    const int step = a.state[0] + 1;  // this update's step number (all blocks read before block 0 may bump it: see tail)
-    const double bias1 = 1.0 - pow(a.beta1, (double)step);
-    const float bias2_sqrt = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+    if ((int)threadIdx.x < a.n_groups) {
+        const int step = a.state[0] + 1 - a.state[2 + threadIdx.x];  // this update's step number for the group
+        const double bias1 = 1.0 - pow(a.beta1, (double)step);
+        s_ss[threadIdx.x] = (float)((double)a.lr[threadIdx.x] / bias1);
+        s_b2[threadIdx.x] = (float)sqrt(1.0 - pow(a.beta2, (double)step));
+    }
+    __syncthreads();
     const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
     for (long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         if (!skip) {
             int gi = 0;
             while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;
-            float p = a.p[i], m = a.m[i], v = a.v[i];
-            adam_update(p, a.g[i], m, v, (float)((double)a.lr[gi] / bias1), w1, b2, w2, a.eps, bias2_sqrt);
-            a.p[i] = p; a.m[i] = m; a.v[i] = v;
+            if (!((a.skip_mask >> gi) & 1u)) {
+                float p = a.p[i], m = a.m[i], v = a.v[i];
+                adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+                a.p[i] = p; a.m[i] = m; a.v[i] = v;
+            }
         }
         if (a.zero_grad) a.g[i] = 0.f;
     }
 }
 
-// Runs after k_adam on the same stream: advance the step counter unless skipped, clear the flag.
-__global__ void k_adam_finish(int* state)
+// Runs after k_adam on the same stream: advance the step counter unless skipped, note which groups sat the step out,
+// clear the flag.
+__global__ void k_adam_finish(int* state, unsigned skip_mask, int n_groups)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
-        if (!state[1]) state[0] += 1;
+        if (!state[1]) {
+            state[0] += 1;
+            for (int g = 0; g < n_groups; g++)
+                if ((skip_mask >> g) & 1u) state[2 + g] += 1;
+        }
         state[1] = 0;
     }
 }

@@ -541,7 +541,8 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
 
 int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, float* p, float* g, float* m, float* v,
                         int32_t* state, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
-                        double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last)
+                        double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last,
+                        uint32_t skip_mask)
 {
     if (n < 0 || begin < 0 || count < 0 || begin + count > n || !p || !g || !m || !v || !state || n_groups <= 0 ||
         n_groups > GHR_ADAM_MAX_GROUPS || !group_end_host || !lr_host)
@@ -553,22 +554,22 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
         ghr::AdamArgs a;
         a.begin = begin; a.n = begin + count; a.p = p; a.g = g; a.m = m; a.v = v; a.state = state; a.n_groups = n_groups;
         for (int i = 0; i < n_groups; i++) { a.end[i] = group_end_host[i]; a.lr[i] = lr_host[i]; }
-        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad;
+        a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad; a.skip_mask = skip_mask;
         const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
         if (nan_guard == 1)
             hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
         hipLaunchKernelGGL(ghr::k_adam, dim3(blocks), dim3(256), 0, s, a);
     }
-    if (last && n > 0) hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state);
+    if (last && n > 0) hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state, skip_mask, n_groups);
     return finish(s, 0);
 }
 
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
-                  int32_t nan_guard, int32_t zero_grad)
+                  int32_t nan_guard, int32_t zero_grad, uint32_t skip_mask)
 {
     return ghr_adam_step_range(stream, n, 0, n, p, g, m, v, state, n_groups, group_end_host, lr_host, beta1, beta2,
-                               eps, nan_guard, zero_grad, 1);
+                               eps, nan_guard, zero_grad, 1, skip_mask);
 }
 
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

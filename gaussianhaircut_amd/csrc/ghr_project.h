@@ -77,16 +77,20 @@ struct ModelGrads {
     float* d_dir3d;           // [P,3] mode 1 (NULL: not wanted).  In mode 1 d_log_scales / d_opacity_logit / d_label_logit /
                               // d_orient_conf_log receive the gradients of the LINEAR quantities and may be NULL
     int accumulate;           // != 0: parameter gradients are ADDED to the output buffers (d_means2D is always assigned)
-    int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN
+    int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN or +-inf
 };
 
-// Writes (or accumulates) one parameter-gradient element; returns whether the stored value is NaN.
+// Writes (or accumulates) one parameter-gradient element; returns whether the stored value is NON-FINITE.  The
+// reference's guard looks for NaN only (train_gaussians.py:174-177); raising the flag for +-inf as well costs nothing (an
+// infinite gradient turns the parameter into NaN in the very next Adam update anyway) and closes the data-parallel hole
+// in which +inf on one rank and -inf on another meet as a NaN only inside the all-reduced sum.
+GHR_HD bool nonfinite(float v) { return !(fabsf(v) <= 3.402823466e38f); }
 GHR_HD bool grad_out(float* p, float v, int accumulate)
 {
     if (p == nullptr) return false;
     if (accumulate) v += *p;
     *p = v;
-    return v != v;
+    return nonfinite(v);
 }
 
 GHR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
@@ -592,14 +596,14 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
             f4 v = s4[i];
             if (accumulate) v += old[it];
             d4[i] = v;
-            bad |= (v.x != v.x) | (v.y != v.y) | (v.z != v.z) | (v.w != v.w);
+            bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
         }
     }
     for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) {
         float v = src[i];
         if (accumulate) v += dst[i];
         dst[i] = v;
-        bad |= v != v;
+        bad |= nonfinite(v);
     }
     return bad;
 }

@@ -38,7 +38,18 @@ class FusedAdam:
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.state_dev = torch.zeros(2, dtype=torch.int32, device=dev)  # {step, nan flag}
+        # {step, nan flag, steps each group has sat out}
+        self.state_dev = torch.zeros(_lib.ADAM_STATE, dtype=torch.int32, device=dev)
+        # groups whose parameters were replaced since the last step (densification / opacity reset): the reference's new
+        # nn.Parameters have grad None, so its optimizer.step() passes them by on that iteration -- no moment decay, no
+        # update, no step count (train_gaussians.py:158-181).  Bit g = group g; consumed by the next step.  Contract: the
+        # surgery sits between backward() and step() like the reference's densification block; a backward AFTER the
+        # surgery through the fused renderer clears the marks again (note_direct_backward), a caller that fills .grad any
+        # other way before stepping calls ``cancel_skip()``.
+        self._skip_next = 0
+        # number of higher-order SH coefficients (rows of f_rest's middle axis) that can carry a gradient, i.e.
+        # (active_sh_degree + 1)^2 - 1; None = all.  Set by trainer.training_step; only shortens the all-reduce.
+        self.active_rest_coeffs = None
         off, ends = 0, []
         for g in self.param_groups:
             for p in g["params"]:
@@ -65,7 +76,17 @@ class FusedAdam:
     def all_reduce(self, average_over=None, async_op=False):
         work = None
         if dist.is_initialized() and dist.get_world_size() > 1:
-            work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
+            if not async_op and self.active_rest_coeffs is not None:
+                for a, b, how in self._reduce_plan(1):  # inactive SH bands are not sent (see _reduce_plan)
+                    if how == "sum":
+                        dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM)
+                    elif isinstance(how, tuple):
+                        view = self.flat_grad[a:b].view(how[1], how[2], 3)[:, :how[3]]
+                        packed = view.contiguous()
+                        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+                        view.copy_(packed)
+            else:
+                work = dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, async_op=async_op)
         if average_over and average_over != 1 and not async_op:
             self.flat_grad.div_(average_over)
         return work
@@ -101,6 +122,7 @@ class FusedAdam:
         self._ends = (ctypes.c_int64 * len(ends))(*ends)
         self.params = params
         self._direct_backwards = 0
+        self._skip_next = (1 << len(self.param_groups)) - 1  # every parameter is new: the coming step is a no-op
         return out
 
     def _group_views(self):
@@ -131,12 +153,18 @@ class FusedAdam:
     def replace(self, tensor: torch.Tensor, name: str):
         """``replace_tensor_to_optimizer`` (gaussian_model.py:581-594): new values, zeroed moments, for one group."""
         out = {}
-        for g, p, m, v in self._group_views():
+        for i, (g, p, m, v) in enumerate(self._group_views()):
             if g["name"] == name:
                 p.data.copy_(tensor.detach().reshape(p.shape))
                 m.zero_(); v.zero_()
+                if p.grad is not None:
+                    p.grad.zero_()  # the stale gradient of this iteration belongs to the replaced values
+                self._skip_next |= 1 << i
                 out[name] = p
         return out
+
+    def cancel_skip(self):
+        self._skip_next = 0
 
     # ---- direct-gradient sink used by gaussian_renderer.fused
     def nan_flag_ptr(self):
@@ -144,6 +172,7 @@ class FusedAdam:
 
     def note_direct_backward(self):
         self._direct_backwards += 1
+        self._skip_next = 0  # fresh gradients for the (new) parameters: they take part in the coming step
 
     # ---- views of one step on several HIP streams (trainer.training_step): the direct backward ACCUMULATES into the
     # flat gradient buffer with plain read-modify-writes, so the accumulating kernels of different views are chained
@@ -167,11 +196,12 @@ class FusedAdam:
         guard = 0 if not self.nan_guard else (1 if nan_scan or self._direct_backwards == 0 else 2)
         self._direct_backwards = 0
         self._acc_event = None
+        skip, self._skip_next = self._skip_next, 0
         with torch.cuda.device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                                                self.betas[0], self.betas[1], self.eps, guard, int(zero_grad)))
+                                                self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), skip))
 
     def _chunk_ranges(self, chunks: int):
         n = self.flat_param.numel()
@@ -179,34 +209,76 @@ class FusedAdam:
         per = -(-per // 1024) * 1024  # whole 4-KiB pieces
         return [(a, min(a + per, n)) for a in range(0, n, per)]
 
+    def _reduce_plan(self, chunks: int):
+        """[(a, b, how)] covering the flat buffer in order: ``how`` = "sum" (all-reduce flat_grad[a:b]), "none" (no
+        rank can hold a non-zero gradient there) or ("rest", P, K1, act) (only the first ``act`` of the K1 higher-order
+        SH coefficients of every Gaussian can be non-zero: they are packed, reduced and scattered back).  While
+        ``active_sh_degree`` < 3 -- the first 3000 iterations of the reference's schedule (oneupSHdegree every 1000) --
+        the gradients of the SH bands above the active degree are exactly zero (sh_utils.eval_sh never reads them) and
+        make up to 45 of the 61 floats per Gaussian of the message."""
+        n = self.flat_param.numel()
+        per = -(-n // max(int(chunks), 1))
+        per = -(-per // 1024) * 1024  # whole 4-KiB pieces
+        plan, run_a, off = [], 0, 0
+        act = self.active_rest_coeffs
+
+        def flush(b):
+            for a in range(run_a, b, per):
+                plan.append((a, min(a + per, b), "sum"))
+
+        for g in self.param_groups:
+            p = g["params"][0]
+            k = p.numel()
+            if g.get("name") == "f_rest" and act is not None and p.dim() == 3 and act < p.shape[1]:
+                flush(off)
+                plan.append((off, off + k, "none" if act <= 0 else ("rest", p.shape[0], p.shape[1], int(act))))
+                run_a = off + k
+            off += k
+        flush(n)
+        return [x for x in plan if x[1] > x[0]]
+
     def step_chunked(self, chunks: int = 4, zero_grad: bool = True, reduce: bool = False):
         """The same update as ``step(nan_scan=False)`` applied range by range (``ghr_adam_step_range``).  With
         ``reduce`` (more than one rank) every range's gradient all-reduce is started up front and the range is updated
         as soon as its sum has arrived, so all but the last chunk of the Adam pass runs under the remaining
-        communication.  The skip-on-NaN decision must be known before the first range is touched: the flag the fused
-        backward maintains is exact for this rank's gradients and is OR-ed over the ranks first (4 bytes).  Only valid
-        when every gradient of the step came through the fused renderer's direct backward (as with ``nan_scan=False``);
-        a NaN that only appears in the cross-rank sum (+inf on one rank, -inf on another) is not caught."""
+        communication; ranges that cannot hold a non-zero gradient on any rank (inactive SH bands, ``_reduce_plan``)
+        are not sent at all.  The skip-on-NaN decision must be known before the first range is touched: the flag the
+        fused backward maintains is exact for this rank's gradients -- it is raised by any NON-FINITE value, so that
+        +inf on one rank and -inf on another cannot meet as a NaN only inside the sum -- and is OR-ed over the ranks
+        first (4 bytes).  Only valid when every gradient of the step came through the fused renderer's direct backward
+        (as with ``nan_scan=False``)."""
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 2 if self.nan_guard else 0
         self._direct_backwards = 0
         self._acc_event = None
-        ranges = self._chunk_ranges(chunks)
-        works = None
-        if reduce and dist.is_initialized() and dist.get_world_size() > 1:
+        skip, self._skip_next = self._skip_next, 0
+        comm = reduce and dist.is_initialized() and dist.get_world_size() > 1
+        plan = self._reduce_plan(chunks) if comm else [(a, b, "local") for a, b in self._chunk_ranges(chunks)]
+        works = [None] * len(plan)
+        if comm:
             flag = self.state_dev[1:2]
             flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
-            works = [dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True) for a, b in ranges]
+            for i, (a, b, how) in enumerate(plan):
+                if how == "sum":
+                    works[i] = (dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True), None, None)
+                elif isinstance(how, tuple):
+                    _, P, K1, act = how
+                    view = self.flat_grad[a:b].view(P, K1, 3)[:, :act]
+                    packed = view.contiguous()
+                    works[i] = (dist.all_reduce(packed, op=dist.ReduceOp.SUM, async_op=True), view, packed)
             flag_work.wait()
         n = self.flat_param.numel()
         with torch.cuda.device(self.flat_param.device):
-            for i, (a, b) in enumerate(ranges):
-                if works is not None:
-                    works[i].wait()  # orders the current stream behind this chunk's collective
+            for i, (a, b, how) in enumerate(plan):
+                if works[i] is not None:
+                    w, view, packed = works[i]
+                    w.wait()  # orders the current stream behind this chunk's collective
+                    if view is not None:
+                        view.copy_(packed)
                 _lib.check(_lib.lib().ghr_adam_step_range(
                     _stream(), n, a, b - a, _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
                     _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(ranges) - 1)))
+                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(plan) - 1), skip))
 
     def state_dict(self):
         return {"flat_param": self.flat_param, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
@@ -217,6 +289,8 @@ class FusedAdam:
         self.flat_param.copy_(sd["flat_param"])
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.state_dev.copy_(sd["state"])
+        st = sd["state"]
+        self.state_dev.zero_()
+        self.state_dev[: st.numel()].copy_(st)  # checkpoints of ABI <= 10 carry {step, flag} only
         for g, lr in zip(self.param_groups, sd["lrs"]):
             g["lr"] = lr

@@ -76,7 +76,11 @@ def view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
         w = torch.ones_like(gt_mask[:1]) * cam.original_orient_conf
         Lorient = or_loss(render_pkg["orient_angle"], cam.original_orient_angle, render_pkg["orient_conf"], weight=w,
                           mask=gt_mask[:1])
-        Lorient = torch.where(torch.isnan(Lorient), torch.zeros_like(Lorient), Lorient)
+        # train_gaussians.py:133: `if torch.isnan(Lorient).any(): Lorient = torch.zeros_like(Ll1)` -- a host decision that
+        # drops the term from the graph.  Masking the VALUE (torch.where) would still back-propagate 0/0 through a view
+        # whose orientation weights are all zero and poison the other three terms' step.
+        if bool(torch.isnan(Lorient).any()):
+            Lorient = torch.zeros_like(Ll1)
         loss = loss + Lorient * opt.lambda_dorient
     return loss * scale if scale != 1.0 else loss
 
@@ -141,8 +145,18 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     dropped and the step is recomputed view by view with exact capacities, so the result never depends on the guess."""
     from .optim import FusedAdam
     gaussians.update_learning_rate(iteration)
-    V = global_views or len(cams)
+    # the loss of a view is scaled 1 / V: with more than one rank V defaults to the GLOBAL number of views (the
+    # all-reduce sums the ranks' gradients), assuming every rank holds len(cams) of them
+    V = global_views or len(cams) * _world_size()
     sink = gaussians.optimizer if isinstance(getattr(gaussians, "optimizer", None), FusedAdam) else None
+    if sink is not None and sink.direct_grads:
+        # the direct backward needs every leaf of the fused renderer inside the optimizer (e.g. train_orient_conf = False
+        # leaves _orient_conf out): otherwise autograd accumulates and the scanning guard applies -- a property of the
+        # configuration, identical on every rank
+        leaves = (gaussians._xyz, gaussians._scaling, gaussians._rotation, gaussians._opacity, gaussians._label,
+                  gaussians._orient_conf, gaussians._features_dc, gaussians._features_rest)
+        if not all(isinstance(p, torch.nn.Parameter) and p.grad is not None for p in leaves):
+            sink = None
     can_overlap = (sink is not None and sink.direct_grads and len(cams) > 1 and background.is_cuda and
                    not getattr(pipe, "debug", False))
     n_streams = (2 if streams is None else int(streams)) if can_overlap else 0
@@ -166,6 +180,8 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     else:
         total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
     if isinstance(gaussians.optimizer, FusedAdam):
+        # SH bands above the active degree carry exactly-zero gradients on every rank: not part of the all-reduce
+        gaussians.optimizer.active_rest_coeffs = (int(gaussians.active_sh_degree) + 1) ** 2 - 1
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
         # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no
         # other rank contributes: the guard needs no scan over the gradients
@@ -188,11 +204,26 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         bad = bucket.has_nan()
     else:
         bad = torch.stack([p.grad.isnan().any() for p in gaussians.leaf_parameters() if p.grad is not None]).any()
-    # train_gaussians.py:174-181: a NaN anywhere skips the update (device-side select, no host sync)
+    # train_gaussians.py:174-181: a NaN anywhere skips the update -- the reference drops the gradients
+    # (zero_grad(set_to_none=True)), so optimizer.step() touches nothing: no moment decay, no step count.
     if bucket is not None:
-        bucket.flat.mul_((~bad).to(bucket.flat.dtype))
+        # device-side and sync-free: take the step, then put parameters and optimizer state back where `bad` is set
+        # (a zeroed gradient is NOT a skip for Adam: the moments would decay and the parameters drift by lr m / sqrt(v))
+        params = [p for g in gaussians.optimizer.param_groups for p in g["params"]]
+        snap = []
+        for p in params:
+            st = gaussians.optimizer.state.get(p, {})
+            snap.append((p.detach().clone(), {k: v.clone() for k, v in st.items() if isinstance(v, torch.Tensor)}))
         torch.nan_to_num_(bucket.flat, nan=0.0)
         gaussians.optimizer.step()
+        for p, (p0, st0) in zip(params, snap):
+            p.data.copy_(torch.where(bad, p0, p.data))
+            st = gaussians.optimizer.state.get(p, {})
+            for k, v0 in st0.items():
+                st[k].copy_(torch.where(bad, v0, st[k]))
+            for k, v in st.items():  # state created by this very step (first step): back to its initial value
+                if isinstance(v, torch.Tensor) and k not in st0:
+                    v.copy_(torch.where(bad, torch.zeros_like(v), v))
         bucket.zero()
     else:
         if bool(bad):
@@ -249,7 +280,8 @@ def strand_view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
             w = w * cam.original_orient_conf
         conf = render_pkg["orient_conf"] if opt.train_orient_conf else None
         Lorient = or_loss(render_pkg["orient_angle"], cam.original_orient_angle, conf, weight=w, mask=gt_mask[:1])
-        Lorient = torch.where(torch.isnan(Lorient), torch.zeros_like(Lorient), Lorient)
+        if bool(torch.isnan(Lorient).any()):  # train_strands.py:141: the term is dropped from the graph
+            Lorient = torch.zeros_like(loss)
         loss = loss + Lorient * opt.lambda_dorient
     return loss * scale if scale != 1.0 else loss
 

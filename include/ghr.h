@@ -38,9 +38,10 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 10
+#define GHR_ABI_VERSION 11
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
+#define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
 
 #define GHR_OK 0
@@ -225,21 +226,26 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, c
 
 /* ---- fused Adam (src/scene/gaussian_model.py:431-444; src/train_gaussians.py:174-181) ---------------------------
  * One pass over flat buffers p/g/m/v of n floats split into n_groups contiguous groups (group_end[i] = exclusive end
- * offset, lr[i] = its learning rate; host arrays).  state: 2 device ints {step, nan_flag}, zero-initialised once.
+ * offset, lr[i] = its learning rate; host arrays).  state: GHR_ADAM_STATE (18) device ints {step, nan_flag, steps each
+ * group has sat out [16]}, zero-initialised once.  skip_mask bit g: group g takes no update in this step and its own step
+ * number stops advancing for it -- what torch.optim.Adam does for a parameter whose grad is None, i.e. for the
+ * nn.Parameters the reference's densification / opacity reset has just replaced (gaussian_model.py:581-658; the
+ * optimizer step follows at train_gaussians.py:180).
  * nan_guard != 0: skip the whole update (and do not advance step) when any gradient is NaN, on-device;
  * nan_guard == 1 scans the gradients first, nan_guard == 2 trusts state[1] as maintained by the gradient producer
  * (ghr_model_backward's nan_flag).
  * zero_grad != 0: the gradient buffer is zeroed for the next step. */
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
-                  int32_t nan_guard, int32_t zero_grad);
+                  int32_t nan_guard, int32_t zero_grad, uint32_t skip_mask);
 /* The same update restricted to the elements [begin, begin + count) of the n-element buffers (pointers, groups and n
  * as for the whole buffer), so a step can be applied chunk by chunk as the chunks of an all-reduce arrive.  Every
  * chunk of a step sees the same step number; `last` != 0 on the final chunk advances the counter and clears the
  * flag.  nan_guard 1 (scan) is only accepted for the whole buffer. */
 int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, float* p, float* g, float* m, float* v,
                         int32_t* state, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
-                        double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last);
+                        double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last,
+                        uint32_t skip_mask);
 
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

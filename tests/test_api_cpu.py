@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ghr_abi_version() == 10
+    assert L.ghr_abi_version() == 11
 
 
 def test_workspace_sizes_and_error_codes():
@@ -255,3 +255,33 @@ def test_adam_chunk_ranges_tile_the_buffer(n, chunks):
     for (a, b), (c, d) in zip(ranges, ranges[1:]):
         assert b == c
     assert all(a < b and a % 1024 == 0 for a, b in ranges)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3, None])
+def test_adam_reduce_plan_covers_the_buffer_and_skips_inactive_sh_bands(deg):
+    """FusedAdam.step_chunked(reduce=True) walks `_reduce_plan`: consecutive ranges exactly covering the flat buffer; the
+    f_rest group is sent whole (degree 3 / unknown), packed to its active coefficients (degree 1, 2) or not at all
+    (degree 0); everything else is all-reduced in place."""
+    from types import SimpleNamespace
+    from gaussianhaircut_amd.optim import FusedAdam
+    P = 1234
+    shapes = [("xyz", (P, 3)), ("f_dc", (P, 1, 3)), ("f_rest", (P, 15, 3)), ("opacity", (P, 1)), ("label", (P, 1)),
+              ("scaling", (P, 3)), ("rotation", (P, 4)), ("orient_conf", (P, 1))]
+    groups = [{"name": n, "params": [torch.empty(s)]} for n, s in shapes]
+    n = sum(g["params"][0].numel() for g in groups)
+    act = None if deg is None else (deg + 1) ** 2 - 1
+    fake = SimpleNamespace(flat_param=torch.empty(n), param_groups=groups, active_rest_coeffs=act)
+    plan = FusedAdam._reduce_plan(fake, 4)
+    assert plan[0][0] == 0 and plan[-1][1] == n
+    for x, y in zip(plan, plan[1:]):
+        assert x[1] == y[0] and x[0] < x[1]
+    rest_a, rest_b = 6 * P, 6 * P + 45 * P
+    sent = sum(b - a for a, b, how in plan if how == "sum") + sum(how[1] * how[3] * 3 for a, b, how in plan
+                                                                if isinstance(how, tuple))
+    if deg in (3, None):
+        assert all(how == "sum" for _, _, how in plan) and sent == n
+    else:
+        special = [x for x in plan if x[2] != "sum"]
+        assert len(special) == 1 and special[0][:2] == (rest_a, rest_b)
+        assert special[0][2] == ("none" if deg == 0 else ("rest", P, 15, act))
+        assert sent == n - 45 * P + 3 * P * act

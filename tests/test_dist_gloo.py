@@ -39,15 +39,24 @@ def _worker(rank, world, port, q):
         model, cams = _setup(VIEWS)
         bucket = FlatGradBucket(model.leaf_parameters())
         mine = shard_views(cams, rank, world)
-        grads = None
+        grads = _capture(model, bucket)
         for it in range(2):
-            if it == 1:  # snapshot the reduced gradient of the last step before Adam zeroes it
-                pass
             training_step(model, mine, syn.background(), OptimizationParams(), it + 1, bucket=bucket,
                           global_views=VIEWS)
-        q.put((rank, param_checksum(model.leaf_parameters()), model._xyz.detach().numpy().copy()))
+        q.put((rank, param_checksum(model.leaf_parameters()), model._xyz.detach().numpy().copy(), grads[0]))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _capture(model, bucket):
+    """the all-reduced flat gradient of every step, copied just before torch.optim.Adam consumes it"""
+    grads, orig = [], model.optimizer.step
+
+    def step(*a, **k):
+        grads.append(bucket.flat.detach().numpy().copy())
+        return orig(*a, **k)
+    model.optimizer.step = step
+    return grads
 
 
 def _free_port():
@@ -77,10 +86,16 @@ def test_two_rank_view_sharding_equals_sequential_accumulation():
     with oracle_rasterizer():
         model, cams = _setup(VIEWS)
         bucket = FlatGradBucket(model.leaf_parameters())
+        grads = _capture(model, bucket)
         for it in range(2):
             training_step(model, cams, syn.background(), OptimizationParams(), it + 1, bucket=bucket, global_views=VIEWS)
+    # G-GPU result == 1-GPU sequential accumulation of the same V views, <= 1e-5 on the GRADIENTS
+    # (fp32 reassociation of the 4-view sum: 2 + 2 vs sequential)
+    np.testing.assert_array_equal(res[0][3], res[1][3])
+    scale = np.abs(grads[0]).max()
+    assert scale > 0 and np.abs(res[0][3] - grads[0]).max() <= 1e-5 * scale
     ref = model._xyz.detach().numpy()
-    # fp32 reassociation of the 4-view sum (2+2 vs sequential) passes through Adam's normalisation: compare loosely
+    # the parameters have been through Adam's normalisation twice: looser
     assert np.abs(res[0][2] - ref).max() < 5e-5
 
 

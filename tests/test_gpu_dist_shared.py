@@ -1,0 +1,140 @@
+"""`-m gpu`: the N > 1 path bench.py takes -- trainer.training_step -> FusedAdam.step_chunked(reduce=True): two view
+streams per rank, chunked asynchronous gradient all-reduces, each chunk's Adam update as its sum arrives, the NaN flag
+OR-ed over the ranks first -- run by TWO ranks that share cuda:0, with gloo carrying the collectives (the builder's and
+the driver's test boxes have one GPU; RCCL itself is exercised by the driver's multi-GPU bench).  SURVEY 8(e):
+  * the all-reduced flat gradient equals the 1-rank accumulation of the same 8 views to 1e-5 of its largest entry,
+  * the replicas stay bit-identical over several steps (also with the SH bands above the active degree left out of
+    the all-reduce),
+  * a non-finite gradient on ONE rank skips the step on BOTH (parameters, moments and step counter untouched).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+VIEWS, STEPS = 8, 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene(dev, sh_degree):
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth
+    from gaussianhaircut_amd.utils import synthetic as syn
+    spec = syn.CONFIGS["tiny_strands"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    model, gt = syn.make_model(spec, dev), syn.make_model(spec, dev)
+    model.active_sh_degree = sh_degree
+    with torch.no_grad():
+        gt._features_dc.add_(0.25)
+        gt._xyz.add_(0.003 * torch.randn(gt._xyz.shape, generator=torch.Generator().manual_seed(5)).to(dev))
+    cams = ring_cameras(VIEWS, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    make_ground_truth(gt, cams, bg)
+    model.training_setup(opt)
+    return model, cams, bg, opt
+
+
+def _capture_reduced_gradient(model, store):
+    """step / step_chunked with the gradient zeroing taken out, so the (reduced) flat gradient can be copied first"""
+    o = model.optimizer
+    orig_c, orig_s = o.step_chunked, o.step
+
+    def chunked(chunks=4, zero_grad=True, reduce=False):
+        orig_c(chunks=chunks, zero_grad=False, reduce=reduce)
+        store.append(o.flat_grad.detach().clone())
+        o.flat_grad.zero_()
+
+    def step(zero_grad=True, nan_scan=True):
+        store.append(o.flat_grad.detach().clone())
+        orig_s(zero_grad=zero_grad, nan_scan=nan_scan)
+
+    o.step_chunked, o.step = chunked, step
+
+
+def _worker(rank, world, port, q, sh_degree, poison_rank):
+    import torch.distributed as dist
+    from gaussianhaircut_amd.parallel import param_checksum, shard_views
+    from gaussianhaircut_amd.trainer import training_step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, cams, bg, opt = _scene(dev, sh_degree)
+    mine = shard_views(cams, rank, world)
+    grads = []
+    _capture_reduced_gradient(model, grads)
+    for it in range(STEPS):
+        training_step(model, mine, bg, opt, it + 1, global_views=VIEWS)
+    torch.cuda.synchronize()
+    out = dict(rank=rank, checksum=param_checksum(model.leaf_parameters()), grad0=grads[0].cpu().numpy(),
+               step=int(model.optimizer.state_dev[0]), chunked=model.optimizer.flat_param.numel())
+    if poison_rank is not None:
+        before = model.optimizer.flat_param.detach().clone()
+        m_before = model.optimizer.exp_avg.detach().clone()
+        if rank == poison_rank:  # this rank's ground truth makes its loss -- and all its gradients -- NaN
+            mine[0].original_image = mine[0].original_image.clone()
+            mine[0].original_image[0, 3, 5] = float("nan")
+        training_step(model, mine, bg, opt, STEPS + 1, global_views=VIEWS)
+        torch.cuda.synchronize()
+        out["skipped"] = bool(torch.equal(model.optimizer.flat_param, before) and
+                              torch.equal(model.optimizer.exp_avg, m_before) and
+                              int(model.optimizer.state_dev[0]) == out["step"] and int(model.optimizer.state_dev[1]) == 0
+                              and float(model.optimizer.flat_grad.abs().sum()) == 0.0)
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_two_ranks(sh_degree, poison_rank=None):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sh_degree, poison_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("sh_degree", [3, 1])
+def test_two_ranks_on_one_gpu_through_step_chunked_reduce(sh_degree):
+    from gaussianhaircut_amd.trainer import training_step
+    res = _run_two_ranks(sh_degree, poison_rank=1 if sh_degree == 3 else None)
+    assert res[0]["checksum"] == res[1]["checksum"], "replicas diverged"
+    assert res[0]["step"] == res[1]["step"] == STEPS
+    np.testing.assert_array_equal(res[0]["grad0"], res[1]["grad0"])
+    if sh_degree == 3:
+        assert res[0]["skipped"] and res[1]["skipped"], "a non-finite gradient on one rank must skip the step on both"
+    # one rank accumulating the same 8 views
+    dev = torch.device("cuda:0")
+    model, cams, bg, opt = _scene(dev, sh_degree)
+    grads = []
+    _capture_reduced_gradient(model, grads)
+    training_step(model, cams, bg, opt, 1, global_views=VIEWS)
+    torch.cuda.synchronize()
+    ref = grads[0].cpu().numpy()
+    got = res[0]["grad0"]
+    scale = np.abs(ref).max()
+    assert scale > 0 and np.abs(got - ref).max() <= 1e-5 * scale, (np.abs(got - ref).max(), scale)
+    if sh_degree < 3:  # the bands that were left out of the all-reduce are zero on the reference as well
+        P = model.get_xyz.shape[0]
+        rest = ref[6 * P: 51 * P].reshape(P, 15, 3)
+        assert np.abs(rest[:, (sh_degree + 1) ** 2 - 1:]).max() == 0.0
