@@ -204,7 +204,7 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "VALU-bound gradient walk (SQ_ACTIVE_INST_VALU ~89 % of the SIMD cycles); algorithmic bytes "
+                "note": "VALU-bound gradient walk (SQ_ACTIVE_INST_VALU ~89 %% of the SIMD cycles); algorithmic bytes "
                         "132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured view; kernel duration from "
                         "HIP events the library records around the kernel on its launch stream, %d solo passes" % n_ev}
 

@@ -87,7 +87,7 @@ def _worker(rank, world, port, q, sh_degree, poison_rank):
         m_before = model.optimizer.exp_avg.detach().clone()
         if rank == poison_rank:  # this rank's ground truth makes its loss -- and all its gradients -- NaN
             mine[0].original_image = mine[0].original_image.clone()
-            mine[0].original_image[0, 3, 5] = float("nan")
+            mine[0].original_image[:, :, mine[0].original_image.shape[2] // 2] = float("nan")  # a column through the hair
         training_step(model, mine, bg, opt, STEPS + 1, global_views=VIEWS)
         torch.cuda.synchronize()
         out["skipped"] = bool(torch.equal(model.optimizer.flat_param, before) and
