@@ -5,8 +5,9 @@ Thin numpy/ctypes front end over ``ghr_oracle.c`` (a plain-C restatement of
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this package; the
 product package ``gaussianhaircut_amd`` never does.
 
-Parity status: **parity unpinned** for the rasterizer kernels (the reference has no tests/golden vectors and its
-CUDA sources cannot be built here); see the header of ``ghr_oracle.c`` for what pins it instead.
+Parity status: **pinned** to outputs of the reference's own CUDA rasterizer (hipified and compiled for gfx950 by
+``oracle/Makefile.ref``, run once on an MI355X -> ``tests/golden/reference_cuda_golden.npz``; checked on the CPU by
+``tests/test_reference_cuda_golden.py``: integers bit-identical, images / gradients to 1e-5).  See ``ghr_oracle.c``.
 
 The two entry points mirror the reference's native boundary (``R:rasterize_points.h:18-69``):
 

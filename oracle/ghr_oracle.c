@@ -5,12 +5,18 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library.
  * The product path (gaussianhaircut_amd/) never links, imports or calls it.
  *
- * PARITY STATUS: "parity unpinned" for the rasterizer kernels.  The reference ships no tests, no golden
- * vectors and no CPU path (SURVEY.md F1,F2), and its CUDA sources cannot be compiled here (no nvcc, glm not
- * vendored).  This file is therefore pinned by (i) analytic closed-form micro-cases,
- * (ii) an independent fp64 PyTorch autograd renderer (tests/test_oracle_autograd.py), and (iii) the
- * reference's own Python restatement of the cull/radius/rect logic (`filter_points`,
- * src/scene/gaussian_model.py:143-228), executed from /root/reference by tests/golden/make_reference_golden.py.
+ * PARITY STATUS: PINNED to outputs of the reference's own rasterizer.  The reference ships no tests or golden
+ * vectors and no CPU path (SURVEY.md F1,F2), so the pin was made here: oracle/Makefile.ref hipifies the nine files of
+ * /root/reference/ext/diff_gaussian_rasterization_hair/cuda_rasterizer (text substitution, algorithm untouched) and
+ * compiles them for gfx950 against a minimal glm stand-in (oracle/ref_shim/) into oracle/_ref/libghr_ref.so;
+ * tests/golden/make_reference_cuda_golden.py ran it on an MI355X and stored inputs, outputs, internal state and
+ * gradients of six cases (modes A, A_sr, B_sr, B_cov) in tests/golden/reference_cuda_golden.npz.
+ * tests/test_reference_cuda_golden.py compares this file with them on the CPU: radii, tile counts, offsets, the
+ * 64-bit sort keys, sorted point lists, tile ranges, depth bits, pixel means and n_contrib are BIT-IDENTICAL;
+ * images agree to 1e-5, gradients to 1e-5 (the reference accumulates with fp32 atomics in arbitrary order); the
+ * in-kernel conic of mode B to 4e-7 (the reference binary contracts a*b+c, this file does not).
+ * Further pins: (i) analytic closed-form micro-cases, (ii) an independent fp64 PyTorch autograd renderer
+ * (tests/test_oracle_autograd.py), (iii) the reference's own Python `filter_points` (tests/test_reference_golden.py).
  *
  * Every function cites the reference lines it follows.  R: = ext/diff_gaussian_rasterization_hair/
  *
