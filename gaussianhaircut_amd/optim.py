@@ -18,6 +18,10 @@ from . import _lib
 from .diff_gaussian_rasterization import _ptr, _stream
 
 
+_TORCH_ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
+                            differentiable=False, fused=None, decoupled_weight_decay=False)
+
+
 class FusedAdam:
     def __init__(self, param_groups: List[Dict], betas=(0.9, 0.999), eps: float = 1e-15, nan_guard: bool = True,
                  direct_grads: bool = True):
@@ -280,17 +284,74 @@ class FusedAdam:
                     _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
                     self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(plan) - 1), skip))
 
+    def _param_ranges(self):
+        off = 0
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                yield gi, off, off + p.numel(), p
+                off += p.numel()
+
     def state_dict(self):
-        return {"flat_param": self.flat_param, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "state": self.state_dev, "lrs": [g["lr"] for g in self.param_groups],
-                "names": [g.get("name") for g in self.param_groups]}
+        """``torch.optim.Adam.state_dict()`` layout (what the reference's ``GaussianModel.capture`` stores,
+        src/scene/gaussian_model.py:84-99): ``state[i] = {step, exp_avg, exp_avg_sq}`` per parameter index and
+        ``param_groups`` with ``params`` as indices -- a checkpoint written here restores into torch.optim.Adam and the
+        other way round.  ``step`` of a parameter is the optimizer's step count less the steps its group sat out."""
+        st = self.state_dev.cpu()
+        state = {}
+        for i, (gi, a, b, p) in enumerate(self._param_ranges()):
+            steps = int(st[0]) - int(st[2 + gi])
+            if steps > 0 or bool(self.exp_avg_sq[a:b].any()):
+                state[i] = {"step": torch.tensor(float(steps)), "exp_avg": self.exp_avg[a:b].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[a:b].view(p.shape).clone()}
+        groups, i = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d.setdefault("betas", self.betas)
+            d.setdefault("eps", self.eps)
+            for k, v in _TORCH_ADAM_DEFAULTS.items():  # so torch.optim.Adam.load_state_dict finds every key it reads
+                d.setdefault(k, v)
+            d["params"] = list(range(i, i + len(g["params"])))
+            i += len(g["params"])
+            groups.append(d)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.flat_param.copy_(sd["flat_param"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        st = sd["state"]
-        self.state_dev.zero_()
-        self.state_dev[: st.numel()].copy_(st)  # checkpoints of ABI <= 10 carry {step, flag} only
-        for g, lr in zip(self.param_groups, sd["lrs"]):
-            g["lr"] = lr
+        """Accepts ``torch.optim.Adam.state_dict()`` (also the one ``state_dict`` above writes) and round 1's flat
+        layout.  Parameters are not part of an optimizer checkpoint (the reference restores them from the model tuple)."""
+        if "flat_param" in sd:  # round-1 layout
+            self.flat_param.copy_(sd["flat_param"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            st = sd["state"]
+            self.state_dev.zero_()
+            self.state_dev[: st.numel()].copy_(st)  # checkpoints of ABI <= 10 carry {step, flag} only
+            for g, lr in zip(self.param_groups, sd["lrs"]):
+                g["lr"] = lr
+            return
+        assert len(sd["param_groups"]) == len(self.param_groups), "optimizer checkpoint has a different group layout"
+        ranges = list(self._param_ranges())
+        steps = [0] * len(self.param_groups)
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, (gi, a, b, p) in enumerate(ranges):
+            e = sd["state"].get(i)
+            if e is None:
+                continue
+            assert e["exp_avg"].numel() == b - a, "optimizer checkpoint does not match parameter %d" % i
+            self.exp_avg[a:b].copy_(e["exp_avg"].reshape(-1))
+            self.exp_avg_sq[a:b].copy_(e["exp_avg_sq"].reshape(-1))
+            steps[gi] = max(steps[gi], int(float(e["step"])))
+        st = torch.zeros(_lib.ADAM_STATE, dtype=torch.int32)
+        st[0] = max(steps)
+        for gi, k in enumerate(steps):
+            st[2 + gi] = max(steps) - k
+        self.state_dev.copy_(st)
+        for g, d in zip(self.param_groups, sd["param_groups"]):
+            for k, v in d.items():
+                if k != "params":
+                    g[k] = v
+        if "betas" in self.param_groups[0]:
+            self.betas = tuple(self.param_groups[0]["betas"])
+        if "eps" in self.param_groups[0]:
+            self.eps = self.param_groups[0]["eps"]
+        self._skip_next = 0

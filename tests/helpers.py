@@ -3,7 +3,9 @@
 Comparison rules (the parity bar of BASELINE.json's north_star, tolerance 1e-4):
 * integer / index outputs (radii, tile ranges, sorted point lists, n_contrib): bit-exact;
 * float images: |a - b| <= 1e-4 * max(1, |b|);
-* gradients: |a - b| <= 1e-4 * (|b| + max|b| of the tensor)  (abs + rel, with fp32 atomic-reorder slack);
+* gradients: per ROW (one Gaussian), |a - b| <= 1e-4 * (|b| + max|b| of the row) + 2e-6 * max|b| of the tensor  (round 1
+  scaled by the tensor maximum, under which a small element could be 100 % wrong and pass; the floor covers the fp32
+  cancellation noise of rows whose own gradient is ~0);
 * "fragile" pixels -- where the oracle's walk took a discrete decision (alpha < 1/255, T < 1e-4) within a relative
   margin 2e-5 of its threshold, so a 1-ulp different exp() may legitimately decide otherwise -- are excluded from the
   exact image comparison (their count is bounded) and get dL/dpixel = 0 in gradient tests, which removes every
@@ -60,21 +62,28 @@ def image_close(a, b, tol=TOL):
     return np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))
 
 
-def grad_close(a, b, tol=TOL):
-    scale = np.abs(b).max() if b.size else 0.0
-    return np.abs(a - b) <= tol * (np.abs(b) + scale) + 1e-30
+GRAD_FLOOR = 2e-6  # of the tensor's largest |ref|
+
+
+def grad_close(a, b, tol=TOL, floor=GRAD_FLOOR):
+    """a, b: [rows, ...] (one row per Gaussian)."""
+    a2, b2 = a.reshape(len(a), -1) if a.ndim > 1 else a.reshape(-1, 1), b.reshape(len(b), -1) if b.ndim > 1 else b.reshape(-1, 1)
+    rows = np.abs(b2).max(axis=1, keepdims=True) if b2.size else 0.0
+    scale = np.abs(b2).max() if b2.size else 0.0
+    return (np.abs(a2 - b2) <= tol * (np.abs(b2) + rows) + floor * scale + 1e-30).reshape(a.shape)
 
 
 def assert_grads_close(got: dict, ref: dict, keys=None, tol=TOL):
     for k in (keys or ref.keys()):
-        a, b = np.asarray(got[k], dtype=np.float32).reshape(-1), np.asarray(ref[k], dtype=np.float32).reshape(-1)
+        a, b = np.asarray(got[k], dtype=np.float32), np.asarray(ref[k], dtype=np.float32)
         assert a.shape == b.shape, (k, a.shape, b.shape)
         assert np.isfinite(a).all(), k
         ok = grad_close(a, b, tol)
         if not ok.all():
-            i = int(np.argmax(np.abs(a - b) - tol * (np.abs(b) + np.abs(b).max())))
+            a1, b1, o1 = a.reshape(-1), b.reshape(-1), ok.reshape(-1)
+            i = int(np.argmax(np.abs(a1 - b1) * ~o1))
             raise AssertionError("%s: %d / %d elements off; worst idx %d got %g ref %g (tensor max %g)" %
-                                 (k, (~ok).sum(), ok.size, i, a[i], b[i], np.abs(b).max()))
+                                 (k, (~o1).sum(), o1.size, i, a1[i], b1[i], np.abs(b1).max()))
 
 
 # --------------------------------------------------------------------------------------------------------------------

@@ -321,3 +321,56 @@ def test_step_after_optimizer_surgery_passes_the_replaced_groups_by_like_torch_a
     mf.optimizer.step(zero_grad=True)
     mt.optimizer.step()
     compare("first step on the densified model")
+
+
+def test_optimizer_checkpoints_interchange_with_torch_adam():
+    """The reference checkpoints ``optimizer.state_dict()`` inside GaussianModel.capture() and restores it with
+    load_state_dict (src/scene/gaussian_model.py:84-127): a torch.optim.Adam checkpoint must restore into FusedAdam and
+    a FusedAdam checkpoint into torch.optim.Adam, and training must continue identically either way."""
+    from gaussianhaircut_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    shapes = [(500, 3), (500, 15, 3), (500, 1)]
+    lrs = [1.6e-4, 1.25e-4, 0.05]
+    init = [torch.randn(*s, generator=g) for s in shapes]
+
+    def pair(tensors):
+        pa = [torch.nn.Parameter(t.clone().to(dev)) for t in tensors]
+        pb = [torch.nn.Parameter(t.clone().to(dev)) for t in tensors]
+        fa = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pa, lrs))], eps=1e-15)
+        tb = torch.optim.Adam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(pb, lrs))],
+                              lr=0.0, eps=1e-15)
+        return pa, pb, fa, tb
+
+    def run(pa, pb, fa, tb, steps):
+        for _ in range(steps):
+            for p, q, s in zip(pa, pb, shapes):
+                gr = torch.randn(*s, generator=g).to(dev)
+                p.grad.copy_(gr)
+                q.grad = gr.clone()
+            fa.step()
+            tb.step()
+
+    pa, pb, fa, tb = pair(init)
+    run(pa, pb, fa, tb, 3)
+    sd_f, sd_t = fa.state_dict(), tb.state_dict()
+    assert set(sd_f) == set(sd_t) == {"state", "param_groups"}
+    for i in sd_t["state"]:
+        assert float(sd_f["state"][i]["step"]) == float(sd_t["state"][i]["step"]) == 3.0
+        np.testing.assert_allclose(sd_f["state"][i]["exp_avg"].cpu().numpy(), sd_t["state"][i]["exp_avg"].cpu().numpy(),
+                                   rtol=2e-6, atol=1e-7)  # lerp of O(1) gradients: 1 ulp of the summands
+    # cross-load into a fresh pair that starts from the trained parameters, then keep training
+    now = [p.detach().cpu() for p in pb]
+    pa2, pb2, fa2, tb2 = pair(now)
+    fa2.load_state_dict(sd_t)  # torch checkpoint -> FusedAdam
+    tb2.load_state_dict(sd_f)  # FusedAdam checkpoint -> torch Adam
+    assert int(fa2.state_dev[0]) == 3
+    run(pa2, pb2, fa2, tb2, 3)
+    run(pa, pb, fa, tb, 0)
+    for p, q in zip(pa2, pb2):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    # and its own checkpoint round-trips bit for bit
+    fa3 = pair(now)[2]
+    fa3.load_state_dict(fa2.state_dict())
+    assert torch.equal(fa3.exp_avg, fa2.exp_avg) and torch.equal(fa3.exp_avg_sq, fa2.exp_avg_sq)
+    assert torch.equal(fa3.state_dev, fa2.state_dev)

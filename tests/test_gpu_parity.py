@@ -66,17 +66,19 @@ def test_forward_backward_vs_oracle(oracle_mod, dev, cfg, mode):
     hp.assert_grads_close(got, ref)
 
 
-def test_cfg2_full_size_vs_oracle(oracle_mod, dev):
-    """BASELINE.json configs[1]: 100k Gaussians, 1920x1080, fwd+bwd vs the oracle at full size (tol 1e-4)."""
+@pytest.mark.parametrize("mode", ["A", "B_sr"])
+def test_cfg2_full_size_vs_oracle(oracle_mod, dev, mode):
+    """BASELINE.json configs[1]: 100k Gaussians, 1920x1080, fwd+bwd vs the oracle at full size (tol 1e-4), in pipeline
+    mode (A) and with the covariance computed in the kernel from scales + rotations (B_sr: K9 / K10 / cov3D backward)."""
     from tests.gpu_helpers import GpuRun, to_dev
     spec = syn.CONFIGS["cfg2"]
     ri = syn.raster_inputs(spec)
-    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "A")
-    run = GpuRun(to_dev(ri, dev), "A", debug=False)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
+    run = GpuRun(to_dev(ri, dev), mode, debug=False)
     _check_forward(run, out_o, radii_o, st_o)
     dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
     dL[:, st_o.fragile.astype(bool)] = 0.0
-    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "A")
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, mode)
     got = run.backward(torch.from_numpy(dL))
     hp.assert_grads_close(got, ref)
 
