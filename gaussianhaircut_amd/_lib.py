@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GHR_LIB_PATH") or os.path.join(CSRC, "libghr_hip.so")  # override: kernel experiments
 SOURCES = ["ghr_capi.hip"]
-HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h", "ghr_render_bwd2.h",
+HEADERS = ["ghr_device.h", "ghr_preprocess.h", "ghr_binning.h", "ghr_render_fwd.h", "ghr_render_bwd.h", "ghr_render_bwd2.h", "ghr_render_bwd3.h",
            "ghr_geom_bwd.h", "ghr_project.h", "ghr_loss.h", "ghr_adam.h"]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", "-fPIC",
                "-shared"]
@@ -131,7 +131,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_abi_version.restype = ctypes.c_int
     L.ghr_forward_sizes.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t),
                                     ctypes.POINTER(ctypes.c_size_t)]
-    L.ghr_binning_size.argtypes = [u32, ctypes.POINTER(ctypes.c_size_t)]
+    L.ghr_binning_size.argtypes = [u32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.ghr_forward_stage1.argtypes = [vp, ctypes.POINTER(ViewArgs), vp, vp, vp, vp]
     L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp]
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
@@ -175,7 +175,7 @@ def forward_sizes(P: int, W: int, H: int, mode_b: bool):
     return int(g.value), int(i.value)
 
 
-def binning_size(R: int) -> int:
+def binning_size(R: int, W: int, H: int) -> int:
     b = ctypes.c_size_t(0)
-    check(lib().ghr_binning_size(R, ctypes.byref(b)))
+    check(lib().ghr_binning_size(R, W, H, ctypes.byref(b)))
     return int(b.value)

@@ -19,6 +19,7 @@
 #include "ghr_project.h"
 #include "ghr_render_bwd.h"
 #include "ghr_render_bwd2.h"
+#include "ghr_render_bwd3.h"
 #include "ghr_render_fwd.h"
 
 namespace {
@@ -35,18 +36,32 @@ int k8_variant()
     static int v = -1;
     if (v < 0) {
         const char* e = std::getenv("GHR_K8");
-        v = (e && std::strcmp(e, "scan") == 0) ? 1 : 0;
+        v = (e && std::strcmp(e, "scan") == 0) ? 1 : ((e && std::strcmp(e, "cells") == 0) ? 2 : 0);
     }
     return v;
 }
 
-template <typename... Args>
-void launch_k8(uint32_t T, hipStream_t s, Args... args)
+void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint32_t T_tiles, const uint32_t* tile_start,
+               const uint32_t* point_list, const ghr::f4* rec, const float* bg, const float* final_T,
+               const uint32_t* n_contrib, const float* dL_dpix, const ghr::rect4* rects, float* ginst, uint32_t cap,
+               const unsigned long long* cell_mask, const uint32_t* cell_last)
 {
-    if (k8_variant() == 1)
-        hipLaunchKernelGGL(ghr::k_render_bwd_scan, dim3(ghr::xcd_grid(T)), dim3(GHR_BLOCK), 0, s, args...);
-    else
-        hipLaunchKernelGGL(ghr::k_render_bwd, dim3(ghr::xcd_grid(T)), dim3(GHR_BLOCK), 0, s, args...);
+    const dim3 grid(ghr::xcd_grid(T)), block(GHR_BLOCK);
+    int v = k8_variant();
+    if (v == 2 && !ghr::b3_fits(rows, cap, (size_t)W, (size_t)H)) v = 0;  // its 32-bit offsets
+    switch (v) {
+    case 2:
+        hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
+                           final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last);
+        break;
+    case 1:
+        hipLaunchKernelGGL(ghr::k_render_bwd_scan, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
+                           final_T, n_contrib, dL_dpix, rects, ginst, cap);
+        break;
+    default:
+        hipLaunchKernelGGL(ghr::k_render_bwd, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
+                           final_T, n_contrib, dL_dpix, rects, ginst, cap);
+    }
 }
 
 int fail(int code, const char* fmt, const char* detail = "")
@@ -90,10 +105,12 @@ struct Img {
     uint32_t* tile_count;  // [T]: per-tile instance count, then append cursor
     uint32_t* tile_start;  // [T+1]
     uint32_t* R_dev;
+    uint32_t* cell_last;   // [16 T]: largest n_contrib of each 4x4-pixel cell
 };
 struct Bin {
     uint64_t* keys;
     uint32_t* point_list;
+    unsigned long long* cell_mask;  // [mask_groups(R, T)][16]
 };
 
 size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
@@ -117,16 +134,18 @@ size_t carve_img(char* base, size_t N, size_t T, Img* im)
     uint32_t* tile_count = (uint32_t*)take(T * 4);
     uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
     uint32_t* R_dev = (uint32_t*)take(4);
-    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev};
+    uint32_t* cell_last = (uint32_t*)take(T * 16 * 4);
+    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev, cell_last};
     return off + ALIGN;
 }
-size_t carve_bin(char* base, size_t R, Bin* b)
+size_t carve_bin(char* base, size_t R, size_t T, Bin* b)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
     uint64_t* keys = (uint64_t*)take(R * 8);
     uint32_t* pl = (uint32_t*)take(R * 4);
-    if (b) *b = Bin{keys, pl};
+    unsigned long long* cm = (unsigned long long*)take(ghr::mask_groups(R, T) * 16 * 8);
+    if (b) *b = Bin{keys, pl, cm};
     return off + ALIGN;
 }
 inline char* align_base(const void* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
@@ -178,10 +197,10 @@ int ghr_forward_sizes(int32_t P, int32_t W, int32_t H, int32_t mode_b, size_t* g
     return GHR_OK;
 }
 
-int ghr_binning_size(uint32_t R, size_t* bin_bytes)
+int ghr_binning_size(uint32_t R, int32_t W, int32_t H, size_t* bin_bytes)
 {
-    if (!bin_bytes) return fail(GHR_E_INVALID, "ghr_binning_size: bad args");
-    *bin_bytes = carve_bin(nullptr, (size_t)R, nullptr);
+    if (!bin_bytes || W <= 0 || H <= 0) return fail(GHR_E_INVALID, "ghr_binning_size: bad args");
+    *bin_bytes = carve_bin(nullptr, (size_t)R, (size_t)grid_x(W) * grid_x(H), nullptr);
     return GHR_OK;
 }
 
@@ -240,7 +259,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     Geom g; Img im; Bin b;
     carve_geom(align_base(geom_ws), (size_t)a->P, false, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
-    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)T, &b);
     if (R > 0) {
         // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
@@ -251,7 +270,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                        (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
-                       im.n_contrib, R);
+                       im.n_contrib, R, b.cell_mask, im.cell_last);
     if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }
@@ -278,13 +297,14 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     Geom g; Img im; Bin b;
     carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
-    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)T, &b);
 
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
     if (R > 0)
-        launch_k8((uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
+        launch_k8((size_t)a->P, (uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
                   (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, a->background, (const float*)im.final_T,
-                  (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R);
+                  (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -404,11 +424,12 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     Geom g; Img im; Bin b;
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
-    carve_bin(align_base(bin_ws), (size_t)R, &b);
+    carve_bin(align_base(bin_ws), (size_t)R, (size_t)T, &b);
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    launch_k8((uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start, (const uint32_t*)b.point_list,
+    launch_k8((size_t)rows_total, (uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start, (const uint32_t*)b.point_list,
               (const ghr::f4*)g.rec, background, (const float*)im.final_T, (const uint32_t*)im.n_contrib, dL_dpix,
-              (const ghr::rect4*)g.rects, grad_scratch, R);
+              (const ghr::rect4*)g.rects, grad_scratch, R, (const unsigned long long*)b.cell_mask,
+              (const uint32_t*)im.cell_last);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }
@@ -599,6 +620,21 @@ int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, voi
     return GHR_OK;
 }
 
+#ifdef GHR_K8_PROF
+// kernel-experiment builds only (not declared in include/ghr.h): per-wave phase cycles of the instrumented K8
+int ghr_debug_prof(unsigned long long* out, int n_slots, int reset)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return GHR_E_HIP;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ghr::g_k8_prof), 64 * (size_t)n_slots) != hipSuccess) return GHR_E_HIP;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ghr::g_k8_prof)) != hipSuccess) return GHR_E_HIP;
+        if (hipMemset(p, 0, 64 * (size_t)GHR_PROF_SLOTS) != hipSuccess) return GHR_E_HIP;
+    }
+    return GHR_OK;
+}
+#endif
+
 int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, const void* geom_ws,
                    const void* img_ws, const void* bin_ws, ghr_ws_view* out)
 {
@@ -607,7 +643,7 @@ int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, 
     Geom g; Img im; Bin b;
     carve_geom(align_base(geom_ws), (size_t)P, mode_b != 0, &g);
     carve_img(align_base(img_ws), (size_t)W * H, T, &im);
-    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, &b);
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)T, &b);
     out->rec = (const float*)g.rec;
     out->depths = g.depths;
     out->rects = (const uint32_t*)g.rects;

@@ -293,6 +293,41 @@ GHR_HD uint32_t xcd_tile(uint32_t b, uint32_t n)
     return (j * 8u + xcd) * GHR_XCD_RUN + o;
 }
 
+// Cell masks (written by k_render_fwd, read by k_render_bwd_cells): one group of 16 64-bit words (one per 4x4-pixel
+// cell of the tile) per 64 list positions.  Tile t's groups start at mask_word0(tile_start[t], t): floor(start / 64) + t
+// leaves every tile ceil(n / 64) groups of its own; mask_groups(R, T) groups in all.
+GHR_HD size_t mask_word0(uint32_t tile_beg, uint32_t tile) { return (size_t)(tile_beg >> 6) + tile; }
+GHR_HD size_t mask_groups(size_t R, size_t T) { return (R >> 6) + T + 1; }
+
+// Phase timing for kernel experiments (tools/kbench.py against a -DGHR_K8_PROF build): shader-clock cycles per phase of
+// every wave, one slot per wave (no atomics), summed on the host.  Compiled out of the product.
+#ifdef GHR_K8_PROF
+#define GHR_PROF_SLOTS 65536
+__device__ unsigned long long g_k8_prof[8 * GHR_PROF_SLOTS];
+#define GHR_PROF_DECL                                                           \
+    unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_t0 = prof_t; \
+    unsigned long long prof_a[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define GHR_PROF(i)                                                 \
+    do {                                                            \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        prof_a[i] += t_ - prof_t;                                   \
+        prof_t = t_;                                                \
+    } while (0)
+#define GHR_PROF_COUNT(i, n) do { prof_a[i] += (unsigned long long)(n); } while (0)
+#define GHR_PROF_END(i)                                                                   \
+    do {                                                                                  \
+        prof_a[i] = __builtin_amdgcn_s_memtime() - prof_t0;                               \
+        const uint32_t w_ = (blockIdx.x * 4u + (threadIdx.x >> 6)) % GHR_PROF_SLOTS;      \
+        if ((threadIdx.x & 63) == 0)                                                      \
+            for (int q_ = 0; q_ < 8; q_++) g_k8_prof[8 * w_ + q_] = prof_a[q_];           \
+    } while (0)
+#else
+#define GHR_PROF_DECL
+#define GHR_PROF(i)
+#define GHR_PROF_COUNT(i, n)
+#define GHR_PROF_END(i)
+#endif
+
 // v_exp_f32 / v_rcp_f32 (1 ulp each); exp(x) = 2^(x*log2 e) carries a few ulp more from the rounded product.
 GHR_HD float fast_exp(float x)
 {

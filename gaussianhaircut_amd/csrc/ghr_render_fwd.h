@@ -12,6 +12,9 @@
 // A batch of 256 list entries is staged as packed 64-B records (position, conic, opacity AND the 10 features -- the
 // reference re-gathers features from global memory per contributing pixel, forward.cu:381) into four SoA float4 planes;
 // the gather for batch b+1 is issued into registers before batch b is composited.
+// The cell masks are also what the backward pass needs to know (which list entries can touch which cell): they are
+// stored -- one 64-bit word per (64 list positions, cell), 2 B per instance -- together with each cell's largest
+// n_contrib, so that k_render_bwd_cells (ghr_render_bwd3.h) neither recomputes the cull nor stages whole tiles.
 #pragma once
 #include "ghr_device.h"
 
@@ -60,7 +63,9 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           const uint32_t* __restrict__ point_list,
                                                           const f4* __restrict__ rec, const float* __restrict__ bg,
                                                           float* __restrict__ out_color, float* __restrict__ final_T,
-                                                          uint32_t* __restrict__ n_contrib, uint32_t cap)
+                                                          uint32_t* __restrict__ n_contrib, uint32_t cap,
+                                                          unsigned long long* __restrict__ cell_mask,
+                                                          uint32_t* __restrict__ cell_last)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
@@ -116,6 +121,9 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             const uint32_t e = sub + lane;
             const uint32_t ec = e < cnt ? e : 0;
             unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
+            // word (base + sub) / 64 of this cell: every position a pixel of the cell can count in n_contrib lies in a
+            // word written here (a cell that is finished, or a tile that stops early, has all its n_contrib behind it)
+            if (l == 0) cell_mask[(mask_word0(beg, tile) + ((base + sub) >> 6)) * 16 + 4 * wave + grp] = todo;
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
@@ -127,6 +135,14 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
 
 #undef GHR_GATHER
 
+    {   // the cell's largest n_contrib: positions at or beyond it are dead for all its pixels (backward.cu:490-492)
+        uint32_t lm = inside ? st.last : 0u;
+        lm = max(lm, (uint32_t)__shfl_xor((int)lm, 1));
+        lm = max(lm, (uint32_t)__shfl_xor((int)lm, 2));
+        lm = max(lm, (uint32_t)__shfl_xor((int)lm, 4));
+        lm = max(lm, (uint32_t)__shfl_xor((int)lm, 8));
+        if (l == 0) cell_last[16 * (size_t)tile + 4 * wave + grp] = lm;
+    }
     if (inside) {  // forward.cu:393-399
         const size_t pix = (size_t)W * py + px;
         const size_t plane = (size_t)W * H;

@@ -218,7 +218,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 _ptr(radii), ctypes.c_void_p(pinned.data_ptr())))
 
                 def launch(cap):
-                    b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                    b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
                     _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), cap, _ptr(geomBuffer),
                                                     _ptr(imgBuffer), _ptr(b), _ptr(color)))
                     return b

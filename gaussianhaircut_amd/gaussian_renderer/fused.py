@@ -58,7 +58,7 @@ class _RenderModelFused(torch.autograd.Function):
             va.debug = int(bool(cfg["debug"]))
 
             def launch(cap):
-                b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
                 _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
                                                 _ptr(color)))
                 return b
@@ -219,7 +219,7 @@ class _RenderHairFused(torch.autograd.Function):
             va.debug = int(bool(cfg["debug"]))
 
             def launch(cap):
-                b = torch.empty((_lib.binning_size(cap),), dtype=torch.uint8, device=dev)
+                b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
                 _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
                                                 _ptr(color)))
                 return b

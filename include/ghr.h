@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 11
+#define GHR_ABI_VERSION 12
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -74,10 +74,13 @@ const char* ghr_last_error(void);
 int ghr_abi_version(void);
 
 /* Workspace sizes (host only).  geom: per-Gaussian state (packed 64-B render records, depths, tile rects,
- * [mode B: cov3D]); img: per-pixel final_T / n_contrib + per-tile counts and list offsets. */
+ * [mode B: cov3D]); img: per-pixel final_T / n_contrib + per-tile counts, list offsets and the largest n_contrib of
+ * each 4x4-pixel cell. */
 int ghr_forward_sizes(int32_t P, int32_t W, int32_t H, int32_t mode_b, size_t* geom_bytes, size_t* img_bytes);
-/* bin: per-instance (Gaussian x tile) sort keys + the sorted point list. */
-int ghr_binning_size(uint32_t R, size_t* bin_bytes);
+/* bin: per-instance (Gaussian x tile) sort keys + the sorted point list + (ABI 12) the forward pass's cell masks:
+ * per 64 list positions of a tile and per 4x4-pixel cell, which entries can touch the cell (2 B per instance + 128 B
+ * per tile, hence W and H). */
+int ghr_binning_size(uint32_t R, int32_t W, int32_t H, size_t* bin_bytes);
 
 /* Stage 1 = preprocess (K1) + per-tile instance count + tile offset scan.  Writes radii[P] (int32, 0 = culled)
  * and asynchronously copies num_rendered R to *R_host (pinned host memory; valid once `stream` reaches the

@@ -67,7 +67,7 @@ class GpuRun:
                                         _ptr(self.radii), ctypes.c_void_p(pinned.data_ptr())))
         torch.cuda.current_stream().synchronize()
         self.R = int(pinned[0].item()) if P > 0 else 0
-        self.bin = torch.zeros(_lib.binning_size(self.R), dtype=torch.uint8, device=dev)
+        self.bin = torch.zeros(_lib.binning_size(self.R, W, H), dtype=torch.uint8, device=dev)
         _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(self.args), self.R, _ptr(self.geom), _ptr(self.img),
                                         _ptr(self.bin), _ptr(self.out)))
         torch.cuda.synchronize()

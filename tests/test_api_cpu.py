@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ghr_abi_version() == 11
+    assert L.ghr_abi_version() == 12
 
 
 def test_workspace_sizes_and_error_codes():
@@ -37,7 +37,7 @@ def test_workspace_sizes_and_error_codes():
     gb, _ = _lib.forward_sizes(1000, 1920, 1080, True)
     assert g >= 1000 * (64 + 4 + 8) and gb >= g + 1000 * 24
     assert i >= 1920 * 1080 * 8 + 8160 * 8
-    assert _lib.binning_size(1000) >= 12000 and _lib.binning_size(0) > 0
+    assert _lib.binning_size(1000, 64, 64) >= 12000 and _lib.binning_size(0, 64, 64) > 0
     L = _lib.lib()
     a = _lib.ViewArgs()
     a.P, a.W, a.H, a.C = 4, 64, 64, 3

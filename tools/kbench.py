@@ -43,6 +43,22 @@ def main():
             tf.append(ev[0].elapsed_time(ev[1]))
             tb.append(ev[2].elapsed_time(ev[3]))
     L.ghr_set_profile_events(None, None, None, None)
+    if hasattr(L, "ghr_debug_prof"):  # -DGHR_K8_PROF build: cycles per phase of the instrumented K8, per wave
+        import numpy as np
+        n_slots = 65536
+        buf = np.zeros((n_slots, 8), np.uint64)
+        L.ghr_debug_prof(None, 0, 1)
+        _lib.check(L.ghr_backward(_stream(), ctypes.byref(run.args), run.R, _ptr(run.radii), _ptr(run.geom),
+                                  _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o]))
+        L.ghr_debug_prof(ctypes.c_void_p(buf.ctypes.data), n_slots, 0)
+        v = buf.astype(np.float64)
+        used = v[:, 6] > 0
+        tot = v[used].sum(axis=0)
+        names = os.environ.get("GHR_PROF_NAMES", "p0,p1,p2,p3,p4,p5").split(",")
+        print("PROF " + "  ".join("%s=%.1f%%" % (nm, 100 * tot[i] / tot[6]) for i, nm in enumerate(names)),
+              " waves=%d cycles_per_wave mean %.0f p50 %.0f p99 %.0f max %.0f  count7=%d p4_cycles_per_count=%.0f" %
+              (used.sum(), v[used, 6].mean(), np.percentile(v[used, 6], 50), np.percentile(v[used, 6], 99),
+               v[used, 6].max(), int(tot[7]), tot[4] / max(tot[7], 1)))
     tf.sort(), tb.sort()
     print("KBENCH %s lib=%s P=%d R=%d  k_render_fwd med %.4f min %.4f ms   k_render_bwd med %.4f min %.4f ms" %
           (cfg, _lib.LIB_PATH.split("/")[-1], P, run.R, tf[len(tf) // 2], tf[0], tb[len(tb) // 2], tb[0]))
