@@ -28,15 +28,18 @@ thread_local char g_err[512] = "";
 // Process-wide (NOT thread_local): torch's autograd engine calls ghr_backward from its own worker thread.
 hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
 
-// K8 variant: 0 = cell-group form (k_render_bwd; default: 0.24 ms on 500k strands), 1 = scan form (k_render_bwd_scan:
-// lanes bound to pairs, MFMA reduction; half the VALU instructions but 0.26-0.28 ms -- at four waves per SIMD its
-// load / staging phases do not overlap with the arithmetic).  GHR_K8=cell|scan selects; same line format.
+// K8 variant (same gradient-line format, GHR_K8=cells|cell|scan selects):
+//   2 = cell-list form (k_render_bwd_cells, default): one wave per 4x4 cell from the forward pass's hit masks, records
+//       gathered straight into LDS two chunks ahead; 0.214 ms on 500k strands;
+//   0 = cell-group form (k_render_bwd): lane = pixel, 16-lane butterflies; 0.238 ms; also the fallback where the
+//       cell-list form's 32-bit offsets do not reach (b3_fits);
+//   1 = scan form with the tile pipeline (k_render_bwd_scan): 0.26-0.28 ms.
 int k8_variant()
 {
     static int v = -1;
     if (v < 0) {
         const char* e = std::getenv("GHR_K8");
-        v = (e && std::strcmp(e, "scan") == 0) ? 1 : ((e && std::strcmp(e, "cells") == 0) ? 2 : 0);
+        v = (e && std::strcmp(e, "scan") == 0) ? 1 : ((e && std::strcmp(e, "cell") == 0) ? 0 : 2);
     }
     return v;
 }
@@ -255,6 +258,8 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         return finish(s, a->debug);
     }
     if (!geom_ws || !img_ws || (R > 0 && !bin_ws)) return fail(GHR_E_INVALID, "workspace is NULL");
+    if (ghr::mask_groups((size_t)R, (size_t)T) * 128 >= ((size_t)1 << 32))
+        return fail(GHR_E_INVALID, "too many instances for the 32-bit offsets of the cell masks");
     // the cov3D plane (mode B) lies behind everything stage 2 touches, so the carve is mode-independent here
     Geom g; Img im; Bin b;
     carve_geom(align_base(geom_ws), (size_t)a->P, false, &g);

@@ -123,7 +123,12 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
             // word (base + sub) / 64 of this cell: every position a pixel of the cell can count in n_contrib lies in a
             // word written here (a cell that is finished, or a tile that stops early, has all its n_contrib behind it)
-            if (l == 0) cell_mask[(mask_word0(beg, tile) + ((base + sub) >> 6)) * 16 + 4 * wave + grp] = todo;
+#ifndef GHR_K7_NOMASK
+            // (uniform base + 32-bit byte offset: one address register; the kernel sits at the 80-VGPR occupancy step)
+            if (l == 0)
+                *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(cell_mask) +
+                    (128u * (uint32_t)(mask_word0(beg, tile) + ((base + sub) >> 6)) + 8u * (uint32_t)(4 * wave + grp))) = todo;
+#endif
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
@@ -135,14 +140,16 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
 
 #undef GHR_GATHER
 
+#ifndef GHR_K7_NOLAST
     {   // the cell's largest n_contrib: positions at or beyond it are dead for all its pixels (backward.cu:490-492)
         uint32_t lm = inside ? st.last : 0u;
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 1));
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 2));
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 4));
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 8));
-        if (l == 0) cell_last[16 * (size_t)tile + 4 * wave + grp] = lm;
+        if (l == 0) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cell_last) + (64u * tile + 4u * (uint32_t)(4 * wave + grp))) = lm;
     }
+#endif
     if (inside) {  // forward.cu:393-399
         const size_t pix = (size_t)W * py + px;
         const size_t plane = (size_t)W * H;
