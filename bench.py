@@ -14,7 +14,7 @@ step at every N (a global step covers N views).
   value               = N * P_vis / t_step   Gaussians per second through the whole step, P_vis = Gaussians of the
                         model that pass the cull of the view (radii > 0), NOT the model size
   grad_steps_per_sec  = 1 / t_step
-  roofline            : k_render_bwd (the dominant kernel): SURVEY 8(d) algorithmic bytes / HIP-event duration on the
+  roofline            : k_render_bwd_cells = K8 (the dominant kernel): SURVEY 8(d) algorithmic bytes / HIP-event duration on the
                         launch stream over solo passes of the same view, against 8 TB/s HBM; `traffic` from the committed
                         rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/).
 Further blocks of the same line (N = 1 unless noted), each named for the BASELINE config it measures:
@@ -200,13 +200,16 @@ def main():
             traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
         except Exception:
             traffic = None
-    roofline = {"kernel": "k_render_bwd", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    roofline = {"kernel": "k_render_bwd_cells (K8; GHR_K8=cell|scan select the older forms)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "VALU-bound gradient walk (SQ_ACTIVE_INST_VALU ~89 %% of the SIMD cycles); algorithmic bytes "
-                        "132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured view; kernel duration from "
-                        "HIP events the library records around the kernel on its launch stream, %d solo passes" % n_ev}
+                "note": "gradient walk bound by VALU issue and memory latency, not by bandwidth (profiles/r02b: "
+                        "SQ_ACTIVE_INST_VALU 55 %% of the SIMD cycles at 5 waves per SIMD, half the VALU instructions of "
+                        "round 1's kernel; every L2 atomic is written through to HBM, hence traffic > algorithmic "
+                        "bytes); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured "
+                        "view; kernel duration from HIP events the library records around the kernel on its launch "
+                        "stream, %d solo passes" % n_ev}
 
     out = {
         "metric": "gaussians_per_sec_grad_step_500k_strands_1080p", "value": round(value, 1), "unit": "Gaussians/s",

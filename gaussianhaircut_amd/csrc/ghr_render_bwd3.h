@@ -133,10 +133,11 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
         };
         // chunks of 16 entries from the top of the segment's list: chunk t holds the list indices n_c - 16 t - 1 - e,
         // e = 0..15 (ascending e = back to front); the ones past the front of the list repeat the chunk's last entry and
-        // are masked.  Lane L gathers quarter L & 3 of entry L >> 2.
+        // are masked.  Lane L gathers quarter L >> 4 of entry L & 15, so that a buffer holds the 16 first quarters, then the 16
+        // second ones, ...: the chunk's reads below (16 entries side by side) are free of bank conflicts.
         auto issue = [&](uint32_t t) {
             const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
-            const uint32_t e = min((uint32_t)lane >> 2, cnt - 1u);
+            const uint32_t e = min((uint32_t)lane & 15u, cnt - 1u);
             const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
             uint32_t id, slot;
             if (SMALL) {
@@ -146,8 +147,8 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 id = ld32(point_list, 4u * (beg + pos));
                 slot = min(rect4_slot(ld32(rects, 16u * id), tx, ty), cap - 1u);
             }
-            gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane & 3u), &sh.rec[wave][t % GHR_B3_NBUF][0]);
-            if ((lane & 3) == 0) sh.cslot[wave][t % GHR_B3_NBUF][lane >> 2] = slot;
+            gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][t % GHR_B3_NBUF][0]);
+            if (lane < 16) sh.cslot[wave][t % GHR_B3_NBUF][lane] = slot;
         };
         build();
         while (n_c == 0 && w_hi >= GHR_B3_SEG_WORDS) { w_hi -= GHR_B3_SEG_WORDS; build(); }
@@ -245,11 +246,14 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 
                 const bool valid = (uint32_t)m < cnt;
                 const uint32_t j = min((uint32_t)m, cnt - 1u);  // lanes past the end recompute the last entry, masked
-                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 16u * j;
+                // field f of entry j sits at float (f >> 2) * 64 + 4 j + (f & 3): quarter-major, see the gather
+                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * j;
                 const f4 r0 = *reinterpret_cast<const f4*>(R);              // x y a b
-                const f2b r1 = *reinterpret_cast<const f2b*>(R + 4);        // c o
+                const f2b r1 = *reinterpret_cast<const f2b*>(R + 64);       // c o
                 const float ex = r0.x, ey = r0.y, ca = r0.z, cb = r0.w, cc = r1.x, o = r1.y;
-                const float col0 = R[6 + k], col1 = R[10 + k], col2 = k < 2 ? R[6 + kc2] : 0.f;
+                const int f0 = 6 + k, f1 = 10 + k, f2 = 6 + kc2;            // colours k, 4 + k, 8 + k
+                const float col0 = R[(f0 >> 2) * 64 + (f0 & 3)], col1 = R[(f1 >> 2) * 64 + (f1 & 3)],
+                            col2 = k < 2 ? R[(f2 >> 2) * 64 + (f2 & 3)] : 0.f;
                 const uint32_t pos = 64u * w_lo + list[hi - 1u - j];
                 // colour . dL/dpixel for the lane's four pixels
                 f4 cd = {0.f, 0.f, 0.f, 0.f};
