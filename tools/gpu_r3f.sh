@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/r3f; mkdir -p $O; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+R=$GRAFT_REPO_ROOT
+V=$R/gaussianhaircut_amd/csrc/variants
+export GHR_PROF_NAMES="first acquire,acquire next,-,wait gather,chunk,exit"
+( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_reference_cuda_golden.py tests/test_gpu_fused_fullsize.py -q -m gpu --timeout 800 -x ) > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+tail -3 $O/pytest.log
+for lib in "" $V/libghr_aprof.so; do
+for c in cfg3 cfg2 cfg5; do
+( GHR_LIB_PATH=$lib timeout 120 python tools/kbench.py $c 30 ) 2>&1 | grep -E "KBENCH|PROF|rror" >> $O/kbench.log
+done; done; cat $O/kbench.log
