@@ -325,17 +325,22 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 // without an entry are masked out of EXEC by hand -- under an `if` the compiler would branch around the
                 // instruction -- and lane 0 always takes part (adding 0.0 to a line of the chunk when its row is empty),
                 // so that the instruction never runs with an empty mask.
+                // (lane (k, c) adds to the entries 4k + r: their lines from one 16-B read -- the gather fills all sixteen
+                // slots of a chunk, the ones past the end with the last entry's; which rows have an entry is wave-uniform
+                // arithmetic on cnt: the rows k < ceil((cnt - r) / 4))
+                const uint32_t* cs4 = &sh.cslot[wave][t % GHR_B3_NBUF][4 * k];
+                const uint32_t sl[4] = {cs4[0], cs4[1], cs4[2], cs4[3]};
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint32_t te = 4u * k + r;
-                    const uint32_t slot = sh.cslot[wave][t % GHR_B3_NBUF][min(te, cnt - 1u)];
+                    const uint32_t rows = cnt > (uint32_t)r ? (cnt - (uint32_t)r + 3u) >> 2 : 0u;   // 0..4, wave-uniform
+                    const unsigned long long has = rows >= 4u ? ~0ull : ((1ull << (16u * rows)) - 1ull);
                     float val = r == 0 ? d.x : (r == 1 ? d.y : (r == 2 ? d.z : d.w));
-                    val = te < cnt ? val : 0.f;
+                    val = ((has >> lane) & 1ull) ? val : 0.f;  // (only lane 0 can be active without an entry)
 #ifdef GHR_B3_NOATOM  // ablation: the arithmetic stays alive, the memory operation goes
-                    abl += val * (float)(slot & 1u);
+                    abl += val * (float)(sl[r] & 1u);
 #else
-                    const unsigned long long on = __builtin_amdgcn_ballot_w64(te < cnt) | 1ull;
-                    const uint32_t off = 64u * slot + 4u * (uint32_t)m;
+                    const unsigned long long on = has | 1ull;
+                    const uint32_t off = 64u * sl[r] + 4u * (uint32_t)m;
                     unsigned long long saved;
                     asm volatile("s_mov_b64 %0, exec\n\t"
                                  "s_and_b64 exec, exec, %1\n\t"
