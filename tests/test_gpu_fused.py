@@ -15,9 +15,14 @@ FUSED = SimpleNamespace(debug=False, fused_projection=True)
 GENERIC = SimpleNamespace(debug=False, fused_projection=False)
 
 
-def _run(spec, pipe, dev, weights, deg):
+def _model(spec, dev, deg):
     model = syn.make_model(spec, dev)
     model.active_sh_degree = deg
+    return model
+
+
+def _run(spec, pipe, dev, weights, deg):
+    model = _model(spec, dev, deg)
     cam = syn.make_view(spec, dev)
     pkg = render(cam, model, pipe, syn.background(dev))
     full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
@@ -29,29 +34,76 @@ def _run(spec, pipe, dev, weights, deg):
     return pkg, grads
 
 
+def _pixel_mask(state, H, W, radii_a, radii_b, means2d):
+    """Pixels left out of a comparison between two chains, EXPLICITLY: the oracle's fragile pixels (a discrete decision
+    -- alpha >= 1/255, T < 1e-4 -- within 2e-5 of its threshold) and a box around every Gaussian whose radius differs
+    between the chains (differently rounded projection arithmetic may flip the ceil): its 3-sigma square + one tile.
+    Returns (mask [H, W] bool, number of flipped Gaussians)."""
+    mask = np.asarray(state.fragile).reshape(H, W).astype(bool).copy()
+    flipped = np.nonzero(np.asarray(radii_a) != np.asarray(radii_b))[0]
+    for i in flipped:
+        r = int(max(radii_a[i], radii_b[i])) + 17
+        x, y = float(means2d[i, 0]), float(means2d[i, 1])
+        mask[max(0, int(y) - r):int(y) + r + 1, max(0, int(x) - r):int(x) + r + 1] = True
+    return mask, int(flipped.size)
+
+
+def _assert_rows_close(name, a, b, tol=1e-4, floor=1e-5):
+    """|a - b| <= tol * (|b| + largest |b| of the ROW) + floor * largest |b| of the tensor -- every element.  The floor
+    covers rows whose own gradient is the small difference of large terms (quaternion / scale chains) with fp32 atomics
+    of a different order on BOTH sides of these HIP-vs-HIP comparisons; 1e-5 of the tensor's largest element."""
+    a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
+    assert np.isfinite(a).all(), name
+    rows = np.abs(b).max(axis=1, keepdims=True)
+    ok = np.abs(a - b) <= tol * (np.abs(b) + rows) + floor * np.abs(b).max()
+    assert ok.all(), "%s: %d / %d elements off, worst |d| %g (tensor max %g)" % (
+        name, (~ok).sum(), ok.size, np.abs(a - b)[~ok].max(), np.abs(b).max())
+
+
 @pytest.mark.parametrize("cfg,deg", [("tiny", 3), ("tiny_strands", 3), ("ragged", 1), ("cfg1", 2)])
 def test_fused_render_matches_generic_path(cfg, deg):
+    """Fused projection (k_project / k_project_bwd) vs the generic PyTorch projection around the same HIP rasterizer.
+    No quantiles: the pixels that may legitimately differ are named (`_pixel_mask`, from the oracle chain's state of the
+    same scene) and get zero weight on both sides; everything else must agree -- image 1e-4, every gradient row 1e-4."""
+    from tests import oracle_backend as ob
     dev = torch.device("cuda:0")
     spec = syn.CONFIGS[cfg]
     g = torch.Generator().manual_seed(5)
-    weights = torch.randn(7, spec.H, spec.W, generator=g).to(dev)
+    weights = torch.randn(7, spec.H, spec.W, generator=g)
+    # the oracle chain of the same scene names the fragile pixels
+    mc = syn.make_model(spec, "cpu")
+    mc.active_sh_degree = deg
+    with ob.oracle_rasterizer():
+        pc = render(syn.make_view(spec, "cpu"), mc, GENERIC, syn.background("cpu"))
+    st = ob.LAST["state"]
+    with torch.no_grad():
+        pf0 = render(syn.make_view(spec, dev), _model(spec, dev, deg), FUSED, syn.background(dev))
+        pg0 = render(syn.make_view(spec, dev), _model(spec, dev, deg), GENERIC, syn.background(dev))
+    rf, rg, rc = pf0["radii"].cpu().numpy(), pg0["radii"].cpu().numpy(), pc["radii"].numpy()
+    m2d = pc["viewspace_points"].detach().numpy()
+    mask, n1 = _pixel_mask(st, spec.H, spec.W, rf, rg, m2d)
+    mask2, n2 = _pixel_mask(st, spec.H, spec.W, rf, rc, m2d)
+    mask |= mask2
+    assert n1 + n2 <= max(2, int(1e-3 * spec.P)) and mask.mean() < 0.05, (n1, n2, mask.mean())
+    weights = weights * torch.from_numpy(~mask).float()
+    # the orientation angle (normalize / mirror / clamp / acos of the rendered 2D direction, gaussian_renderer:53-57) has
+    # its own non-smooth places: null direction, mirror line, clamp ends -- no weight there either
+    d = pc._cov2d[:2].detach()
+    nrm = d.norm(dim=0)
+    c = d[1] / nrm.clamp_min(1e-12)
+    weights[6] *= ((nrm > 1e-2) & (d[0].abs() > 1e-3 * nrm) & (c.abs() < 0.998)).float()
+    weights = weights.to(dev)
     pf, gf = _run(spec, FUSED, dev, weights, deg)
     pg, gg = _run(spec, GENERIC, dev, weights, deg)
-    assert (pf["radii"] != pg["radii"]).float().mean() < 1e-3  # differently-rounded fp32 may flip a ceil()
     assert torch.equal(pf["visibility_filter"], pf["radii"] > 0)
-    for k in ("render", "mask", "orient_conf", "orient_angle"):
-        a, b = pf[k].detach().cpu().numpy(), pg[k].detach().cpu().numpy()
-        err = np.abs(a - b) / np.maximum(1.0, np.abs(b))
-        assert np.quantile(err, 0.999) < 1e-4, (k, np.quantile(err, 0.999), err.max())
+    ok = torch.from_numpy(~mask).to(dev)
+    for k in ("render", "mask", "orient_conf"):
+        a, b = pf[k].detach()[:, ok].cpu().numpy(), pg[k].detach()[:, ok].cpu().numpy()
+        assert (np.abs(a - b) <= 1e-4 * np.maximum(1.0, np.abs(b))).all(), (k, np.abs(a - b).max())
     vf, vg = pf["viewspace_points"].detach().cpu().numpy(), pg["viewspace_points"].detach().cpu().numpy()
     assert np.abs(vf[:, :2] - vg[:, :2]).max() < 1e-5
     for k in gg:
-        a, b = gf[k].reshape(len(gf[k]), -1), gg[k].reshape(len(gg[k]), -1)
-        assert np.isfinite(a).all()
-        scale = np.abs(b).max() + 1e-30
-        rows = np.abs(b).max(axis=1, keepdims=True)
-        err = np.abs(a - b) / (rows + 1e-3 * scale)
-        assert np.quantile(err, 0.995) < 2e-3, (k, np.quantile(err, 0.995), err.max())
+        _assert_rows_close(k, gf[k], gg[k])
 
 
 def test_fused_training_step_runs_and_learns():
@@ -213,42 +265,62 @@ def test_direct_gradient_sink_equals_autograd_accumulation_and_raises_nan_flag()
     assert bool(same.all()) and int(model.optimizer.state_dev[0]) == 0 and int(model.optimizer.state_dev[1]) == 0
 
 
-def test_render_hair_gpu_matches_cpu_oracle_path():
-    """render_hair() on the HIP rasterizer (mode A_sr) vs the same host code driving the CPU oracle: image, radii and
-    the gradients that reach the strand parameters."""
+def _hair_weights(spec, pkg_cpu, state, radii_list, seed=3):
+    """Loss weights of the hair comparisons: random, zero on the pixels named by `_pixel_mask` (against every radii set
+    in radii_list) and, for the angle channel, on the non-smooth places of the orientation angle."""
+    w = torch.randn(7, spec.H, spec.W, generator=torch.Generator().manual_seed(seed))
+    rc = pkg_cpu["radii"].numpy()
+    m2d = pkg_cpu["viewspace_points"].detach().numpy()
+    mask, flips = np.zeros((spec.H, spec.W), bool), 0
+    for r in radii_list:
+        mk, n = _pixel_mask(state, spec.H, spec.W, rc, r, m2d)
+        mask |= mk
+        flips += n
+    assert flips <= max(2, int(1e-3 * rc.size)) and mask.mean() < 0.05, (flips, mask.mean())
+    w = w * torch.from_numpy(~mask).float()
+    d = pkg_cpu._cov2d[:2].detach()
+    nrm = d.norm(dim=0)
+    c = d[1] / nrm.clamp_min(1e-12)
+    w[6] *= ((nrm > 1e-2) & (d[0].abs() > 1e-3 * nrm) & (c.abs() < 0.998)).float()
+    return w, mask
+
+
+def _hair_pass(where, pipe, w, init_gaussians=False):
     from gaussianhaircut_amd.gaussian_renderer import render_hair
     from tests.oracle_backend import oracle_rasterizer
     from tests.test_api_cpu import _hair_scene
+    import contextlib
+    spec, head, hair, cam = _hair_scene(where)
+    if init_gaussians:  # strand parameters are the leaves: rebuild the per-Gaussian tensors inside the graph
+        hair.initialize_gaussians_hair()
+    with (oracle_rasterizer() if str(where) == "cpu" else contextlib.nullcontext()):
+        pkg = render_hair(cam, head, hair, pipe, syn.background(where))
+        full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
+        if w is not None:
+            (full * w.to(where)).sum().backward()
+    grads = None
+    if w is not None:
+        grads = {n: getattr(hair, n).grad.detach().cpu().numpy() for n in ("_dirs", "_features_dc", "_features_rest", "_orient_conf")}
+    return spec, pkg, full.detach().cpu().numpy(), grads
+
+
+def test_render_hair_gpu_matches_cpu_oracle_path():
+    """render_hair() on the HIP rasterizer (mode A_sr) vs the same host code driving the CPU oracle: image, radii and
+    the gradients that reach the strand parameters.  Explicit pixel mask (`_pixel_mask`), then every element: image 1e-4,
+    gradient rows 1e-4."""
+    from tests import oracle_backend as ob
     dev = torch.device("cuda:0")
-    g = torch.Generator().manual_seed(3)
-    res = {}
-    for where in ("cpu", dev):
-        spec, head, hair, cam = _hair_scene(where)
-        w = torch.randn(7, spec.H, spec.W, generator=torch.Generator().manual_seed(3)).to(where)
-        bg = syn.background(where)
-        if where == "cpu":
-            with oracle_rasterizer():
-                pkg = render_hair(cam, head, hair, GENERIC, bg)
-                full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
-                (full * w).sum().backward()
-        else:
-            pkg = render_hair(cam, head, hair, GENERIC, bg)
-            full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
-            (full * w).sum().backward()
-        res[str(where)] = (full.detach().cpu().numpy(), pkg["radii"].cpu().numpy(),
-                           {n: getattr(hair, n).grad.detach().cpu().numpy() for n in
-                            ("_dirs", "_features_dc", "_features_rest", "_orient_conf")})
-    (img_c, rad_c, g_c), (img_g, rad_g, g_g) = res["cpu"], res[str(dev)]
-    assert (rad_c != rad_g).mean() < 1e-3
-    err = np.abs(img_c[:6] - img_g[:6]) / np.maximum(1.0, np.abs(img_c[:6]))
-    assert np.quantile(err, 0.999) < 1e-4
+    spec, pc0, _, _ = _hair_pass("cpu", GENERIC, None)
+    st = ob.LAST["state"]
+    with torch.no_grad():
+        _, pg0, _, _ = _hair_pass(dev, GENERIC, None)
+    w, mask = _hair_weights(spec, pc0, st, [pg0["radii"].cpu().numpy()])
+    _, pc, img_c, g_c = _hair_pass("cpu", GENERIC, w)
+    _, pg, img_g, g_g = _hair_pass(dev, GENERIC, w)
+    ok = ~mask
+    assert (np.abs(img_g[:6] - img_c[:6])[:, ok] <= 1e-4 * np.maximum(1.0, np.abs(img_c[:6][:, ok]))).all()
     for k in g_c:
-        a, b = g_g[k].reshape(len(g_g[k]), -1), g_c[k].reshape(len(g_c[k]), -1)
-        assert np.isfinite(a).all()
-        scale = np.abs(b).max() + 1e-30
-        rows = np.abs(b).max(axis=1, keepdims=True)
-        e = np.abs(a - b) / (rows + 1e-3 * scale)
-        assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())
+        _assert_rows_close(k, g_g[k], g_c[k])
 
 
 def test_densification_with_fused_adam_matches_torch_adam_surgery():
@@ -357,40 +429,32 @@ def test_speculative_stage2_capacity_guess_never_changes_the_result(pipe):
 def test_fused_render_hair_matches_generic_path():
     """Strand stage: the segmented fused projection behind render_hair() (explicit mode of k_project / k_project_bwd,
     head + strands as two segments of one rasterizer state) vs the generic PyTorch projection path: image, radii,
-    viewspace points and the gradients that reach the strand parameters through initialize_gaussians_hair()."""
-    from gaussianhaircut_amd.gaussian_renderer import render_hair
-    from tests.test_api_cpu import _hair_scene
+    viewspace points and the gradients that reach the strand parameters through initialize_gaussians_hair().  Explicit
+    pixel mask from the oracle chain of the same scene, then every element."""
+    from tests import oracle_backend as ob
     dev = torch.device("cuda:0")
+    spec, pc0, _, _ = _hair_pass("cpu", GENERIC, None, init_gaussians=True)
+    st = ob.LAST["state"]
+    with torch.no_grad():
+        _, pf0, _, _ = _hair_pass(dev, FUSED, None, init_gaussians=True)
+        _, pg0, _, _ = _hair_pass(dev, GENERIC, None, init_gaussians=True)
+    w, mask = _hair_weights(spec, pc0, st, [pf0["radii"].cpu().numpy(), pg0["radii"].cpu().numpy()])
     res = {}
     for name, pipe in (("fused", FUSED), ("generic", GENERIC)):
-        spec, head, hair, cam = _hair_scene(dev)
-        # strand parameters are the leaves: rebuild the per-Gaussian tensors inside the graph like train_strands.py:102
-        hair.initialize_gaussians_hair()
-        w = torch.randn(7, spec.H, spec.W, generator=torch.Generator().manual_seed(3)).to(dev)
-        pkg = render_hair(cam, head, hair, pipe, syn.background(dev))
-        full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"], pkg["orient_angle"]], dim=0)
-        (full * w).sum().backward()
-        res[name] = (full.detach().cpu().numpy(), pkg["radii"].cpu().numpy(),
-                     pkg["viewspace_points"].detach().cpu().numpy(),
-                     {n: getattr(hair, n).grad.detach().cpu().numpy() for n in
-                      ("_dirs", "_features_dc", "_features_rest", "_orient_conf")},
+        _, pkg, img, g = _hair_pass(dev, pipe, w, init_gaussians=True)
+        res[name] = (img, pkg["radii"].cpu().numpy(), pkg["viewspace_points"].detach().cpu().numpy(), g,
                      pkg["viewspace_points"].grad.detach().cpu().numpy())
     (img_f, rad_f, vs_f, g_f, vg_f), (img_g, rad_g, vs_g, g_g, vg_g) = res["fused"], res["generic"]
-    assert rad_f.shape == rad_g.shape and (rad_f != rad_g).mean() < 1e-3
-    err = np.abs(img_f[:6] - img_g[:6]) / np.maximum(1.0, np.abs(img_g[:6]))
-    assert np.quantile(err, 0.999) < 1e-4
+    assert rad_f.shape == rad_g.shape
+    ok = ~mask
+    assert (np.abs(img_f[:6] - img_g[:6])[:, ok] <= 1e-4 * np.maximum(1.0, np.abs(img_g[:6][:, ok]))).all()
     assert np.abs(vs_f[:, :2] - vs_g[:, :2]).max() < 1e-5
     n_head = int((rad_f.shape[0] - g_f["_features_dc"].shape[0]))
     # densification signal of the strand rows (the head is frozen: its rows stay 0 on the fused path)
-    a, b = vg_f[n_head:, :2], vg_g[n_head:, :2]
-    assert np.abs(a - b).max() <= 2e-3 * np.abs(b).max() and np.abs(vg_f[:n_head]).max() == 0
+    assert np.abs(vg_f[:n_head]).max() == 0
+    _assert_rows_close("viewspace", vg_f[n_head:, :2], vg_g[n_head:, :2])
     for k in g_g:
-        a, b = g_f[k].reshape(len(g_f[k]), -1), g_g[k].reshape(len(g_g[k]), -1)
-        assert np.isfinite(a).all()
-        scale = np.abs(b).max() + 1e-30
-        rows = np.abs(b).max(axis=1, keepdims=True)
-        e = np.abs(a - b) / (rows + 1e-3 * scale)
-        assert np.quantile(e, 0.995) < 2e-3, (k, np.quantile(e, 0.995), e.max())
+        _assert_rows_close(k, g_f[k], g_g[k])
 
 
 def test_strand_training_step_learns_on_gpu():
