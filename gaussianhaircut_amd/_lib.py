@@ -109,7 +109,7 @@ class WsView(ctypes.Structure):
 
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
-           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_selftest_wave", "ghr_model_forward_stage1",
+           "ghr_forward_stage2", "ghr_backward", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
            "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range"]
@@ -137,6 +137,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
+    L.ghr_set_deterministic.argtypes = [i32]
     L.ghr_selftest_wave.argtypes = [vp, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
     L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]

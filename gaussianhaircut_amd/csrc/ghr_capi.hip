@@ -34,6 +34,8 @@ hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, b
 //   0 = cell-group form (k_render_bwd): lane = pixel, 16-lane butterflies; 0.238 ms; also the fallback where the
 //       cell-list form's 32-bit offsets do not reach (b3_fits);
 //   1 = scan form with the tile pipeline (k_render_bwd_scan): 0.26-0.28 ms.
+int g_deterministic = 0;  // ghr_set_deterministic
+
 int k8_variant()
 {
     static int v = -1;
@@ -51,11 +53,12 @@ void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uin
 {
     const dim3 grid(ghr::xcd_grid(T)), block(GHR_BLOCK);
     int v = k8_variant();
+    if (g_deterministic) v = 2;  // the ordered walk exists in the cell-list form
     if (v == 2 && !ghr::b3_fits(rows, cap, (size_t)W, (size_t)H)) v = 0;  // its 32-bit offsets
     switch (v) {
     case 2:
         hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last);
+                           final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic);
         break;
     case 1:
         hipLaunchKernelGGL(ghr::k_render_bwd_scan, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
@@ -616,6 +619,13 @@ int ghr_selftest_wave(void* stream, const float* in, float* out)
     if (!in || !out) return fail(GHR_E_INVALID, "ghr_selftest_wave: NULL buffer");
     hipLaunchKernelGGL(ghr::k_wave_selftest, dim3(1), dim3(64), 0, (hipStream_t)stream, in, out);
     return finish((hipStream_t)stream, 1);
+}
+
+int ghr_set_deterministic(int32_t on)
+{
+    const int prev = g_deterministic;
+    g_deterministic = on != 0;
+    return prev;
 }
 
 int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop)

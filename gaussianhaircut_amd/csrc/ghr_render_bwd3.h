@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
                                                                 const rect4* __restrict__ rects, float* ginst,
                                                                 uint32_t cap,
                                                                 const unsigned long long* __restrict__ cell_mask,
-                                                                const uint32_t* __restrict__ cell_last)
+                                                                const uint32_t* __restrict__ cell_last, int ordered)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ B3Shared sh;
@@ -412,6 +412,9 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
     if (tid < 16) sh.clast[tid] = cell_last[16u * tile + tid];
     if (tid == 0) sh.next = 0u;
     __syncthreads();  // orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
+    // ghr_set_deterministic: one wave draws all sixteen cells, in index order -- the additions into a line (issued by one
+    // wave to one address) then happen in program order
+    if (ordered && tid >= 64) return;
 
     if (small)
         b3_tile<true>(sh, W, H, tx, ty, tile, beg, n, point_list, rec, bg, final_T, n_contrib, dL_dpix, rects, ginst, cap,

@@ -259,6 +259,12 @@ int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float*
  * gradient-walk kernel (ghr_backward: k_render_bwd).  NULL disables a pair.  Sticky until changed. */
 int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, void* bwd_stop);
 
+/* Debug aid (ABI 12; SURVEY.md 5: the reference has none -- its backward sums with float atomics in scheduling
+ * order): on != 0 makes the gradient walk bit-reproducible from run to run.  One wave per tile then works the tile's
+ * sixteen cells in index order, so the additions into a gradient line happen in one fixed order (the per-Gaussian sum
+ * over lines is ordered anyway); about 3x the kernel time.  Process-wide, sticky; returns the previous setting. */
+int ghr_set_deterministic(int32_t on);
+
 /* Self test of the wave-level primitives the scan form of the gradient walk is built from (16-lane DPP row scans,
  * row broadcast, v_mfma_f32_16x16x4_f32 operand / result layout): in[8][64] floats -> out[12][64] floats (device
  * pointers); tests/test_gpu_wave_primitives.py states the expected values. */

@@ -310,3 +310,28 @@ def test_non_finite_feature_of_a_non_contributing_gaussian_does_not_leak(oracle_
         a, b = outs[1][1][k][keep], outs[0][1][k][keep]
         assert np.isfinite(a).all(), k
         assert np.allclose(a, b, rtol=1e-4, atol=1e-6 * np.abs(b).max()), k
+
+
+def test_deterministic_backward_is_bit_reproducible(oracle_mod, dev):
+    """ghr_set_deterministic (optional per-tile-ordered backward): with it the gradients of repeated
+    backward passes over the same state are bit-identical (cfg2-like blobs overlap heavily: many cells add into every
+    gradient line), and they are the same gradients (oracle tolerance)."""
+    from gaussianhaircut_amd import _lib
+    from tests.gpu_helpers import GpuRun, to_dev
+    spec = syn.CONFIGS["cfg1"]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "A")
+    run = GpuRun(to_dev(ri, dev), "A")
+    dL = syn.grad_image(spec, 7).numpy() * (spec.H * spec.W)
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "A")
+    L = _lib.lib()
+    assert L.ghr_set_deterministic(1) == 0
+    try:
+        runs = [run.backward(torch.from_numpy(dL)) for _ in range(4)]
+    finally:
+        assert L.ghr_set_deterministic(0) == 1
+    hp.assert_grads_close(runs[0], ref)
+    for other in runs[1:]:
+        for k in runs[0]:
+            assert np.array_equal(np.asarray(runs[0][k]).view(np.uint32), np.asarray(other[k]).view(np.uint32)), k
