@@ -151,9 +151,9 @@ def main():
         loss.backward()
     L.ghr_set_profile_events(None, None, None, None)
     torch.cuda.synchronize()
-    model.optimizer.flat_grad.zero_()
-    model.optimizer.state_dev[1:2].zero_()
     model.optimizer._direct_backwards = 0
+    model.optimizer.zero()
+    model.optimizer.state_dev[1:2].zero_()
     torch.cuda.synchronize()
     replicas_identical = None
     if world > 1:

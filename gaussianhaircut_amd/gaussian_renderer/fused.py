@@ -109,6 +109,10 @@ class _RenderModelFused(torch.autograd.Function):
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+            # the step's first gradients into a buffer that is known to hold zeros are assigned, not added (optim.py)
+            acc = 1
+            if P > 0 and direct and sink.take_known_zero():
+                acc = 0
             if P > 0 and direct and sink.concurrent:
                 # this view shares the GPU with its neighbours (trainer.training_step): only the kernel that adds into
                 # the shared gradient buffer is ordered after the previous view's
@@ -119,13 +123,13 @@ class _RenderModelFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
                                                         _ptr(d_op), _ptr(d_label), _ptr(d_conf), _ptr(d_fdc),
-                                                        _ptr(d_frest), None, 1, sink.nan_flag_ptr(), rows))
+                                                        _ptr(d_frest), None, acc, sink.nan_flag_ptr(), rows))
                 sink.accumulate_end(stream)
             elif P > 0:
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
-                                                _ptr(d_fdc), _ptr(d_frest), int(direct),
+                                                _ptr(d_fdc), _ptr(d_frest), acc if direct else 0,
                                                 sink.nan_flag_ptr() if direct else None))
         if direct:
             sink.note_direct_backward()

@@ -65,6 +65,20 @@ class FusedAdam:
             ends.append(off)
         self._ends = (ctypes.c_int64 * len(ends))(*ends)
         self.params = params
+        self._mark_zero()
+
+    # ---- "the gradient buffer is all zero" as a checked fact.  The first direct backward of a step may then ASSIGN
+    # instead of accumulate (k_project_bwd skips reading 244 B of zeros per Gaussian).  The library's own kernels are
+    # tracked here; anything PyTorch does to the buffer or to a parameter's .grad view in place (autograd accumulation of
+    # another loss, zero_(), an all-reduce) bumps the tensor's version counter, which withdraws the fact.
+    def _mark_zero(self):
+        self._zero_version = self.flat_grad._version
+
+    def take_known_zero(self) -> bool:
+        ok = (self._zero_version is not None and self.flat_grad._version == self._zero_version and
+              self._direct_backwards == 0)
+        self._zero_version = None
+        return ok
 
     # ---- gradient-bucket interface (same as parallel.FlatGradBucket)
     @property
@@ -73,9 +87,11 @@ class FusedAdam:
 
     def zero(self):
         self.flat_grad.zero_()
+        self._mark_zero()
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()  # grads alias the flat buffer: never dropped
+        self._mark_zero()
 
     def all_reduce(self, average_over=None, async_op=False):
         work = None
@@ -125,6 +141,7 @@ class FusedAdam:
         self.flat_param, self.exp_avg, self.exp_avg_sq = flat_p, flat_m, flat_v
         self._ends = (ctypes.c_int64 * len(ends))(*ends)
         self.params = params
+        self._mark_zero()
         self._direct_backwards = 0
         self._skip_next = (1 << len(self.param_groups)) - 1  # every parameter is new: the coming step is a no-op
         return out
@@ -176,6 +193,7 @@ class FusedAdam:
 
     def note_direct_backward(self):
         self._direct_backwards += 1
+        self._zero_version = None
         self._skip_next = 0  # fresh gradients for the (new) parameters: they take part in the coming step
 
     # ---- views of one step on several HIP streams (trainer.training_step): the direct backward ACCUMULATES into the
@@ -206,6 +224,10 @@ class FusedAdam:
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
                                                 self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), skip))
+        if zero_grad:
+            self._mark_zero()  # (the kernel zeroes the gradients whether or not the guard lets the update through)
+        else:
+            self._zero_version = None
 
     def _chunk_ranges(self, chunks: int):
         n = self.flat_param.numel()
@@ -283,6 +305,10 @@ class FusedAdam:
                     _stream(), n, a, b - a, _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
                     _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
                     self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(plan) - 1), skip))
+        if zero_grad:
+            self._mark_zero()  # every range of the plan has been through the kernel, which zeroes its gradients
+        else:
+            self._zero_version = None
 
     def _param_ranges(self):
         off = 0

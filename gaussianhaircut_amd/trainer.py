@@ -170,9 +170,9 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     if any(overflow):
         # a guessed capacity was too small: that view's image, loss and gradients are garbage (memory-safe garbage).
         # Drop everything this step accumulated and redo it with blocking, exactly sized forwards.
-        sink.flat_grad.zero_()
-        sink.state_dev[1:2].zero_()
         sink._direct_backwards = 0
+        sink.zero()
+        sink.state_dev[1:2].zero_()
         sink._acc_event = None
         losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, pipe, 0, sink)
     if not losses:  # a rank without views in this step still takes part in the collectives and the update

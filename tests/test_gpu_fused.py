@@ -486,3 +486,41 @@ def test_strand_training_step_learns_on_gpu():
         losses = [float(strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=FUSED)) for i in range(10)]
         assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
         assert (hair._dirs.detach() - d0).abs().max() > 0
+
+
+def test_first_direct_backward_assigns_only_into_a_buffer_known_to_be_zero():
+    """FusedAdam.take_known_zero: the step's first direct backward may assign instead of accumulate (k_project_bwd then
+    skips reading the zeros) -- but only while the gradient buffer is KNOWN to be zero; anything PyTorch wrote into a
+    .grad view in the meantime (another loss, here an in-place add) must survive."""
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    cam, bg = syn.make_view(spec, dev), syn.background(dev)
+    w = torch.randn(6, spec.H, spec.W, generator=torch.Generator().manual_seed(2)).to(dev)
+    model = syn.make_model(spec, dev)
+    model.training_setup(OptimizationParams())
+    opt = model.optimizer
+
+    def backward():
+        pkg = render(cam, model, FUSED, bg)
+        (torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0) * w).sum().backward()
+        torch.cuda.synchronize()
+        return opt.flat_grad.detach().clone()
+
+    assert opt._zero_version is not None          # fresh optimizer: zeros
+    g0 = backward()                               # assigned
+    assert opt._zero_version is None and opt._direct_backwards == 1
+    g1 = backward()                               # accumulated on top
+    assert torch.allclose(g1, 2 * g0, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+    opt._direct_backwards = 0
+    opt.zero()
+    model._xyz.grad.add_(1.0)                     # somebody else's gradient, through PyTorch
+    g2 = backward()
+    expect = g0.clone()
+    n_xyz = model._xyz.numel()
+    expect[:n_xyz] += 1.0                         # xyz is the first group of the flat buffer
+    assert torch.allclose(g2, expect, rtol=1e-5, atol=1e-6 * float(g0.abs().max()))
+    # and a step leaves the buffer known-zero again; the next backward reproduces g0 (parameters moved: only its shape)
+    opt._direct_backwards = 1
+    opt.step(zero_grad=True, nan_scan=True)
+    assert opt._zero_version is not None and float(opt.flat_grad.abs().sum()) == 0.0
