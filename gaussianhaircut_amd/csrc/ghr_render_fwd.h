@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
     const uint32_t beg = min(tile_start[tile], cap), end = min(tile_start[tile + 1], cap);  // cap: ghr_forward_stage2
     const uint32_t n = end - beg;
 
+    GHR_PROF_DECL;
     PixFwd st;
     st.T = 1.0f;
     st.last = 0;
@@ -107,11 +108,14 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
 
     for (uint32_t base = 0; base < n; base += GHR_BLOCK) {
         // forward.cu:335-337: stop when the whole tile is done.  The barrier also protects the LDS planes.
+        GHR_PROF(0);
         if (__syncthreads_count(done) == GHR_BLOCK) break;
+        GHR_PROF(1);
         s_r0[tid] = g0; s_r1[tid] = g1; s_r2[tid] = g2; s_r3[tid] = g3;
         s_bb[tid] = alpha_bbox(g0, g1);
         s_ep[tid] = ellipse_params(g0, g1);
         __syncthreads();
+        GHR_PROF(2);
         if (base + GHR_BLOCK < n) GHR_GATHER(base + GHR_BLOCK);
 
         const uint32_t cnt = min((uint32_t)GHR_BLOCK, n - base);
@@ -121,6 +125,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             const uint32_t e = sub + lane;
             const uint32_t ec = e < cnt ? e : 0;
             unsigned long long todo = cell_masks(s_bb[ec], s_ep[ec], s_r0[ec], e < cnt, wx0, cy0, grp);
+            GHR_PROF(3);
             // word (base + sub) / 64 of this cell: every position a pixel of the cell can count in n_contrib lies in a
             // word written here (a cell that is finished, or a tile that stops early, has all its n_contrib behind it)
 #ifndef GHR_K7_NOMASK
@@ -135,6 +140,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                 todo &= todo - 1;
                 done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
             }
+            GHR_PROF(4);
         }
     }
 
@@ -158,6 +164,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
 #pragma unroll
         for (int c = 0; c < GHR_C; c++) out_color[c * plane + pix] = st.C[c] + st.T * bg[c];
     }
+    GHR_PROF(5);
+#ifdef GHR_K7_PROF
+    GHR_PROF_END(6);
+#endif
 #endif
 }
 

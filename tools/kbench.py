@@ -43,7 +43,20 @@ def main():
             tf.append(ev[0].elapsed_time(ev[1]))
             tb.append(ev[2].elapsed_time(ev[3]))
     L.ghr_set_profile_events(None, None, None, None)
-    if hasattr(L, "ghr_debug_prof"):  # -DGHR_K8_PROF build: cycles per phase of the instrumented K8, per wave
+    if hasattr(L, "ghr_debug_prof") and os.environ.get("GHR_PROF_K7"):  # -DGHR_K8_PROF -DGHR_K7_PROF build: phases of K7
+        import numpy as np
+        buf = np.zeros((65536, 8), np.uint64)
+        L.ghr_debug_prof(None, 0, 1)
+        run = GpuRun(ri, "A", debug=False)
+        torch.cuda.synchronize()
+        L.ghr_debug_prof(ctypes.c_void_p(buf.ctypes.data), 65536, 0)
+        v = buf.astype(np.float64)
+        used = v[:, 6] > 0
+        tot = v[used].sum(axis=0)
+        names = os.environ.get("GHR_PROF_NAMES", "p0,p1,p2,p3,p4,p5").split(",")
+        print("PROFK7 " + "  ".join("%s=%.1f%%" % (nm, 100 * tot[i] / tot[6]) for i, nm in enumerate(names)),
+              " waves=%d cycles_per_wave mean %.0f" % (used.sum(), v[used, 6].mean()))
+    elif hasattr(L, "ghr_debug_prof"):  # -DGHR_K8_PROF build: cycles per phase of the instrumented K8, per wave
         import numpy as np
         n_slots = 65536
         buf = np.zeros((n_slots, 8), np.uint64)
