@@ -18,6 +18,10 @@ namespace ghr {
 
 #define GHR_SCAN_BLOCK 1024
 #define GHR_SORT_CAP 2048  // keys sorted in LDS (16 KiB); longer lists use the in-place global path
+#define GHR_SORT_BIG_CAP 8192   // keys per LDS block of k_tile_sort_big (64 KiB)
+#define GHR_SORT_BIG_BLOCK 1024
+#define GHR_SORT_BIG_MIN_AVG 256  // k_tile_sort_big is launched when the lists average at least this many instances
+#define GHR_SORT_DONE 0xffffffffu  // tile_cursor value k_tile_sort_big leaves for k_tile_sort: "this tile is sorted"
 #define GHR_SORT_BLOCK 256  // the sort is latency-bound (about one compare-exchange per thread and step at typical
                             // list lengths): 16 KiB of LDS instead of 32 keeps 8 tiles in flight per CU (measured 72 -> 49 us;
                             // 128-thread workgroups: 56 us)
@@ -201,8 +205,10 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     const int tid = threadIdx.x;
     // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may
     // be replayed, e.g. after a too small speculative capacity)
+    const bool sorted_already = tile_cursor[tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
+    __syncthreads();
     if (tid == 0) tile_cursor[tile] = 0u;
-    if (n == 0) return;
+    if (n == 0 || sorted_already) return;
     uint64_t* g = keys + s;
     if (n <= GHR_SORT_CAP) {
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) s_keys[i] = g[i];
@@ -220,6 +226,97 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
         bitonic_any_n<false>(g, n, tid, GHR_SORT_BLOCK);
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) point_list[s + i] = (uint32_t)g[i];
     }
+}
+
+// Dense tiles (more than GHR_SORT_CAP instances; profiles/r02c: at the reference's strand-stage size the in-place global
+// network of k_tile_sort set the kernel's duration, 0.74 ms).  A few 1024-thread workgroups walk the tiles; a dense one is
+// sorted by the SAME network in blocks of GHR_SORT_BIG_CAP keys: everything of the network that stays inside an aligned
+// block runs in LDS (one load / store of the block per pass), only the steps whose partner distance reaches across
+// blocks touch global memory -- none up to 8192 keys, 1 of 105 steps at 16 384, 6 of 136 at 65 536.  The tile is then
+// marked (tile_cursor = GHR_SORT_DONE) and k_tile_sort, which runs afterwards over all tiles, passes it by.  Launched
+// only for dense scenes (host heuristic: average list length); a dense tile it does not see is still sorted by
+// k_tile_sort's global path -- same network, same result.
+template <typename KeyPtr>
+GHR_HD void bitonic_disperse_from(KeyPtr k, uint32_t n, uint32_t count, uint32_t j0, int tid, int nthreads)
+{
+    // the disperse steps j0, j0/2, .. 1 of the network over `count` (a power of two) slots of which the first n hold keys
+    for (uint32_t j = j0; j >= 1; j >>= 1) {
+        for (uint32_t i = tid; i < (count >> 1); i += nthreads) {
+            const uint32_t l = 2 * j * (i / j) + (i % j), u = l + j;
+            if (u < n) {
+                const uint64_t a = k[l], b = k[u];
+                if (b < a) { k[l] = b; k[u] = a; }
+            }
+        }
+        if (j <= 32) GHR_SYNC_WAVE(); else GHR_SYNC();
+    }
+    GHR_SYNC();
+}
+
+__global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T, const uint32_t* __restrict__ tile_start,
+                                                                   uint64_t* keys, uint32_t* point_list, uint32_t cap,
+                                                                   uint32_t* tile_cursor)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint64_t s_keys[GHR_SORT_BIG_CAP];
+    const int tid = threadIdx.x;
+    constexpr uint32_t B = GHR_SORT_BIG_CAP;
+    for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+        const uint32_t s = min(tile_start[tile], cap);
+        const uint32_t n = min(tile_start[tile + 1], cap) - s;
+        if (n <= GHR_SORT_CAP) continue;  // workgroup-uniform
+        uint64_t* g = keys + s;
+        const uint32_t nb = (n + B - 1) / B;
+        // every block on its own: the network's steps up to size B
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t cnt = min(B, n - b * B);
+            __syncthreads();
+            for (uint32_t i = tid; i < cnt; i += GHR_SORT_BIG_BLOCK) s_keys[i] = g[b * B + i];
+            __syncthreads();
+            bitonic_any_n<true>(s_keys, cnt, tid, GHR_SORT_BIG_BLOCK);
+            for (uint32_t i = tid; i < cnt; i += GHR_SORT_BIG_BLOCK) g[b * B + i] = s_keys[i];
+        }
+        if (nb > 1) {
+            uint32_t np2 = 1;
+            while (np2 < n) np2 <<= 1;
+            const uint32_t half = np2 >> 1;
+            for (uint32_t size = 2 * B; size <= np2; size <<= 1) {
+                const uint32_t hs = size >> 1;
+                __syncthreads();  // (one workgroup, one CU: the barrier orders its global accesses, as in k_tile_sort)
+                for (uint32_t i = tid; i < half; i += GHR_SORT_BIG_BLOCK) {  // flip, across blocks
+                    const uint32_t blk = i / hs, off = i - blk * hs;
+                    const uint32_t l = blk * size + off, u = blk * size + (size - 1 - off);
+                    if (u < n) {
+                        const uint64_t a = g[l], bb = g[u];
+                        if (bb < a) { g[l] = bb; g[u] = a; }
+                    }
+                }
+                __syncthreads();
+                for (uint32_t j = hs >> 1; j >= B; j >>= 1) {  // disperse steps that still reach across blocks
+                    for (uint32_t i = tid; i < half; i += GHR_SORT_BIG_BLOCK) {
+                        const uint32_t l = 2 * j * (i / j) + (i % j), u = l + j;
+                        if (u < n) {
+                            const uint64_t a = g[l], bb = g[u];
+                            if (bb < a) { g[l] = bb; g[u] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+                for (uint32_t b = 0; b < nb; b++) {  // the rest of this size's disperse steps: inside the blocks
+                    const uint32_t cnt = min(B, n - b * B);
+                    for (uint32_t i = tid; i < cnt; i += GHR_SORT_BIG_BLOCK) s_keys[i] = g[b * B + i];
+                    __syncthreads();
+                    bitonic_disperse_from(s_keys, cnt, B, B >> 1, tid, GHR_SORT_BIG_BLOCK);
+                    for (uint32_t i = tid; i < cnt; i += GHR_SORT_BIG_BLOCK) g[b * B + i] = s_keys[i];
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BIG_BLOCK) point_list[s + i] = (uint32_t)g[i];
+        if (tid == 0) tile_cursor[tile] = GHR_SORT_DONE;
+    }
+#endif
 }
 
 }  // namespace ghr

@@ -272,6 +272,12 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, b.keys, R);
+        // dense scenes (long lists on average) first get their dense tiles sorted in big LDS blocks; the regular kernel
+        // then passes those by.  R is the capacity here, an upper bound of the count: a guess that is too high only
+        // costs an idle 3-us launch.
+        if ((size_t)R >= (size_t)GHR_SORT_BIG_MIN_AVG * (size_t)T)
+            hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
+                               im.tile_start, b.keys, b.point_list, R, im.tile_count);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
                            im.tile_start, b.keys, b.point_list, R, im.tile_count);
     }

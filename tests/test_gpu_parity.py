@@ -199,18 +199,19 @@ def test_edge_borders_huge_and_ragged_image(oracle_mod, dev):
     assert run.R > 0
 
 
-def test_edge_depth_ties_and_long_tile_list(oracle_mod, dev):
-    """> 4096 instances in ONE tile (LDS sort capacity) with many exactly equal depths: exercises the in-place
-    global sort path and the tie-break by ascending Gaussian index."""
-    P = 5000
+@pytest.mark.parametrize("P", [5000, 20000, 40000])
+def test_edge_depth_ties_and_long_tile_list(oracle_mod, dev, P):
+    """> 4096 instances in ONE tile (LDS sort capacity) with many exactly equal depths: exercises the dense-tile sort
+    (k_tile_sort_big: one LDS block at 5000, three / five blocks with global flip and disperse steps at 20000 / 40000)
+    and the tie-break by ascending Gaussian index; also the > 1024-instance path of the backward render kernel."""
     g = torch.Generator().manual_seed(3)
     xyz = torch.zeros(P, 3)
     xyz[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 0.05
     xyz[:, 2] = torch.randint(0, 7, (P,), generator=g).float() * 0.01  # 7 distinct depths => massive ties
-    ri = _manual_inputs(dev, xyz, torch.full((P, 3), 0.004), torch.full((P,), 0.02), W=64, H=64)
+    ri = _manual_inputs(dev, xyz, torch.full((P, 3), 0.004), torch.full((P,), 0.02 * 5000 / P), W=64, H=64)
     run, st = _run_manual(oracle_mod, dev, ri)
     counts = np.diff(run.inspect()["tile_start"].astype(np.int64))
-    assert counts.max() > 4096
+    assert counts.max() > 4096 * (P // 5000)
 
 
 def test_analytic_single_gaussian(dev):

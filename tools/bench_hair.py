@@ -6,7 +6,8 @@ from types import SimpleNamespace
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussianhaircut_amd.gaussian_renderer import render_hair  # noqa: E402
 from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands  # noqa: E402
 from gaussianhaircut_amd.utils import synthetic as syn  # noqa: E402

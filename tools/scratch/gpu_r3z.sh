@@ -1,0 +1,16 @@
+#!/bin/bash
+O=gpurun_out/r3z; mkdir -p $O; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+R=$GRAFT_REPO_ROOT
+( timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu --timeout 800 -k "long_tile or cfg2 or cfg3 or tiny" ) > $O/pytest.log 2>&1; echo "rc=$?" >> $O/pytest.log
+grep -n "AssertionError\|Error\|passed\|failed\|^FAILED\|^E  " $O/pytest.log | head -20
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/sc2 -- python $R/tools/sort_cliff.py ) > $O/cliff.log 2>&1
+python tools/sort_cliff.py --parse /tmp/sc2
+( timeout 300 python tools/bench_hair.py 30000 100000 ) 2>&1 | grep "HAIR fused"
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/hair_kt -o kt -- python $R/tools/bench_hair.py 30000 100000 ) > $O/kt.log 2>&1
+python - <<PY
+import csv, glob
+for f in glob.glob('/tmp/hair_kt/**/*kernel_stats.csv', recursive=True):
+    rows = sorted(csv.DictReader(open(f)), key=lambda r: -float(r.get('TotalDurationNs', 0) or 0))
+    for r in [x for x in rows if 'ghr::' in x['Name']][:12]:
+        print('KT %-60s calls %5s avg %9.1f us' % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3))
+PY

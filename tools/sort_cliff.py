@@ -23,14 +23,15 @@ def parse(d):
     for r in rows:
         name = r["Kernel_Name"].split("(")[0].split("::")[-1]
         per.setdefault(name, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    print("%8s %14s %14s %14s   (us, min of %d)" % ("N", "k_tile_sort", "k_render_fwd", "k_render_bwd", REPS))
+    print("%8s %16s %14s %14s %14s   (us, min of %d)" % ("N", "k_tile_sort_big", "k_tile_sort", "k_render_fwd",
+                                                          "k_render_bwd", REPS))
     for i, n in enumerate(NS):
         vals = []
-        for k in ("k_tile_sort", "k_render_fwd", "k_render_bwd"):
-            key = [x for x in per if x.startswith(k)]
+        for k in ("k_tile_sort_big", "k_tile_sort", "k_render_fwd", "k_render_bwd"):
+            key = [x for x in per if x == k or (k.startswith("k_render") and x.startswith(k))]
             v = sum((per[x] for x in key), [])
             vals.append(min(v[i * REPS:(i + 1) * REPS]) if len(v) >= (i + 1) * REPS else float("nan"))
-        print("%8d %14.1f %14.1f %14.1f" % (n, *vals))
+        print("%8d %16.1f %14.1f %14.1f %14.1f" % (n, *vals))
 
 
 def main():
