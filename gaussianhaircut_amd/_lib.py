@@ -152,7 +152,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6
-    L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32]
+    L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

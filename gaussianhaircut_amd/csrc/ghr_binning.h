@@ -193,9 +193,20 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
     GHR_SYNC();
 }
 
+// Both sort kernels also write, for every instance, where its gradient line will be: inst_line[instance] = position in
+// the sorted lists (instances are numbered by rect4_slot; the lines lie in list order, ghr_device.h gather_inst_grads).
+GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* rects, uint32_t pos, uint32_t id, int tx,
+                      int ty, uint32_t cap)
+{
+    point_list[pos] = id;
+    const uint32_t inst = rect4_slot(rects[id], tx, ty);
+    if (inst < cap) inst_line[inst] = pos;
+}
+
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
-                                                         uint32_t* tile_cursor)
+                                                         uint32_t* tile_cursor, const rect4* __restrict__ rects,
+                                                         uint32_t* inst_line, int gx)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
     const uint32_t tile = xcd_tile(blockIdx.x, T);
@@ -217,14 +228,15 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) {
             const uint64_t k = s_keys[i];
             g[i] = k;
-            point_list[s + i] = (uint32_t)k;
+            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)k, tile % gx, tile / gx, cap);
         }
     } else {
         // Rare: a single tile with more instances than fit in LDS.  Same network, in place in global memory
         // (one workgroup => same CU/L1, __syncthreads orders the accesses).
         __syncthreads();
         bitonic_any_n<false>(g, n, tid, GHR_SORT_BLOCK);
-        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) point_list[s + i] = (uint32_t)g[i];
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK)
+            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], tile % gx, tile / gx, cap);
     }
 }
 
@@ -255,7 +267,8 @@ GHR_HD void bitonic_disperse_from(KeyPtr k, uint32_t n, uint32_t count, uint32_t
 
 __global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                                    uint64_t* keys, uint32_t* point_list, uint32_t cap,
-                                                                   uint32_t* tile_cursor)
+                                                                   uint32_t* tile_cursor, const rect4* __restrict__ rects,
+                                                                   uint32_t* inst_line, int gx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint64_t s_keys[GHR_SORT_BIG_CAP];
@@ -313,7 +326,8 @@ __global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T
             }
         }
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += GHR_SORT_BIG_BLOCK) point_list[s + i] = (uint32_t)g[i];
+        for (uint32_t i = tid; i < n; i += GHR_SORT_BIG_BLOCK)
+            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], (int)(tile % (uint32_t)gx), (int)(tile / (uint32_t)gx), cap);
         if (tid == 0) tile_cursor[tile] = GHR_SORT_DONE;
     }
 #endif

@@ -117,6 +117,7 @@ struct Bin {
     uint64_t* keys;
     uint32_t* point_list;
     unsigned long long* cell_mask;  // [mask_groups(R, T)][16]
+    uint32_t* inst_line;            // [R]: gradient line (= list position) of every instance (numbered by rect4_slot)
 };
 
 size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
@@ -151,7 +152,8 @@ size_t carve_bin(char* base, size_t R, size_t T, Bin* b)
     uint64_t* keys = (uint64_t*)take(R * 8);
     uint32_t* pl = (uint32_t*)take(R * 4);
     unsigned long long* cm = (unsigned long long*)take(ghr::mask_groups(R, T) * 16 * 8);
-    if (b) *b = Bin{keys, pl, cm};
+    uint32_t* il = (uint32_t*)take(R * 4);
+    if (b) *b = Bin{keys, pl, cm, il};
     return off + ALIGN;
 }
 inline char* align_base(const void* p) { return (char*)(((uintptr_t)p + ALIGN - 1) / ALIGN * ALIGN); }
@@ -277,9 +279,9 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // costs an idle 3-us launch.
         if ((size_t)R >= (size_t)GHR_SORT_BIG_MIN_AVG * (size_t)T)
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
-                               im.tile_start, b.keys, b.point_list, R, im.tile_count);
+                               im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
-                           im.tile_start, b.keys, b.point_list, R, im.tile_count);
+                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
@@ -326,7 +328,8 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.ginst = grad_scratch; ga.rects = g.rects; ga.rec = g.rec; ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
+    ga.ginst = grad_scratch; ga.inst_line = b.inst_line; ga.ginst_rows = R;
+    ga.rects = g.rects; ga.rec = g.rec; ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
@@ -452,11 +455,13 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
                                const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
                                float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
-                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows)
+                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows, const void* bin_ws,
+                               uint32_t R)
 {
     ghr::ModelArgs a;
     if (int rc = fill_model(m, &a)) return rc;
     if (rows_total < 0 || (long long)a.row0 + a.P > rows_total) return fail(GHR_E_INVALID, "segment exceeds rows_total");
+    if (!bin_ws && R > 0) return fail(GHR_E_INVALID, "ghr_model_backward_segment: bin_ws is NULL");
     hipStream_t s = (hipStream_t)stream;
     if (a.P == 0) return GHR_OK;
     const bool need_act = a.mode == 0;
@@ -468,8 +473,11 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     a.radii = const_cast<int*>(radii);
     a.rects = g.rects;
     a.rec = g.rec;  // the gather unpacks the gradient lines with the pixel mean / conic / opacity k_project stored
+    Bin b;
+    carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)a.gx * a.gy, &b);
     ghr::ModelGrads mg;
-    mg.ginst = grad_scratch; mg.ginst_rows = grad_rows ? grad_rows : 0xffffffffu; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
+    mg.inst_line = b.inst_line;
+    mg.ginst = grad_scratch; mg.ginst_rows = grad_rows ? (grad_rows < R ? grad_rows : R) : R; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
@@ -494,7 +502,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
         return rc;
     return ghr_model_backward_segment(stream, m, m->P, radii, geom_ws, grad_scratch, d_means2D, d_xyz, d_log_scales,
                                       d_rotations, d_opacity_logit, d_label_logit, d_orient_conf_log, d_features_dc,
-                                      d_features_rest, nullptr, accumulate, nan_flag, R);
+                                      d_features_rest, nullptr, accumulate, nan_flag, R, bin_ws, R);
 }
 
 namespace ghr {

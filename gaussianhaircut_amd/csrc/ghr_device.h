@@ -143,12 +143,16 @@ GHR_HD void line_acc_finish(const LineAcc& A, const f4& r0, const f4& r1, float 
 // gradient terms.  r0 / r1: the first two 16-B pieces of the Gaussian's render record (pixel mean, conic, opacity).
 // `rows`: number of lines `ginst` holds.  A Gaussian whose lines would reach past it (only possible when the forward ran
 // with a capacity below the true instance count, whose results the caller discards) reads nothing.
-GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, const f4& r0, const f4& r1, float half_w, float half_h,
-                              float* ga, uint32_t rows = 0xffffffffu)
+GHR_HD void gather_inst_grads(const float* ginst, const uint32_t* inst_line, const rect4& r, const f4& r0, const f4& r1,
+                              float half_w, float half_h, float* ga, uint32_t rows = 0xffffffffu)
 {
     uint32_t cnt = rect4_area(r);
     if ((uint64_t)r.z + r.w + cnt > (uint64_t)rows) cnt = 0;
-    const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * ((size_t)r.z + r.w);
+    // the Gaussian's instances are numbered r.z + r.w + ordinal(tile in its rect) (rect4_slot); their gradient lines lie
+    // in TILE-LIST order (line of an instance = its position in the sorted lists, where K8 finds it without a lookup):
+    // inst_line[instance] is that position, written by the tile sort
+    const uint32_t* il = inst_line + ((size_t)r.z + r.w);
+    const f4* lines = reinterpret_cast<const f4*>(ginst);
     const uint32_t x0 = r.x & 0xffffu, wdt = (r.x >> 16) - x0, y0 = r.y & 0xffffu;
     LineAcc A;
     line_acc_init(A);
@@ -157,13 +161,20 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, const f4& r0, 
     // order (ascending ordinal) is unchanged.
     const f4 z = {0.f, 0.f, 0.f, 0.f};
     uint32_t tx = 0, ty = 0;  // position of the instance's tile inside the rect
-    for (uint32_t k = 0; k < cnt; k += 4, p += 16) {
+    for (uint32_t k = 0; k < cnt; k += 4) {
+        uint32_t ln[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t v_ = k + j < cnt ? il[k + j] : 0u;
+            ln[j] = v_ < rows ? v_ : 0u;  // (a stale entry after a too small capacity: memory-safe, the result is discarded)
+        }
         f4 v[16];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const bool in = k + j < cnt;
+            const f4* p = lines + 4 * (size_t)ln[j];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[4 * j + q] = in ? p[4 * j + q] : z;
+            for (int q = 0; q < 4; q++) v[4 * j + q] = in ? p[q] : z;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -186,15 +197,16 @@ GHR_HD void gather_inst_grads(const float* ginst, const rect4& r, const f4& r0, 
 // Sum of the instance gradient lines for every lane's Gaussian.  Small rects: per lane (gather_inst_grads, ascending
 // ordinal).  Big rects: one at a time by the whole wave -- lane l sums the lines l, l+64, ... (coalesced), then a
 // butterfly over the 64 lanes; the order differs from the sequential one but is fixed.  All lanes of the wave call it.
-__device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const rect4& r, const f4& r0, const f4& r1,
-                                                       float half_w, float half_h, float* ga, uint32_t rows)
+__device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const uint32_t* inst_line, const rect4& r,
+                                                       const f4& r0, const f4& r1, float half_w, float half_h, float* ga,
+                                                       uint32_t rows)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t cnt = rect4_area(r);
     const bool big = cnt > GHR_BIG_GATHER;
     rect4 small = r;
     if (big) { small.x = 0u; small.y = 0u; }  // empty rect: nothing to read
-    gather_inst_grads(ginst, small, r0, r1, half_w, half_h, ga, rows);
+    gather_inst_grads(ginst, inst_line, small, r0, r1, half_w, half_h, ga, rows);
     unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
     while (todo) {  // wave-uniform
         const int src = __builtin_ctzll(todo);
@@ -205,11 +217,11 @@ __device__ __forceinline__ void gather_inst_grads_wave(const float* ginst, const
         const uint32_t rx = (uint32_t)__shfl((int)r.x, src), ry = (uint32_t)__shfl((int)r.y, src);
         const float mx = __shfl(r0.x, src), my = __shfl(r0.y, src);
         const uint32_t x0 = rx & 0xffffu, wdt = (rx >> 16) - x0, y0 = ry & 0xffffu;
-        const f4* p = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)first;
         LineAcc A;
         line_acc_init(A);
         for (uint32_t k = lane; k < n; k += 64) {
-            const f4* q = p + 4 * (size_t)k;
+            const uint32_t ln = inst_line[(size_t)first + k];
+            const f4* q = reinterpret_cast<const f4*>(ginst) + 4 * (size_t)(ln < rows ? ln : 0u);
             line_acc_add(A, q[0], q[1], q[2], q[3], mx, my, x0 + k % wdt, y0 + k / wdt);
         }
         float v[16] = {A.s0, A.s1, A.sxx, A.sxy, A.syy, A.s5, A.c0.z, A.c0.w, A.c1.x, A.c1.y, A.c1.z, A.c1.w,

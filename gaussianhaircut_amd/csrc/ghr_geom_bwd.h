@@ -21,7 +21,9 @@ struct GeomBwdArgs {
     const float* view;
     const float* proj;
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y;
-    const float* ginst;  // [R][16] per-instance gradient lines (slots: rect4_slot; format: ghr_device.h LineAcc)
+    const float* ginst;  // [R][16] per-instance gradient lines in tile-list order (format: ghr_device.h LineAcc)
+    const uint32_t* inst_line;  // [R] line of every instance (instances numbered by rect4_slot), from the tile sort
+    uint32_t ginst_rows;        // lines in ginst / entries in inst_line (bound of the gather)
     const rect4* rects;
     const f4* rec;       // [P][4] packed render records (pixel mean, conic, opacity: needed to unpack the lines)
     float half_w, half_h;  // 0.5 W, 0.5 H (backward.cu:464-465)
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_geom_bwd(GeomBwdArgs a)
     f4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = r0;
     if (idx < a.P && rect4_area(r) != 0u) { r0 = a.rec[4 * (size_t)idx]; r1 = a.rec[4 * (size_t)idx + 1]; }
     float ga[16];
-    gather_inst_grads_wave(a.ginst, r, r0, r1, a.half_w, a.half_h, ga, 0xffffffffu);  // every lane of the wave takes part
+    gather_inst_grads_wave(a.ginst, a.inst_line, r, r0, r1, a.half_w, a.half_h, ga, a.ginst_rows);  // every lane of the wave takes part
     if (idx < a.P) geom_bwd_one(a, idx, ga);
 #endif
 }

@@ -63,7 +63,8 @@ struct ModelArgs {
 };  // rec / depths / rects / radii / means2D / slot_blk are indexed by WORKSPACE ROW (row0 + idx)
 
 struct ModelGrads {
-    const float* ginst;  // [R][16] per-instance packed gradients from k_render_bwd (slots: rect4_slot)
+    const float* ginst;  // [R][16] per-instance packed gradients from K8, in tile-list order
+    const uint32_t* inst_line;  // [R] line of every instance (instances numbered by rect4_slot), from the tile sort
     uint32_t ginst_rows; // lines in ginst (bound of the gather)
     float* d_means2D;   // [P,3]  dL/d(NDC mean) (densification signal), z = 0
     float* d_xyz;       // [P,3]
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;  // pixel mean / conic / opacity of the record k_project wrote (culled rows: none)
     if (idx < a.P && rect4_area(r) != 0u) { q0 = a.rec[4 * ((size_t)a.row0 + idx)]; q1 = a.rec[4 * ((size_t)a.row0 + idx) + 1]; }
     float ga[16];
-    gather_inst_grads_wave(g.ginst, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
+    gather_inst_grads_wave(g.ginst, g.inst_line, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
     if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     __syncthreads();
     bool bad = false;

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
             const uint32_t id = point_list[beg + (n_eff - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)id;
             const f4 a0 = r[0], a1 = r[1];
-            const uint32_t slot = min(rect4_slot(rects[id], tx, ty), cap - 1u);
+            const uint32_t slot = min(beg + (n_eff - 1 - (base + tid)), cap - 1u);  // lines lie in list order
             f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)slot;  // zero the instance's gradient line
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
             dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
@@ -349,8 +349,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_bwd(int W, int H, int gx, 
     }
     // list entries no pixel of the tile ever reached (positions >= n_eff): their slots must read as zero
     for (uint32_t i = n_eff + tid; i < n; i += GHR_BLOCK) {
-        const uint32_t id = point_list[beg + i];
-        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)min(rect4_slot(rects[id], tx, ty), cap - 1u);
+        f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)min(beg + i, cap - 1u);
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
         dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
     }

@@ -182,13 +182,11 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
     // it: they are requested together with the pixel data (one memory round trip for both).
     uint32_t e_id = 0u;
     f4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0, e3 = e0;
-    rect4 e_rc = make_rect4(0, 0, 0, 0, 0u);
     auto fetch_entry = [&](uint32_t base) {
         if (base + (uint32_t)tid < n) {
             e_id = point_list[beg + (n - 1 - (base + tid))];
             const f4* r = rec + 4 * (size_t)e_id;
             e0 = r[0]; e1 = r[1]; e2 = r[2]; e3 = r[3];
-            e_rc = rects[e_id];
         }
     };
     fetch_entry(0u);
@@ -227,7 +225,7 @@ __global__ void __launch_bounds__(GHR_BLOCK, 4) k_render_bwd_scan(int W, int H, 
         if (live_batch) __syncthreads();                 // previous batch fully consumed
         uint32_t cm = 0u;
         if ((uint32_t)tid < cnt) {
-            const uint32_t slot = min(rect4_slot(e_rc, tx, ty), cap - 1u);
+            const uint32_t slot = min(beg + (n - 1 - (base + tid)), cap - 1u);  // lines lie in list order
             f4* dst = reinterpret_cast<f4*>(ginst) + 4 * (size_t)slot;  // zero the instance's gradient line
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
             dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;

@@ -34,7 +34,7 @@ namespace ghr {
 
 #define GHR_B3_SEG_WORDS 8                       // mask words (of 64 list positions) expanded at a time
 #define GHR_B3_LIST (64 * GHR_B3_SEG_WORDS)      // ... hence at most this many hits per segment
-#define GHR_B3_CACHE 1024                        // tiles with at most this many instances keep ids / slots / masks in LDS
+#define GHR_B3_CACHE 2048                        // tiles with at most this many instances keep ids and masks in LDS
 #define GHR_B3_CWORDS (GHR_B3_CACHE / 64)
 #define GHR_B3_NBUF 3                            // gather buffers per wave (chunk t, t+1, t+2)
 #ifndef GHR_B3_WAVES
@@ -69,7 +69,6 @@ __device__ __forceinline__ void gather16_to_lds(const void* base, uint32_t byte_
 
 struct B3Shared {
     uint32_t id[GHR_B3_CACHE];                         // tile: Gaussian of each list position (tiles of <= GHR_B3_CACHE)
-    uint32_t slot[GHR_B3_CACHE];                       // tile: its gradient line
     unsigned long long mask[GHR_B3_CWORDS][16];        // tile: mask words, [word][cell]
     uint32_t clast[16];                                // tile: largest n_contrib of each cell
     uint16_t list[4][GHR_B3_LIST];                     // per wave: hit positions of the segment, ascending
@@ -78,7 +77,7 @@ struct B3Shared {
     uint32_t next;                                     // next cell of the tile nobody has taken yet
 };
 
-// The cells of one tile.  SMALL: the tile's ids, slots and mask words are in LDS (n <= GHR_B3_CACHE) and the gather runs
+// The cells of one tile.  SMALL: the tile's ids and mask words are in LDS (n <= GHR_B3_CACHE) and the gather runs
 // two chunks ahead; otherwise they are fetched from global memory chunk by chunk and nothing is overlapped (dense tiles
 // of more than GHR_B3_CACHE instances: correct, not fast).
 template <bool SMALL>
@@ -139,14 +138,8 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
             const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
             const uint32_t e = min((uint32_t)lane & 15u, cnt - 1u);
             const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
-            uint32_t id, slot;
-            if (SMALL) {
-                id = sh.id[pos];
-                slot = sh.slot[pos];
-            } else {
-                id = ld32(point_list, 4u * (beg + pos));
-                slot = min(rect4_slot(ld32(rects, 16u * id), tx, ty), cap - 1u);
-            }
+            const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
+            const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
             gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][t % GHR_B3_NBUF][0]);
             if (lane < 16) sh.cslot[wave][t % GHR_B3_NBUF][lane] = slot;
         };
@@ -401,14 +394,15 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
     // ---- tile prologue: zero the gradient lines of all the tile's instances (k_geom_bwd / k_project_bwd read every
     //      line of a Gaussian) and bring what every cell needs from the lists into LDS
     for (uint32_t i = tid; i < n; i += GHR_BLOCK) {
-        const uint32_t id = point_list[beg + i];
-        const uint32_t slot = min(rect4_slot(rects[id], tx, ty), cap - 1u);
-        if (small) { sh.id[i] = id; sh.slot[i] = slot; }
-        f4* dst = reinterpret_cast<f4*>(ginst) + 4u * slot;
+        if (small) sh.id[i] = point_list[beg + i];
+        // the lines lie in list order (the per-Gaussian gather finds them through the sort's inst_line): plain
+        // consecutive stores, nothing to look up
+        f4* dst = reinterpret_cast<f4*>(ginst) + 4u * min(beg + i, cap - 1u);
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
         dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
     }
-    if (small && (uint32_t)tid < 16u * ((n + 63u) >> 6)) (&sh.mask[0][0])[tid] = cell_mask[word0 * 16 + tid];
+    if (small)
+        for (uint32_t i = tid; i < 16u * ((n + 63u) >> 6); i += GHR_BLOCK) (&sh.mask[0][0])[i] = cell_mask[word0 * 16 + i];
     if (tid < 16) sh.clast[tid] = cell_last[16u * tile + tid];
     if (tid == 0) sh.next = 0u;
     __syncthreads();  // orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below

@@ -123,7 +123,8 @@ class _RenderModelFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
                                                         _ptr(d_op), _ptr(d_label), _ptr(d_conf), _ptr(d_fdc),
-                                                        _ptr(d_frest), None, acc, sink.nan_flag_ptr(), rows))
+                                                        _ptr(d_frest), None, acc, sink.nan_flag_ptr(), rows,
+                                                        _ptr(binb), ctx.cap))
                 sink.accumulate_end(stream)
             elif P > 0:
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
@@ -269,7 +270,7 @@ class _RenderHairFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
                                                         _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
-                                                        _ptr(d_dir), 0, None, scratch.shape[0]))
+                                                        _ptr(d_dir), 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
         return d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d, None, None
 

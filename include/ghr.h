@@ -174,7 +174,9 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
 /* Backward in two steps: K8 over the whole state (rows_total rows), then the per-Gaussian chain for the segments that
  * need gradients.  d_means2D is [rows_total,3]; the parameter gradients are per segment ([P,...]); in mode 1
  * d_log_scales / d_opacity_logit / d_label_logit / d_orient_conf_log are the gradients of the linear quantities and,
- * like d_dir3d, may be NULL.  grad_rows: number of lines in grad_scratch (0: not bounded), see ghr_backward. */
+ * like d_dir3d, may be NULL.  grad_rows: number of lines in grad_scratch (0: R), see ghr_backward.  bin_ws / R: the binning
+ * workspace and the capacity ghr_forward_stage2 ran with (ABI 12: the gradient lines lie in tile-list order, the per-Gaussian
+ * chain finds a Gaussian's lines through the index the tile sort left in bin_ws). */
 int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
                         const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
                         float* grad_scratch);
@@ -182,7 +184,8 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
                                const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
                                float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
-                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows);
+                               int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows, const void* bin_ws,
+                               uint32_t R);
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,

@@ -146,7 +146,8 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     Sim* s = (Sim*)h;
     const int P = s->P, T = s->T;
     const size_t N = (size_t)a->W * a->H;
-    // one 64-B line per Gaussian-tile instance (rect4_slot), as k_render_bwd writes them; the per-pixel sum inside
+    // one 64-B line per Gaussian-tile instance, in tile-list order as K8 writes them (inst_line maps a Gaussian's
+    // instances, numbered by rect4_slot, to their lines: what the tile sort leaves); the per-pixel sum inside
     // an instance is order-free on the GPU (wave butterfly + ds_add), so it is accumulated in double here
     std::vector<double> acc((size_t)16 * s->R, 0.0);
     for (int t = 0; t < T; t++) {
@@ -183,28 +184,35 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
                 float g[16];
                 // branch-free step: non-contributing visits (pos >= n_contrib of THIS pixel included) run with alpha = 0
                 if (ghr::bwd_step(st, pos < last, (float)px, (float)py, r[0], r[1], r[2], r[3], (float)(tid & 15), (float)(tid >> 4), g)) {
-                    const size_t slot = ghr::rect4_slot(s->rects[id], tx, ty);
-                    for (int i = 0; i < 16; i++) acc[16 * slot + i] += (double)g[i];
+                    const size_t line = (size_t)beg + pos;
+                    for (int i = 0; i < 16; i++) acc[16 * line + i] += (double)g[i];
                 }
             }
         }
     }
     std::vector<float> ginst((size_t)16 * s->R + 16);
     for (size_t i = 0; i < acc.size(); i++) ginst[i] = (float)acc[i];
+    std::vector<uint32_t> inst_line((size_t)s->R + 1, 0u);
+    for (int t = 0; t < T; t++) {
+        const uint32_t beg = s->tile_start[t], n = s->tile_start[t + 1] - beg;
+        for (uint32_t pos = 0; pos < n; pos++)
+            inst_line[ghr::rect4_slot(s->rects[s->point_list[beg + pos]], t % s->gx, t / s->gx)] = beg + pos;
+    }
     ghr::GeomBwdArgs ga;
     ga.P = P; ga.means3D = a->means3D; ga.radii = s->radii.data(); ga.scales = a->scales; ga.rotations = a->rotations;
     ga.cov3D = s->cov3D.data(); ga.conic_precomp = a->conic_precomp; ga.view = a->viewmatrix; ga.proj = a->projmatrix;
     ga.scale_modifier = a->scale_modifier; ga.tan_fovx = a->tan_fovx; ga.tan_fovy = a->tan_fovy;
     ga.focal_y = a->H / (2.0f * a->tan_fovy);
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
-    ga.ginst = ginst.data(); ga.rects = s->rects.data(); ga.rec = s->rec.data();
+    ga.ginst = ginst.data(); ga.inst_line = inst_line.data(); ga.ginst_rows = (uint32_t)s->R;
+    ga.rects = s->rects.data(); ga.rec = s->rec.data();
     ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
     ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     for (int idx = 0; idx < P; idx++) {
         float g16[16];
-        ghr::gather_inst_grads(ga.ginst, ga.rects[idx], ga.rec[4 * (size_t)idx], ga.rec[4 * (size_t)idx + 1], ga.half_w,
-                               ga.half_h, g16);
+        ghr::gather_inst_grads(ga.ginst, ga.inst_line, ga.rects[idx], ga.rec[4 * (size_t)idx], ga.rec[4 * (size_t)idx + 1],
+                               ga.half_w, ga.half_h, g16, ga.ginst_rows);
         ghr::geom_bwd_one(ga, idx, g16);
     }
 }
