@@ -133,7 +133,7 @@ def lib() -> ctypes.CDLL:
                                     ctypes.POINTER(ctypes.c_size_t)]
     L.ghr_binning_size.argtypes = [u32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.ghr_forward_stage1.argtypes = [vp, ctypes.POINTER(ViewArgs), vp, vp, vp, vp]
-    L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp]
+    L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp, vp]
     L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]

@@ -206,7 +206,7 @@ GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* re
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                          uint32_t* tile_cursor, const rect4* __restrict__ rects,
-                                                         uint32_t* inst_line, int gx)
+                                                         uint32_t* inst_line, int gx, float* ginst)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
     const uint32_t tile = xcd_tile(blockIdx.x, T);
@@ -216,6 +216,13 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     const int tid = threadIdx.x;
     // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may
     // be replayed, e.g. after a too small speculative capacity)
+    // The tile's gradient lines are its n consecutive lines from s (they lie in list order): when the caller hands the
+    // backward pass's scratch over, they are zeroed here, under the sort's LDS round trips where the memory pipe is idle
+    // (the backward render kernel then starts accumulating at once: -10 % of its time inside the step).
+    if (ginst != nullptr) {
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) reinterpret_cast<f4*>(ginst)[4 * (size_t)s + i] = zero;
+    }
     const bool sorted_already = tile_cursor[tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
     __syncthreads();
     if (tid == 0) tile_cursor[tile] = 0u;

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "ghr_binning.h"
 #include "ghr_device.h"
@@ -36,6 +38,26 @@ hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, b
 //   1 = scan form with the tile pipeline (k_render_bwd_scan): 0.26-0.28 ms.
 int g_deterministic = 0;  // ghr_set_deterministic
 
+// Which scratch buffer the tile sort of a forward pass has zeroed, by binning workspace (ghr_forward_stage2's optional
+// grad_scratch).  The first backward render over that state with that scratch skips its own zero-fill; host bookkeeping
+// in enqueue order (forward and backward of a state are ordered on their stream anyway).
+std::mutex g_zeroed_mu;
+std::unordered_map<const void*, const void*> g_zeroed;
+void note_zeroed(const void* bin_ws, const void* scratch)
+{
+    std::lock_guard<std::mutex> lk(g_zeroed_mu);
+    if (scratch) g_zeroed[bin_ws] = scratch; else g_zeroed.erase(bin_ws);
+}
+bool take_zeroed(const void* bin_ws, const void* scratch)
+{
+    std::lock_guard<std::mutex> lk(g_zeroed_mu);
+    auto it = g_zeroed.find(bin_ws);
+    if (it == g_zeroed.end()) return false;
+    const bool hit = it->second == scratch;
+    g_zeroed.erase(it);
+    return hit;
+}
+
 int k8_variant()
 {
     static int v = -1;
@@ -49,7 +71,7 @@ int k8_variant()
 void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint32_t T_tiles, const uint32_t* tile_start,
                const uint32_t* point_list, const ghr::f4* rec, const float* bg, const float* final_T,
                const uint32_t* n_contrib, const float* dL_dpix, const ghr::rect4* rects, float* ginst, uint32_t cap,
-               const unsigned long long* cell_mask, const uint32_t* cell_last)
+               const unsigned long long* cell_mask, const uint32_t* cell_last, bool prezeroed)
 {
     const dim3 grid(ghr::xcd_grid(T)), block(GHR_BLOCK);
     int v = k8_variant();
@@ -58,7 +80,8 @@ void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uin
     switch (v) {
     case 2:
         hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic);
+                           final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic,
+                           prezeroed ? 1 : 0);
         break;
     case 1:
         hipLaunchKernelGGL(ghr::k_render_bwd_scan, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
@@ -248,7 +271,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
 }
 
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
-                       float* out_color)
+                       float* out_color, float* grad_scratch)
 {
     if (int rc = check_dims(a)) return rc;  // stage 2 only reads P, W, H, C, background (+ debug)
     if (!out_color) return fail(GHR_E_INVALID, "out_color is NULL");
@@ -281,8 +304,9 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
                                im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
-                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
+                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, grad_scratch);
     }
+    note_zeroed(bin_ws, R > 0 ? grad_scratch : nullptr);
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                        (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
@@ -320,7 +344,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
         launch_k8((size_t)a->P, (uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
                   (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, a->background, (const float*)im.final_T,
                   (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
-                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last);
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, take_zeroed(bin_ws, grad_scratch));
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -446,7 +470,7 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     launch_k8((size_t)rows_total, (uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start, (const uint32_t*)b.point_list,
               (const ghr::f4*)g.rec, background, (const float*)im.final_T, (const uint32_t*)im.n_contrib, dL_dpix,
               (const ghr::rect4*)g.rects, grad_scratch, R, (const unsigned long long*)b.cell_mask,
-              (const uint32_t*)im.cell_last);
+              (const uint32_t*)im.cell_last, take_zeroed(bin_ws, grad_scratch));
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }

@@ -377,7 +377,8 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
                                                                 const rect4* __restrict__ rects, float* ginst,
                                                                 uint32_t cap,
                                                                 const unsigned long long* __restrict__ cell_mask,
-                                                                const uint32_t* __restrict__ cell_last, int ordered)
+                                                                const uint32_t* __restrict__ cell_last, int ordered,
+                                                                int prezeroed)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ B3Shared sh;
@@ -397,9 +398,11 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
         if (small) sh.id[i] = point_list[beg + i];
         // the lines lie in list order (the per-Gaussian gather finds them through the sort's inst_line): plain
         // consecutive stores, nothing to look up
-        f4* dst = reinterpret_cast<f4*>(ginst) + 4u * min(beg + i, cap - 1u);
-        const f4 zero = {0.f, 0.f, 0.f, 0.f};
-        dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
+        if (!prezeroed) {  // (wave-uniform) else the tile sort of this state's forward pass has zeroed them already
+            f4* dst = reinterpret_cast<f4*>(ginst) + 4u * min(beg + i, cap - 1u);
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
+            dst[0] = zero; dst[1] = zero; dst[2] = zero; dst[3] = zero;
+        }
     }
     if (small)
         for (uint32_t i = tid; i < 16u * ((n + 63u) >> 6); i += GHR_BLOCK) (&sh.mask[0][0])[i] = cell_mask[word0 * 16 + i];

@@ -16,6 +16,7 @@ must live on a ROCm device and the HIP library must be present.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import NamedTuple
 
 import torch
@@ -217,13 +218,18 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(L.ghr_forward_stage1(_stream(), ctypes.byref(args), _ptr(geomBuffer), _ptr(imgBuffer),
                                                 _ptr(radii), ctypes.c_void_p(pinned.data_ptr())))
 
+                want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+                f32 = dict(dtype=torch.float32, device=dev)
+
                 def launch(cap):
                     b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
+                    # the backward pass's gradient lines, zeroed under the tile sort (include/ghr.h, ghr_forward_stage2)
+                    sc = torch.empty((max(int(cap), 1), _lib.GRAD_STRIDE), **f32) if want_grad and cap > 0 else None
                     _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), cap, _ptr(geomBuffer),
-                                                    _ptr(imgBuffer), _ptr(b), _ptr(color)))
-                    return b
+                                                    _ptr(imgBuffer), _ptr(b), _ptr(color), _ptr(sc)))
+                    return b, sc
 
-                num_rendered, bin_cap, binningBuffer = run_stage2(dev, P, pinned, launch)
+                num_rendered, bin_cap, (binningBuffer, ctx.scratch) = run_stage2(dev, P, pinned, launch)
             except Exception as ex:
                 if cpu_args is not None:
                     torch.save(cpu_args, "snapshot_fw.dump")
@@ -268,7 +274,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_conic = torch.empty((P, 2, 2), **f32)
             grad_scales = torch.empty((P, 3), **f32)
             grad_rotations = torch.empty((P, 4), **f32)
-            scratch = torch.empty((max(int(num_rendered), 1), _lib.GRAD_STRIDE), **f32)  # one line per instance
+            scratch = getattr(ctx, "scratch", None)  # one line per instance; zeroed by the forward pass if it made it
+            if scratch is None:
+                scratch = torch.empty((max(int(num_rendered), 1), _lib.GRAD_STRIDE), **f32)
             dL = grad_out_color
             if dL.dtype != torch.float32:
                 dL = dL.float()

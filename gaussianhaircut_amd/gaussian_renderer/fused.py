@@ -8,6 +8,7 @@ the leaf parameters run in hand-written HIP kernels instead of ~60 PyTorch kerne
 from __future__ import annotations
 
 import ctypes
+import os
 
 import torch
 
@@ -57,14 +58,19 @@ class _RenderModelFused(torch.autograd.Function):
             va.background = _ptr(bg)
             va.debug = int(bool(cfg["debug"]))
 
+            want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+
             def launch(cap):
                 b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
+                # the backward pass's gradient lines, zeroed under the tile sort (include/ghr.h, ghr_forward_stage2)
+                sc = (torch.empty((max(int(cap), 1), _lib.GRAD_STRIDE), dtype=torch.float32, device=dev)
+                      if want_grad and cap > 0 else None)
                 _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
-                                                _ptr(color)))
-                return b
+                                                _ptr(color), _ptr(sc)))
+                return b, sc
 
             # speculative (see diff_gaussian_rasterization.run_stage2); with cfg["defer_count"] R is a PendingCount
-            R, cap, binb = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
+            R, cap, (binb, ctx.scratch) = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
         cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
         # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
@@ -104,8 +110,11 @@ class _RenderModelFused(torch.autograd.Function):
                 d_fdc = torch.empty((P, 1, 3), **f32)
                 d_frest = torch.empty((P, K - 1, 3), **f32)
             # one line per instance; `cap` lines while the count is still pending (include/ghr.h, ghr_backward)
-            rows = max(int(R), 1) if isinstance(R, int) else max(int(ctx.cap), 1)
-            scratch = torch.empty((rows, _lib.GRAD_STRIDE), **f32)
+            scratch = getattr(ctx, "scratch", None)  # made (and zeroed) by the forward pass when it knew of a backward
+            if scratch is None:
+                rows = max(int(R), 1) if isinstance(R, int) else max(int(ctx.cap), 1)
+                scratch = torch.empty((rows, _lib.GRAD_STRIDE), **f32)
+            rows = scratch.shape[0]
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
@@ -223,13 +232,17 @@ class _RenderHairFused(torch.autograd.Function):
             va.background = _ptr(cam_t[3])
             va.debug = int(bool(cfg["debug"]))
 
+            want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+
             def launch(cap):
                 b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
+                sc = (torch.empty((max(int(cap), 1), _lib.GRAD_STRIDE), dtype=torch.float32, device=dev)
+                      if want_grad and cap > 0 else None)
                 _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
-                                                _ptr(color)))
-                return b
+                                                _ptr(color), _ptr(sc)))
+                return b, sc
 
-            R, cap, binb = run_stage2(dev, rows, pinned, launch)
+            R, cap, (binb, ctx.scratch) = run_stage2(dev, rows, pinned, launch)
             # the reference's outputs are indexed by [head rows, strand rows] without the alignment padding
             radii = torch.cat([radii_ws[:n_head], radii_ws[row0:]])
             screenspace_points.detach().copy_(torch.cat([m2d_ws[:n_head], m2d_ws[row0:]]))
@@ -258,7 +271,9 @@ class _RenderHairFused(torch.autograd.Function):
             d_rot, d_dir = torch.empty((n_hair, 4), **f32), torch.empty((n_hair, 3), **f32)
             d_conf = torch.empty((n_hair, 1), **f32)
             d_fdc, d_frest = torch.empty((n_hair, 1, 3), **f32), torch.empty((n_hair, K - 1, 3), **f32)
-            scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)
+            scratch = getattr(ctx, "scratch", None)  # made (and zeroed) by the forward pass when it knew of a backward
+            if scratch is None:
+                scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)
             dL = grad_color.float().contiguous()
             hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
             m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, [view, proj, campos, bg], cfg,

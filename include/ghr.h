@@ -95,9 +95,12 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
  * count stage 1 reported for the result to be valid, and the same value must be passed to the backward call.  A caller
  * may therefore launch stage 2 speculatively with a capacity guessed from the previous frame BEFORE reading *R_host
  * (no GPU bubble behind the host round trip) and relaunch it only if the true count turned out larger: instances
- * beyond the capacity are dropped without touching memory outside bin_ws.  Stage 2 may be replayed. */
+ * beyond the capacity are dropped without touching memory outside bin_ws.  Stage 2 may be replayed.
+ * grad_scratch (ABI 12, may be NULL): the scratch the backward call over this state will be given (>= R lines).  Its
+ * lines are then zeroed here, under the tile sort, and the first ghr_backward / ghr_render_backward with this bin_ws and
+ * this scratch skips its own zero-fill (the library remembers the pair; any other backward zeroes for itself). */
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
-                       float* out_color);
+                       float* out_color, float* grad_scratch);
 
 /* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  R: the capacity stage 2 was run with (layout of bin_ws).
  * grad_scratch: GHR_GRAD_STRIDE floats (one 64-B gradient line) per Gaussian-tile instance actually reported by stage 1

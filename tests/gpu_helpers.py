@@ -40,7 +40,10 @@ def _slice(buf: torch.Tensor, ptr, nbytes, dtype):
 class GpuRun:
     """One forward (+ optional backward) of the rasterizer through the C ABI, keeping every buffer."""
 
-    def __init__(self, ri, mode="A", debug=True):
+    def __init__(self, ri, mode="A", debug=True, scratch=None):
+        """scratch: the gradient-line buffer a later ghr_backward will get; stage 2 then zeroes it under the tile sort
+        (include/ghr.h) -- the product's op does this, the parity tests leave it out on purpose (both ways are tested:
+        the op-level tests go through the product path)."""
         L = _lib.lib()
         self.L = L
         self.ri, self.mode = ri, mode
@@ -69,7 +72,7 @@ class GpuRun:
         self.R = int(pinned[0].item()) if P > 0 else 0
         self.bin = torch.zeros(_lib.binning_size(self.R, W, H), dtype=torch.uint8, device=dev)
         _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(self.args), self.R, _ptr(self.geom), _ptr(self.img),
-                                        _ptr(self.bin), _ptr(self.out)))
+                                        _ptr(self.bin), _ptr(self.out), _ptr(scratch)))
         torch.cuda.synchronize()
 
     def inspect(self):
