@@ -207,7 +207,7 @@ def main():
                 "note": "gradient walk bound by VALU issue and memory latency, not by bandwidth (profiles/r02b: "
                         "SQ_ACTIVE_INST_VALU 55 %% of the SIMD cycles at 5 waves per SIMD, half the VALU instructions of "
                         "round 1's kernel; every L2 atomic is written through to HBM, hence traffic > algorithmic "
-                        "bytes); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured "
+                        "bytes; the zero-fill of the gradient lines runs under the forward pass's tile sort); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured "
                         "view; kernel duration from HIP events the library records around the kernel on its launch "
                         "stream, %d solo passes" % n_ev}
 
