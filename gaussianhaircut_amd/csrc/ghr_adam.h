@@ -12,7 +12,10 @@
 namespace ghr {
 
 #define GHR_ADAM_MAX_GROUPS 16
+#ifndef GHR_ADAM_STATE  // include/ghr.h states the same number for the callers
 #define GHR_ADAM_STATE (2 + GHR_ADAM_MAX_GROUPS)
+#endif
+static_assert(GHR_ADAM_STATE == 2 + GHR_ADAM_MAX_GROUPS, "GHR_ADAM_STATE of include/ghr.h");
 
 struct AdamArgs {
     long long begin;      // first element of the range this launch updates
