@@ -336,3 +336,36 @@ def test_deterministic_backward_is_bit_reproducible(oracle_mod, dev):
     for other in runs[1:]:
         for k in runs[0]:
             assert np.array_equal(np.asarray(runs[0][k]).view(np.uint32), np.asarray(other[k]).view(np.uint32)), k
+
+
+def test_op_backward_twice_on_one_forward(oracle_mod, dev):
+    """The op hands the backward's scratch to the forward pass, whose tile sort zeroes the gradient lines
+    (ghr_forward_stage2 grad_scratch): only the FIRST backward over that state may rely on it.  retain_graph + a second
+    backward must give the same gradients again (the render kernel then zeroes for itself), both equal to the oracle's."""
+    from gaussianhaircut_amd.diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    spec = syn.CONFIGS["tiny"]
+    ri = syn.raster_inputs(spec)
+    out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, "B_sr")
+    dL = syn.grad_image(spec, 5).numpy() * (spec.H * spec.W)
+    dL[:, st_o.fragile.astype(bool)] = 0.0
+    ref = hp.oracle_backward(oracle_mod, st_o, ri, dL, "B_sr")
+    d = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in ri.items()}
+    rs = GaussianRasterizationSettings(ri["H"], ri["W"], ri["tanfovx"], ri["tanfovy"], d["bg"], 1.0, d["viewmatrix"],
+                                       d["projmatrix"], 3, d["campos"], True, False)
+    leaves = {k: d[k].clone().requires_grad_(True) for k in ("means3D", "colors", "opacities", "scales", "rotations")}
+    color, radii = GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=d["means2D"], opacities=leaves["opacities"],
+                                          colors_precomp=leaves["colors"], scales=leaves["scales"],
+                                          rotations=leaves["rotations"])
+    w = torch.from_numpy(dL).to(dev)
+    grads = []
+    for rep in range(3):
+        for t in leaves.values():
+            t.grad = None
+        (color * w).sum().backward(retain_graph=True)
+        torch.cuda.synchronize()
+        grads.append({k: t.grad.detach().cpu().numpy().copy() for k, t in leaves.items()})
+    names = dict(means3D="dL_dmeans3D", colors="dL_dcolors", opacities="dL_dopacity", scales="dL_dscales",
+                 rotations="dL_drotations")
+    for g in grads:
+        hp.assert_grads_close({names[k]: v.reshape(ref[names[k]].shape) for k, v in g.items()},
+                              {names[k]: ref[names[k]] for k in g})
