@@ -28,7 +28,7 @@ def _tan_half(fov) -> float:
         return math.tan(float(fov) * 0.5)
     cached = getattr(fov, "_ghr_tan_half", None)
     if cached is None or cached[0] != fov._version:
-        cached = (fov._version, math.tan(float(fov) * 0.5))
+        cached = (fov._version, math.tan(float(fov.detach()) * 0.5))
         try:
             fov._ghr_tan_half = cached
         except AttributeError:
@@ -113,17 +113,37 @@ def _package(renders, screenspace_points, radii):
                          viewspace_points=screenspace_points, radii=radii)
 
 
-def _use_fused(pc, pipe) -> bool:
+_CAMERA_TENSORS = ("world_view_transform", "full_proj_transform", "camera_center", "projection_matrix", "FoVx", "FoVy")
+
+
+def camera_requires_grad(cam) -> bool:
+    """True when autograd is recording and any tensor of the camera the projection reads is being trained.  The
+    reference optimises camera pose and FoV by default (``src/arguments/__init__.py:61-62``, ``src/scene/cameras.py:
+    83-151``, stepped at ``src/train_gaussians.py:183-196``); their gradients flow through get_conic / get_mean_2d /
+    get_direction_2d / get_depths.  The fused projection kernels take the camera as constants, so such a camera must
+    take the generic (PyTorch autograd) projection path -- it is never silently detached."""
+    if not torch.is_grad_enabled():
+        return False
+    for name in _CAMERA_TENSORS:
+        t = getattr(cam, name, None)
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+            return True
+    return False
+
+
+def _use_fused(pc, pipe, cam=None) -> bool:
     """The fused HIP path covers exactly the free-Gaussian ``GaussianModel`` parametrisation (exp / sigmoid / normalize
-    activations, longest-axis direction); anything else (strand models, the reference's own classes) takes the generic
-    path below, which only relies on the model's public interface."""
+    activations, longest-axis direction) seen through a CONSTANT camera; anything else (strand models, the reference's
+    own classes, a camera whose tensors require grad) takes the generic path below, which only relies on the model's
+    public interface and on PyTorch autograd."""
     from ..scene.gaussian_model import GaussianModel
-    return type(pc) is GaussianModel and getattr(pipe, "fused_projection", True) and pc.get_xyz.is_cuda
+    return (type(pc) is GaussianModel and getattr(pipe, "fused_projection", True) and pc.get_xyz.is_cuda and
+            not (cam is not None and camera_requires_grad(cam)))
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
     """Render the scene (reference :23-113).  ``bg_color`` (10 floats) must be on the GPU."""
-    if _use_fused(pc, pipe):
+    if _use_fused(pc, pipe, viewpoint_camera):
         from .fused import render_model_fused
         # pipe.defer_count (set by trainer.training_step, which owns the recovery): queue the view without ever
         # reading num_rendered back; the package then carries a PendingCount in `.count`
@@ -160,19 +180,20 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     return _package(renders, screenspace_points, radii)
 
 
-def _use_fused_hair(pc, pc_hair, pipe) -> bool:
+def _use_fused_hair(pc, pc_hair, pipe, cam=None) -> bool:
     """Fused strand-stage path: a ``GaussianModel`` head with its ``*_precomp`` attributes and a
-    ``GaussianModelStrands`` on a ROCm device (anything else takes the generic path)."""
+    ``GaussianModelStrands`` on a ROCm device, constant camera (anything else takes the generic path)."""
     from ..scene.gaussian_model import GaussianModel
     from ..scene.gaussian_model_strands import GaussianModelStrands
     from ..scene.gaussian_model_latent_strands import GaussianModelLatentStrands
     return (type(pc) is GaussianModel and type(pc_hair) in (GaussianModelStrands, GaussianModelLatentStrands) and
-            getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view"))
+            getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view") and
+            not (cam is not None and camera_requires_grad(cam)))
 
 
 def render_hair(viewpoint_camera, pc, pc_hair, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
     """Frozen head Gaussians (``*_precomp`` attributes of ``pc``) + trainable hair strands (reference :116-214)."""
-    if _use_fused_hair(pc, pc_hair, pipe):
+    if _use_fused_hair(pc, pc_hair, pipe, viewpoint_camera):
         from .fused import render_hair_fused
         renders, radii, screenspace_points = render_hair_fused(viewpoint_camera, pc, pc_hair, bg_color,
                                                                scaling_modifier, getattr(pipe, "debug", False))

@@ -285,3 +285,24 @@ def test_adam_reduce_plan_covers_the_buffer_and_skips_inactive_sh_bands(deg):
         assert len(special) == 1 and special[0][:2] == (rest_a, rest_b)
         assert special[0][2] == ("none" if deg == 0 else ("rest", P, 15, act))
         assert sent == n - 45 * P + 3 * P * act
+
+
+def test_camera_that_requires_grad_never_takes_the_fused_projection():
+    """The fused kernels take the camera as constants; a trainable camera (reference default: src/arguments/__init__.py:
+    61-62) must fall back to the autograd projection (gaussian_renderer._use_fused / _use_fused_hair)."""
+    import torch
+    from gaussianhaircut_amd.gaussian_renderer import camera_requires_grad
+    from gaussianhaircut_amd.utils import synthetic as syn
+    cam = syn.make_view(syn.CONFIGS["tiny"], "cpu")
+    assert not camera_requires_grad(cam)
+    for name in ("world_view_transform", "full_proj_transform", "camera_center", "FoVx", "FoVy"):
+        c = syn.make_view(syn.CONFIGS["tiny"], "cpu")
+        setattr(c, name, getattr(c, name).clone().requires_grad_(True))
+        assert camera_requires_grad(c), name
+        with torch.no_grad():
+            assert not camera_requires_grad(c), name
+    # non-leaf tensors computed from a trainable pose count as well
+    c = syn.make_view(syn.CONFIGS["tiny"], "cpu")
+    pose = c.world_view_transform.clone().requires_grad_(True)
+    c.full_proj_transform = pose @ c.projection_matrix
+    assert camera_requires_grad(c)
