@@ -200,7 +200,7 @@ def main():
             traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
         except Exception:
             traffic = None
-    roofline = {"kernel": "k_render_bwd_cells (K8; GHR_K8=cell|scan select the older forms)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+    roofline = {"kernel": "k_render_bwd_cells (K8)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),

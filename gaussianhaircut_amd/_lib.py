@@ -23,6 +23,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 NUM_CHANNELS = 10
 GRAD_STRIDE = 16
 ADAM_STATE = 18  # GHR_ADAM_STATE
+ABI_VERSION = 13  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -129,12 +130,17 @@ def lib() -> ctypes.CDLL:
     vp, i32, u32, f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_uint32, ctypes.c_float
     L.ghr_last_error.restype = ctypes.c_char_p
     L.ghr_abi_version.restype = ctypes.c_int
+    got = int(L.ghr_abi_version())
+    if got != ABI_VERSION:
+        # a stale build or a GHR_LIB_PATH experiment library with other argument lists: calling it would read garbage
+        raise GhrError("%s reports ABI %d, this binding needs %d (rebuild: gaussianhaircut_amd._lib.build_library(force=True))"
+                       % (LIB_PATH, got, ABI_VERSION))
     L.ghr_forward_sizes.argtypes = [i32, i32, i32, i32, ctypes.POINTER(ctypes.c_size_t),
                                     ctypes.POINTER(ctypes.c_size_t)]
     L.ghr_binning_size.argtypes = [u32, i32, i32, ctypes.POINTER(ctypes.c_size_t)]
     L.ghr_forward_stage1.argtypes = [vp, ctypes.POINTER(ViewArgs), vp, vp, vp, vp]
     L.ghr_forward_stage2.argtypes = [vp, ctypes.POINTER(ViewArgs), u32, vp, vp, vp, vp, vp]
-    L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14
+    L.ghr_backward.argtypes = [vp, ctypes.POINTER(ViewArgs), u32] + [vp] * 14 + [i32]
     L.ghr_mark_visible.argtypes = [vp, i32, vp, vp, vp, vp]
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_set_deterministic.argtypes = [i32]
@@ -148,10 +154,10 @@ def lib() -> ctypes.CDLL:
     L.ghr_adam_step_range.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp, vp, i32,
                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double,
                                       ctypes.c_double, f32, i32, i32, i32, u32]
-    L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp]
+    L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp, i32]
     L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
-    L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6
+    L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6 + [i32]
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:

@@ -9,8 +9,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
-#include <unordered_map>
 
 #include "ghr_binning.h"
 #include "ghr_device.h"
@@ -30,45 +28,20 @@ thread_local char g_err[512] = "";
 // Process-wide (NOT thread_local): torch's autograd engine calls ghr_backward from its own worker thread.
 hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, bwd start/stop
 
-// K8 variant (same gradient-line format, GHR_K8=cells|cell|scan selects):
+// K8 variant (same gradient-line format; GHR_K8=cell selects the fallback, read at every call so that a test can switch):
 //   2 = cell-list form (k_render_bwd_cells, default): one wave per 4x4 cell from the forward pass's hit masks, records
-//       gathered straight into LDS two chunks ahead; 0.214 ms on 500k strands;
-//   0 = cell-group form (k_render_bwd): lane = pixel, 16-lane butterflies; 0.238 ms; also the fallback where the
-//       cell-list form's 32-bit offsets do not reach (b3_fits);
-//   1 = scan form with the tile pipeline (k_render_bwd_scan): 0.26-0.28 ms.
+//       gathered straight into LDS two chunks ahead;
+//   0 = cell-group form (k_render_bwd, round 1): lane = pixel, 16-lane butterflies; the fallback where the cell-list
+//       form's 32-bit byte offsets do not reach (b3_fits: >= 2^26 rows / instances).
 int g_deterministic = 0;  // ghr_set_deterministic
-
-// Which scratch buffer the tile sort of a forward pass has zeroed, by binning workspace (ghr_forward_stage2's optional
-// grad_scratch).  The first backward render over that state with that scratch skips its own zero-fill; host bookkeeping
-// in enqueue order (forward and backward of a state are ordered on their stream anyway).
-std::mutex g_zeroed_mu;
-std::unordered_map<const void*, const void*> g_zeroed;
-void note_zeroed(const void* bin_ws, const void* scratch)
-{
-    std::lock_guard<std::mutex> lk(g_zeroed_mu);
-    if (scratch) g_zeroed[bin_ws] = scratch; else g_zeroed.erase(bin_ws);
-}
-bool take_zeroed(const void* bin_ws, const void* scratch)
-{
-    std::lock_guard<std::mutex> lk(g_zeroed_mu);
-    auto it = g_zeroed.find(bin_ws);
-    if (it == g_zeroed.end()) return false;
-    const bool hit = it->second == scratch;
-    g_zeroed.erase(it);
-    return hit;
-}
 
 int k8_variant()
 {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = std::getenv("GHR_K8");
-        v = (e && std::strcmp(e, "scan") == 0) ? 1 : ((e && std::strcmp(e, "cell") == 0) ? 0 : 2);
-    }
-    return v;
+    const char* e = std::getenv("GHR_K8");
+    return (e && std::strcmp(e, "cell") == 0) ? 0 : 2;
 }
 
-void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint32_t T_tiles, const uint32_t* tile_start,
+int launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint32_t T_tiles, const uint32_t* tile_start,
                const uint32_t* point_list, const ghr::f4* rec, const float* bg, const float* final_T,
                const uint32_t* n_contrib, const float* dL_dpix, const ghr::rect4* rects, float* ginst, uint32_t cap,
                const unsigned long long* cell_mask, const uint32_t* cell_last, bool prezeroed)
@@ -76,22 +49,23 @@ void launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uin
     const dim3 grid(ghr::xcd_grid(T)), block(GHR_BLOCK);
     int v = k8_variant();
     if (g_deterministic) v = 2;  // the ordered walk exists in the cell-list form
-    if (v == 2 && !ghr::b3_fits(rows, cap, (size_t)W, (size_t)H)) v = 0;  // its 32-bit offsets
+    if (v == 2 && !ghr::b3_fits(rows, cap, (size_t)W, (size_t)H)) {
+        if (g_deterministic) return -1;  // the caller reports it: determinism is never dropped silently
+        v = 0;  // its 32-bit offsets
+    }
     switch (v) {
     case 2:
         hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic,
                            prezeroed ? 1 : 0);
         break;
-    case 1:
-        hipLaunchKernelGGL(ghr::k_render_bwd_scan, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, rects, ginst, cap);
-        break;
     default:
         hipLaunchKernelGGL(ghr::k_render_bwd, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, rects, ginst, cap);
     }
+    return 0;
 }
+#define GHR_E_DETERMINISTIC_MSG "ghr_set_deterministic(1) cannot be honoured at this size (the ordered walk needs 32-bit byte offsets: < 2^26 rows / instances)"
 
 int fail(int code, const char* fmt, const char* detail = "")
 {
@@ -306,7 +280,6 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
                            im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, grad_scratch);
     }
-    note_zeroed(bin_ws, R > 0 ? grad_scratch : nullptr);
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                        (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
@@ -318,7 +291,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
 int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
                  const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
-                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations)
+                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed)
 {
     // backward reads colours / opacity from the packed records in geom_ws, not from `a`
     if (int rc = check_dims(a)) return rc;
@@ -340,11 +313,12 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)T, &b);
 
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    if (R > 0)
+    if (R > 0 &&
         launch_k8((size_t)a->P, (uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
                   (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, a->background, (const float*)im.final_T,
                   (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
-                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, take_zeroed(bin_ws, grad_scratch));
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0))
+        return fail(GHR_E_INVALID, GHR_E_DETERMINISTIC_MSG);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
     ga.P = a->P; ga.means3D = a->means3D; ga.radii = radii; ga.scales = a->scales; ga.rotations = a->rotations;
@@ -454,7 +428,7 @@ int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_w
 
 int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
                         const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
-                        float* grad_scratch)
+                        float* grad_scratch, int32_t prezeroed)
 {
     if (rows_total < 0 || W <= 0 || H <= 0) return fail(GHR_E_INVALID, "bad rows_total/W/H");
     hipStream_t s = (hipStream_t)stream;
@@ -467,10 +441,11 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
     carve_bin(align_base(bin_ws), (size_t)R, (size_t)T, &b);
     if (g_ev[2]) GHR_HIP(hipEventRecord(g_ev[2], s));
-    launch_k8((size_t)rows_total, (uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start, (const uint32_t*)b.point_list,
-              (const ghr::f4*)g.rec, background, (const float*)im.final_T, (const uint32_t*)im.n_contrib, dL_dpix,
-              (const ghr::rect4*)g.rects, grad_scratch, R, (const unsigned long long*)b.cell_mask,
-              (const uint32_t*)im.cell_last, take_zeroed(bin_ws, grad_scratch));
+    if (launch_k8((size_t)rows_total, (uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
+                  (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, background, (const float*)im.final_T,
+                  (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0))
+        return fail(GHR_E_INVALID, GHR_E_DETERMINISTIC_MSG);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);
 }
@@ -514,7 +489,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
-                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag)
+                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag, int32_t prezeroed)
 {
     if (!m) return fail(GHR_E_INVALID, "ghr_model_args is NULL");
     if (m->row0 != 0) return fail(GHR_E_INVALID, "ghr_model_backward: row0 must be 0 (use the segment calls)");
@@ -522,7 +497,7 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
     if (!dL_dpix || (R > 0 && (!grad_scratch || !bin_ws)) || !img_ws || !m->background)
         return fail(GHR_E_INVALID, "ghr_model_backward: NULL buffer");
     if (int rc = ghr_render_backward(stream, m->P, m->W, m->H, R, m->background, geom_ws, img_ws, bin_ws, dL_dpix,
-                                     grad_scratch))
+                                     grad_scratch, prezeroed))
         return rc;
     return ghr_model_backward_segment(stream, m, m->P, radii, geom_ws, grad_scratch, d_means2D, d_xyz, d_log_scales,
                                       d_rotations, d_opacity_logit, d_label_logit, d_orient_conf_log, d_features_dc,

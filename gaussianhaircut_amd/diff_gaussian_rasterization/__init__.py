@@ -161,15 +161,19 @@ def run_stage2(dev, P, pinned, launch, defer=False):
 
 def rasterize_gaussians(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         conics_precomp, raster_settings):
+    # autograd.Function.forward always runs with grad mode off and ctx.needs_input_grad ignores torch.no_grad(): whether
+    # a backward pass can follow is decided here, outside (an eval render must not allocate and zero gradient lines)
     return _RasterizeGaussians.apply(means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, conics_precomp, raster_settings)
+                                     cov3Ds_precomp, conics_precomp, raster_settings, torch.is_grad_enabled())
 
 
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D_precomp, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                conics_precomp, raster_settings):
+                conics_precomp, raster_settings, grad_enabled=None):
         rs = raster_settings
+        ctx.n_inputs = 10 if grad_enabled is None else 11  # the reference's ten arguments (+ ours)
+        grad_enabled = True if grad_enabled is None else bool(grad_enabled)
         L = _lib.lib()
         if means3D.dim() != 2 or means3D.size(1) != 3:
             raise RuntimeError("means3D must have dimensions (num_points, 3)")  # rasterize_points.cu:59-61
@@ -218,7 +222,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(L.ghr_forward_stage1(_stream(), ctypes.byref(args), _ptr(geomBuffer), _ptr(imgBuffer),
                                                 _ptr(radii), ctypes.c_void_p(pinned.data_ptr())))
 
-                want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+                want_grad = grad_enabled and any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
                 f32 = dict(dtype=torch.float32, device=dev)
 
                 def launch(cap):
@@ -240,6 +244,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.bin_cap = bin_cap  # layout of binningBuffer
+        ctx.scratch_clean = ctx.scratch is not None  # stage 2 zeroed its lines and nothing has touched them since
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         # same tuple as the reference (__init__.py:102); tensors are the contiguous fp32 versions the kernels read
@@ -277,6 +282,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             scratch = getattr(ctx, "scratch", None)  # one line per instance; zeroed by the forward pass if it made it
             if scratch is None:
                 scratch = torch.empty((max(int(num_rendered), 1), _lib.GRAD_STRIDE), **f32)
+            # include/ghr.h, ghr_backward: only the FIRST backward over the lines stage 2 zeroed may say so
+            prezeroed = int(bool(getattr(ctx, "scratch_clean", False)))
+            ctx.scratch_clean = False
             dL = grad_out_color
             if dL.dtype != torch.float32:
                 dL = dL.float()
@@ -296,7 +304,8 @@ class _RasterizeGaussians(torch.autograd.Function):
                                               _ptr(geomBuffer), _ptr(imgBuffer), _ptr(binningBuffer), _ptr(dL),
                                               _ptr(scratch), _ptr(grad_means2D), _ptr(grad_conic),
                                               _ptr(grad_opacities), _ptr(grad_colors_precomp), _ptr(grad_means3D),
-                                              _ptr(grad_cov3Ds_precomp), _ptr(grad_scales), _ptr(grad_rotations)))
+                                              _ptr(grad_cov3Ds_precomp), _ptr(grad_scales), _ptr(grad_rotations),
+                                              prezeroed))
             except Exception as ex:
                 if cpu_args is not None:
                     torch.save(cpu_args, "snapshot_bw.dump")
@@ -320,8 +329,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             opt(grad_cov3Ds_precomp, cov3Ds_precomp),
             opt(grad_conics_precomp, conics_precomp),
             None,
+            None,
         )
-        return grads
+        return grads[:ctx.n_inputs]
 
 
 class GaussianRasterizationSettings(NamedTuple):

@@ -58,7 +58,8 @@ class _RenderModelFused(torch.autograd.Function):
             va.background = _ptr(bg)
             va.debug = int(bool(cfg["debug"]))
 
-            want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+            want_grad = (cfg.get("grad_enabled", True) and any(ctx.needs_input_grad) and
+                         not os.environ.get("GHR_NO_PREZERO"))
 
             def launch(cap):
                 b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
@@ -73,6 +74,7 @@ class _RenderModelFused(torch.autograd.Function):
             R, cap, (binb, ctx.scratch) = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
         cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
+        ctx.scratch_clean = ctx.scratch is not None  # zeroed under stage 2's tile sort, untouched since
         # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
         # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
@@ -115,6 +117,9 @@ class _RenderModelFused(torch.autograd.Function):
                 rows = max(int(R), 1) if isinstance(R, int) else max(int(ctx.cap), 1)
                 scratch = torch.empty((rows, _lib.GRAD_STRIDE), **f32)
             rows = scratch.shape[0]
+            # include/ghr.h, ghr_backward: only the FIRST backward over the lines stage 2 zeroed may say so
+            prezeroed = int(bool(getattr(ctx, "scratch_clean", False)))
+            ctx.scratch_clean = False
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
@@ -127,7 +132,7 @@ class _RenderModelFused(torch.autograd.Function):
                 # the shared gradient buffer is ordered after the previous view's
                 stream = torch.cuda.current_stream()
                 _lib.check(L.ghr_render_backward(_stream(), P, cfg["W"], cfg["H"], ctx.cap, _ptr(bg), _ptr(geom),
-                                                 _ptr(img), _ptr(binb), _ptr(dL), _ptr(scratch)))
+                                                 _ptr(img), _ptr(binb), _ptr(dL), _ptr(scratch), prezeroed))
                 sink.accumulate_begin(stream)
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
@@ -140,7 +145,7 @@ class _RenderModelFused(torch.autograd.Function):
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
                                                 _ptr(d_fdc), _ptr(d_frest), acc if direct else 0,
-                                                sink.nan_flag_ptr() if direct else None))
+                                                sink.nan_flag_ptr() if direct else None, prezeroed))
         if direct:
             sink.note_direct_backward()
             return None, None, None, None, None, None, None, None, d_m2d, None
@@ -161,7 +166,8 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
                proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
                tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
-               conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug), defer_count=bool(defer_count))
+               conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug), defer_count=bool(defer_count),
+               grad_enabled=torch.is_grad_enabled())  # (inside Function.forward grad mode is always off)
     from ..optim import FusedAdam
     opt = getattr(pc, "optimizer", None)
     if isinstance(opt, FusedAdam) and opt.direct_grads:
@@ -232,7 +238,8 @@ class _RenderHairFused(torch.autograd.Function):
             va.background = _ptr(cam_t[3])
             va.debug = int(bool(cfg["debug"]))
 
-            want_grad = any(ctx.needs_input_grad) and not os.environ.get("GHR_NO_PREZERO")
+            want_grad = (cfg.get("grad_enabled", True) and any(ctx.needs_input_grad) and
+                         not os.environ.get("GHR_NO_PREZERO"))
 
             def launch(cap):
                 b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
@@ -248,6 +255,7 @@ class _RenderHairFused(torch.autograd.Function):
             screenspace_points.detach().copy_(torch.cat([m2d_ws[:n_head], m2d_ws[row0:]]))
         LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(rows)
         ctx.cfg, ctx.R, ctx.K, ctx.cap, ctx.dims = cfg, R, K, cap, (n_head, n_hair, row0, rows)
+        ctx.scratch_clean = ctx.scratch is not None
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t,
@@ -274,13 +282,15 @@ class _RenderHairFused(torch.autograd.Function):
             scratch = getattr(ctx, "scratch", None)  # made (and zeroed) by the forward pass when it knew of a backward
             if scratch is None:
                 scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)
+            prezeroed = int(bool(getattr(ctx, "scratch_clean", False)))
+            ctx.scratch_clean = False
             dL = grad_color.float().contiguous()
             hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
             m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, [view, proj, campos, bg], cfg,
                                cfg["eps_hair"], (1.0, 1.0, 0.0))
             if rows > 0:
                 _lib.check(L.ghr_render_backward(_stream(), rows, W, H, ctx.cap, _ptr(bg), _ptr(geom), _ptr(img),
-                                                 _ptr(binb), _ptr(dL), _ptr(scratch)))
+                                                 _ptr(binb), _ptr(dL), _ptr(scratch), prezeroed))
             if n_hair > 0:
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
@@ -319,7 +329,7 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
                sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier),
                tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
                eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
-               debug=bool(debug))
+               debug=bool(debug), grad_enabled=torch.is_grad_enabled())
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
                                             pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
                                             screenspace_points, head, cfg)

@@ -180,6 +180,12 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     else:
         total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
     if isinstance(gaussians.optimizer, FusedAdam):
+        # Every backward of this step ran AFTER any earlier optimizer surgery (densification / opacity reset between two
+        # calls), so all groups hold fresh gradients: the "parameters replaced since the last backward" marks never apply
+        # here, whichever path produced the gradients (generic pipe, autograd accumulation, a rank without views).  They
+        # only matter for a hand-written loop that runs backward -> surgery -> step (the reference's order), which calls
+        # optimizer.step() itself.  Unconditional, hence identical on every rank.
+        gaussians.optimizer.cancel_skip()
         # SH bands above the active degree carry exactly-zero gradients on every rank: not part of the all-reduce
         gaussians.optimizer.active_rest_coeffs = (int(gaussians.active_sh_degree) + 1) ** 2 - 1
         # grads already live in the optimizer's flat buffer; NaN guard + Adam + grad zeroing are one HIP pass
@@ -206,30 +212,21 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         bad = torch.stack([p.grad.isnan().any() for p in gaussians.leaf_parameters() if p.grad is not None]).any()
     # train_gaussians.py:174-181: a NaN anywhere skips the update -- the reference drops the gradients
     # (zero_grad(set_to_none=True)), so optimizer.step() touches nothing: no moment decay, no step count.
+    # One host decision per step, like the reference's `if torch.isnan(...)` (the torch.optim.Adam path is not the measured
+    # one; round 2's clone-everything-and-restore variant tripled the optimizer traffic and still synchronised on Adam's
+    # CPU-resident step counters).
+    if bool(bad):
+        print('NaN during backprop was found, skipping iteration...')
+        if bucket is not None:
+            # the gradients alias the bucket and cannot be dropped to None: a step over zeroed gradients would still decay
+            # the moments and move the parameters by lr m / sqrt(v) -- skip the whole step, as the reference's does in effect
+            bucket.zero()
+            return total
+        gaussians.optimizer.zero_grad(set_to_none=True)
+    gaussians.optimizer.step()
     if bucket is not None:
-        # device-side and sync-free: take the step, then put parameters and optimizer state back where `bad` is set
-        # (a zeroed gradient is NOT a skip for Adam: the moments would decay and the parameters drift by lr m / sqrt(v))
-        params = [p for g in gaussians.optimizer.param_groups for p in g["params"]]
-        snap = []
-        for p in params:
-            st = gaussians.optimizer.state.get(p, {})
-            snap.append((p.detach().clone(), {k: v.clone() for k, v in st.items() if isinstance(v, torch.Tensor)}))
-        torch.nan_to_num_(bucket.flat, nan=0.0)
-        gaussians.optimizer.step()
-        for p, (p0, st0) in zip(params, snap):
-            p.data.copy_(torch.where(bad, p0, p.data))
-            st = gaussians.optimizer.state.get(p, {})
-            for k, v0 in st0.items():
-                st[k].copy_(torch.where(bad, v0, st[k]))
-            for k, v in st.items():  # state created by this very step (first step): back to its initial value
-                if isinstance(v, torch.Tensor) and k not in st0:
-                    v.copy_(torch.where(bad, torch.zeros_like(v), v))
         bucket.zero()
     else:
-        if bool(bad):
-            gaussians.optimizer.zero_grad(set_to_none=True)
-            print('NaN during backprop was found, skipping iteration...')
-        gaussians.optimizer.step()
         gaussians.optimizer.zero_grad(set_to_none=True)
     return total
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 12
+#define GHR_ABI_VERSION 13
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -97,15 +97,21 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
  * (no GPU bubble behind the host round trip) and relaunch it only if the true count turned out larger: instances
  * beyond the capacity are dropped without touching memory outside bin_ws.  Stage 2 may be replayed.
  * grad_scratch (ABI 12, may be NULL): the scratch the backward call over this state will be given (>= R lines).  Its
- * lines are then zeroed here, under the tile sort, and the first ghr_backward / ghr_render_backward with this bin_ws and
- * this scratch skips its own zero-fill (the library remembers the pair; any other backward zeroes for itself). */
+ * lines are then zeroed here, under the tile sort, so that the backward call can be told `prezeroed` (below). */
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
                        float* out_color, float* grad_scratch);
 
 /* Backward (K8 + K9 + K10).  dL_dpix is [C,H,W].  R: the capacity stage 2 was run with (layout of bin_ws).
  * grad_scratch: GHR_GRAD_STRIDE floats (one 64-B gradient line) per Gaussian-tile instance actually reported by stage 1
- * (may be NULL when that count is 0), uninitialised on entry: every line is zero-filled and accumulated by K8 and the
- * lines of a Gaussian are summed in a fixed order -- no cross-tile float atomics.  A caller that launched stage 2
+ * (may be NULL when that count is 0): every line is zero-filled and accumulated by K8 and the lines of a Gaussian are
+ * summed in a fixed order -- no cross-tile float atomics.
+ * prezeroed (ABI 13; the library keeps NO record of buffers -- it is stateless between calls): 0 = grad_scratch is
+ * uninitialised, K8 zero-fills it.  != 0 = the CALLER guarantees that grad_scratch is exactly as
+ * ghr_forward_stage2(..., bin_ws, ..., grad_scratch) of THIS state left it: same scratch, zeroed under that stage 2's tile
+ * sort, and nothing written to it since -- in particular no other backward call (of this or any other state).  Sharing
+ * rule: when several states share one scratch buffer, at most the state whose stage 2 was the LAST to be handed the
+ * buffer may be backwarded with prezeroed != 0, and only as the first backward that touches the buffer after it; every
+ * other backward over the shared buffer passes 0.  A second backward over the same state passes 0.  A caller that launched stage 2
  * speculatively and has not read the count yet passes R lines instead: no line index >= R is ever touched, so a count
  * above the capacity (whose results the caller must discard and recompute) cannot write outside the buffer.
  * Outputs (all fully written, no pre-zeroing needed), shapes of rasterize_points.cu:160-168:
@@ -114,7 +120,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
 int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
                  const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
-                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations);
+                 float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed);
 
 /* ---- fused model path ------------------------------------------------------------------------
  * One kernel computes, from the RAW parameters of the reference's GaussianModel, everything render() would build with
@@ -182,7 +188,7 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
  * chain finds a Gaussian's lines through the index the tile sort left in bin_ws). */
 int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, uint32_t R, const float* background,
                         const void* geom_ws, const void* img_ws, const void* bin_ws, const float* dL_dpix,
-                        float* grad_scratch);
+                        float* grad_scratch, int32_t prezeroed /* see ghr_backward */);
 int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, const int32_t* radii,
                                const void* geom_ws, const float* grad_scratch, float* d_means2D, float* d_xyz,
                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, float* d_label_logit,
@@ -194,7 +200,8 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
                        float* d_opacity_logit, float* d_label_logit, float* d_orient_conf_log, float* d_features_dc,
-                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag);
+                       float* d_features_rest, int32_t accumulate, int32_t* nan_flag,
+                       int32_t prezeroed /* see ghr_backward */);
 
 /* ---- fused stage-1 loss (src/train_gaussians.py:126-140; src/utils/loss_utils.py:19-47,91-121) ----------------
  * loss = w_l1 * mean(|image-gt| * m) + w_ssim * (1 - mean(ssim(image*m, gt*m))) + w_mask * mean(|mask-gt_mask|)
@@ -268,7 +275,9 @@ int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, voi
 /* Debug aid (ABI 12; SURVEY.md 5: the reference has none -- its backward sums with float atomics in scheduling
  * order): on != 0 makes the gradient walk bit-reproducible from run to run.  One wave per tile then works the tile's
  * sixteen cells in index order, so the additions into a gradient line happen in one fixed order (the per-Gaussian sum
- * over lines is ordered anyway); about 3x the kernel time.  Process-wide, sticky; returns the previous setting. */
+ * over lines is ordered anyway); about 3x the kernel time.  Process-wide, sticky; returns the previous setting.  While it
+ * is on, a backward call at a size the ordered walk cannot address (>= 2^26 rows or instances) FAILS with GHR_E_INVALID
+ * instead of running unordered. */
 int ghr_set_deterministic(int32_t on);
 
 /* Self test of the wave-level primitives the scan form of the gradient walk is built from (16-lane DPP row scans,

@@ -93,7 +93,8 @@ class GpuRun:
             np.zeros(0, np.uint32),
         )
 
-    def backward(self, dL: torch.Tensor):
+    def backward(self, dL: torch.Tensor, scratch=None, prezeroed=0):
+        """scratch / prezeroed: see include/ghr.h, ghr_backward (default: a NaN-filled scratch the kernel zero-fills)."""
         P, dev = self.P, self.dev
         f = dict(dtype=torch.float32, device=dev)
         nan = float("nan")
@@ -101,13 +102,14 @@ class GpuRun:
                  dL_dopacity=torch.full((P, 1), nan, **f), dL_dcolors=torch.full((P, 10), nan, **f),
                  dL_dmeans3D=torch.full((P, 3), nan, **f), dL_dcov3D=torch.full((P, 6), nan, **f),
                  dL_dscales=torch.full((P, 3), nan, **f), dL_drotations=torch.full((P, 4), nan, **f))
-        scratch = torch.full((max(self.R, 1), 16), nan, **f)
+        if scratch is None:
+            scratch = torch.full((max(self.R, 1), 16), nan, **f)
         dL = dL.to(dev).float().contiguous()
         _lib.check(self.L.ghr_backward(_stream(), ctypes.byref(self.args), self.R, _ptr(self.radii), _ptr(self.geom),
                                        _ptr(self.img), _ptr(self.bin) if self.R else None, _ptr(dL), _ptr(scratch),
                                        _ptr(o["dL_dmeans2D"]), _ptr(o["dL_dconic"]), _ptr(o["dL_dopacity"]),
                                        _ptr(o["dL_dcolors"]), _ptr(o["dL_dmeans3D"]), _ptr(o["dL_dcov3D"]),
-                                       _ptr(o["dL_dscales"]), _ptr(o["dL_drotations"])))
+                                       _ptr(o["dL_dscales"]), _ptr(o["dL_drotations"]), int(prezeroed)))
         torch.cuda.synchronize()
         return {k: v.cpu().numpy() for k, v in o.items()}
 

@@ -587,3 +587,34 @@ def test_trainable_camera_takes_the_generic_path_and_keeps_its_gradients(monkeyp
     with torch.no_grad():
         render(_trainable_camera(spec, dev), _model(spec, dev, deg), FUSED, syn.background(dev))
     assert called
+
+
+@pytest.mark.parametrize("pipe", [FUSED, GENERIC])
+def test_training_step_after_surgery_is_not_a_skipped_step(pipe):
+    """ADVICE r2 (optim.py:146): densification / opacity reset mark every group "replaced since the last backward" so
+    that a hand-written backward -> surgery -> step loop passes the new parameters by like the reference does.  Inside
+    training_step the backward always follows the surgery, so the very next step must update -- also when the gradients
+    do not come through the fused direct backward (generic pipe)."""
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    from tests.test_reference_golden import _densify_sequence
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny"]
+    opt = OptimizationParams()
+    m, cam, bg = syn.make_model(spec, dev), syn.make_view(spec, dev), syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, [cam], bg)
+    m.training_setup(opt)
+    _densify_sequence(m, opt, dev)
+    torch.manual_seed(3)
+    m.densify_and_prune(opt.densify_grad_threshold, 0.005, 2.5, 20)
+    m.reset_opacity()
+    assert m.optimizer._skip_next != 0
+    before = m.optimizer.flat_param.clone()
+    step0 = int(m.optimizer.state_dev[0])
+    training_step(m, [cam], bg, opt, 5, pipe=pipe)
+    assert int(m.optimizer.state_dev[0]) == step0 + 1
+    assert int(m.optimizer.state_dev[2:2 + len(m.optimizer.param_groups)].abs().sum()) == 0  # no group sat the step out
+    assert (m.optimizer.flat_param != before).float().mean() > 0.2

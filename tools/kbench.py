@@ -39,7 +39,8 @@ def main():
         # scratch to stage 2 (zeroed under the tile sort) unless KBENCH_NO_PREZERO is set
         run = GpuRun(ri, "A", debug=False, scratch=None if os.environ.get("KBENCH_NO_PREZERO") else scratch)
         _lib.check(L.ghr_backward(_stream(), ctypes.byref(run.args), run.R, _ptr(run.radii), _ptr(run.geom),
-                                  _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o]))
+                                  _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o],
+                                  0 if os.environ.get("KBENCH_NO_PREZERO") else 1))
         torch.cuda.synchronize()
         if i >= 3:
             tf.append(ev[0].elapsed_time(ev[1]))
@@ -64,7 +65,7 @@ def main():
         buf = np.zeros((n_slots, 8), np.uint64)
         L.ghr_debug_prof(None, 0, 1)
         _lib.check(L.ghr_backward(_stream(), ctypes.byref(run.args), run.R, _ptr(run.radii), _ptr(run.geom),
-                                  _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o]))
+                                  _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o], 0))
         L.ghr_debug_prof(ctypes.c_void_p(buf.ctypes.data), n_slots, 0)
         v = buf.astype(np.float64)
         used = v[:, 6] > 0
