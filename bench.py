@@ -262,6 +262,52 @@ def main():
                                 "gaussians_per_sec": round(float(pv4.item()) / dt4, 1),
                                 "grad_steps_per_sec": round(1.0 / dt4, 3)}
 
+    # ---- N > 1: what the scaling curve is made of (VERDICT r2 next #6b).  Measured with HIP events on this rank's
+    # stream, max over ranks; outside the timed regions above (the buffers hold zeros: the values do not matter).
+    if world > 1 or os.environ.get("GHR_FORCE_COLLECTIVES") == "1":
+        o = model.optimizer
+        o.active_rest_coeffs = (int(model.active_sh_degree) + 1) ** 2 - 1
+        msg = sum((b - a) for a, b, how in o._reduce_plan(4) if how == "sum") + \
+            sum(how[1] * how[3] * 3 for a, b, how in o._reduce_plan(4) if isinstance(how, tuple))
+
+        def timed(fn, n=7):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            t = torch.tensor([ts[len(ts) // 2]], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+
+        ar_ms = timed(lambda: o.all_reduce())                                      # the gradient message alone
+        adam_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=False))  # the local update alone
+        both_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=True))   # as in the step: chunks overlapped
+        G = max(world, 1)
+        shard = out.get("config4_shard")
+        out["scaling"] = {
+            "figure": "config4_shard.gaussians_per_sec (BASELINE configs[3]: %d views per GPU per step, weak scaling): "
+                      "divide by N x the N = 1 run's config4_shard.gaussians_per_sec; the headline `value` is the "
+                      "1-view-per-GPU step of configs[2], whose weak-scaling ceiling is set by the 244 B per Gaussian "
+                      "gradient message (DESIGN.md 6)" % VS,
+            "config4_shard_gaussians_per_sec": shard["gaussians_per_sec"] if shard else None,
+            "config4_shard_ms_per_step": shard["ms_per_step"] if shard else None,
+            "headline_ms_per_step": round(ms_per_step, 4),
+            "all_reduce_ms": round(ar_ms, 4), "adam_ms": round(adam_ms, 4), "all_reduce_plus_adam_chunked_ms": round(both_ms, 4),
+            "message_bytes": int(4 * msg), "bytes_on_wire_per_gpu_ring": int(2 * (G - 1) / G * 4 * msg),
+            "bus_bandwidth_GBps": round(2 * (G - 1) / G * 4 * msg / (ar_ms * 1e-3) / 1e9, 2) if ar_ms > 0 and G > 1 else None,
+            "backend": dist.get_backend() if dist.is_initialized() else None, "replicas_identical": replicas_identical,
+            "note": "HIP events on the rank's stream, median of 7, max over ranks; no curve is computed here (the driver "
+                    "divides the per-N lines)"}
+
     if rank == 0 and world == 1:
         if not args.no_op_only:
             out["op_only"] = {c: op_only_bench(dev, c, iters=50 if c == "cfg2" else 30) for c in ("cfg2", "cfg3")}

@@ -32,9 +32,13 @@
 
 namespace ghr {
 
+#ifndef GHR_B3_SEG_WORDS
 #define GHR_B3_SEG_WORDS 8                       // mask words (of 64 list positions) expanded at a time
+#endif
 #define GHR_B3_LIST (64 * GHR_B3_SEG_WORDS)      // ... hence at most this many hits per segment
+#ifndef GHR_B3_CACHE
 #define GHR_B3_CACHE 2048                        // tiles with at most this many instances keep ids and masks in LDS
+#endif
 #define GHR_B3_CWORDS (GHR_B3_CACHE / 64)
 #define GHR_B3_NBUF 3                            // gather buffers per wave (chunk t, t+1, t+2)
 #ifndef GHR_B3_WAVES
@@ -237,6 +241,9 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 GHR_PROF(3);
                 GHR_PROF_COUNT(7, 1);
 
+#ifdef GHR_B3_NOARITH  // ablation (tools/kbench.py): the chunk's memory skeleton without its arithmetic
+                const f4 d = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * (uint32_t)m);
+#else
                 const bool valid = (uint32_t)m < cnt;
                 const uint32_t j = min((uint32_t)m, cnt - 1u);  // lanes past the end recompute the last entry, masked
                 // field f of entry j sits at float (f >> 2) * 64 + 4 j + (f & 3): quarter-major, see the gather
@@ -311,6 +318,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 db = mfma16(wB.x, phiW[2], db);
                 da = mfma16(wB.y, phiW[3], da);
                 const f4 d = da + db;
+#endif
                 // the gather of chunk t+2 goes out before this chunk's atomics (see GHR_VMCNT above)
                 if (SMALL && t + 2 < nch) issue(t + 2);
                 // a DPP row adds one whole 64-B line per register: resolved in this XCD's L2 (only this workgroup ever

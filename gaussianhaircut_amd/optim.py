@@ -18,6 +18,15 @@ from . import _lib
 from .diff_gaussian_rasterization import _ptr, _stream
 
 
+def collectives_on() -> bool:
+    """More than one rank -- or one rank with GHR_FORCE_COLLECTIVES=1, which sends every collective of the N > 1 path
+    through the backend anyway (tests/test_gpu_dist_shared.py: ONE rank on backend "nccl" = RCCL runs the init, the
+    async work handles and the stream ordering rules that gloo does not have, on a one-GPU box)."""
+    import os
+    return dist.is_available() and dist.is_initialized() and (
+        dist.get_world_size() > 1 or os.environ.get("GHR_FORCE_COLLECTIVES") == "1")
+
+
 _TORCH_ADAM_DEFAULTS = dict(weight_decay=0, amsgrad=False, maximize=False, foreach=None, capturable=False,
                             differentiable=False, fused=None, decoupled_weight_decay=False)
 
@@ -95,7 +104,7 @@ class FusedAdam:
 
     def all_reduce(self, average_over=None, async_op=False):
         work = None
-        if dist.is_initialized() and dist.get_world_size() > 1:
+        if collectives_on():
             if not async_op and self.active_rest_coeffs is not None:
                 for a, b, how in self._reduce_plan(1):  # inactive SH bands are not sent (see _reduce_plan)
                     if how == "sum":
@@ -278,7 +287,7 @@ class FusedAdam:
         self._direct_backwards = 0
         self._acc_event = None
         skip, self._skip_next = self._skip_next, 0
-        comm = reduce and dist.is_initialized() and dist.get_world_size() > 1
+        comm = reduce and collectives_on()
         plan = self._reduce_plan(chunks) if comm else [(a, b, "local") for a, b in self._chunk_ranges(chunks)]
         works = [None] * len(plan)
         if comm:

@@ -195,7 +195,8 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         # The choice below must be the same on every rank (it decides the sequence of collectives): it only depends on
         # the configuration (`fused_sink`), and a rank whose gradients did not all come through the direct backward
         # fails loudly instead of silently taking the other branch.
-        if _world_size() > 1 and fused_sink and OVERLAP_ALL_REDUCE_WITH_ADAM:
+        from .optim import collectives_on
+        if collectives_on() and fused_sink and OVERLAP_ALL_REDUCE_WITH_ADAM:
             if not direct_local:
                 raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
                                    (gaussians.optimizer._direct_backwards, len(cams)))
@@ -203,7 +204,7 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
             gaussians.optimizer.step_chunked(chunks=4, zero_grad=True, reduce=True)
             return total
         gaussians.optimizer.all_reduce()
-        gaussians.optimizer.step(zero_grad=True, nan_scan=not (direct_local and _world_size() == 1))
+        gaussians.optimizer.step(zero_grad=True, nan_scan=not (direct_local and not collectives_on()))
         return total
     if bucket is not None:
         bucket.all_reduce()
