@@ -293,7 +293,7 @@ def main():
         both_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=True))   # as in the step: chunks overlapped
         G = max(world, 1)
         shard = out.get("config4_shard")
-        out["scaling"] = {
+        out["scaling_breakdown"] = {
             "figure": "config4_shard.gaussians_per_sec (BASELINE configs[3]: %d views per GPU per step, weak scaling): "
                       "divide by N x the N = 1 run's config4_shard.gaussians_per_sec; the headline `value` is the "
                       "1-view-per-GPU step of configs[2], whose weak-scaling ceiling is set by the 244 B per Gaussian "
