@@ -71,6 +71,29 @@ __device__ __forceinline__ void gather16_to_lds(const void* base, uint32_t byte_
 }
 #define GHR_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
+// LDS byte address of an object in __shared__ memory
+template <typename T>
+__device__ __forceinline__ uint32_t lds_addr(T* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)p;
+}
+// atomicAdd(lds word, 1) by lane 0 only, result broadcast.  Written in asm: in front of the C++ atomic the compiler puts
+// s_waitcnt vmcnt(0) (it cannot tell the LDS-DMA gathers in flight from the word), which drained the wave's outstanding
+// line atomics and gathers at every cell draw.
+__device__ __forceinline__ uint32_t lds_draw(uint32_t addr)
+{
+    uint32_t ret, one = 1u;
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(ret), "=&s"(saved)
+                 : "v"(addr), "v"(one));   // (no "memory": the word is touched by nothing else between two barriers)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)ret);
+}
+
 struct B3Shared {
     uint32_t id[GHR_B3_CACHE];                         // tile: Gaussian of each list position (tiles of <= GHR_B3_CACHE)
     unsigned long long mask[GHR_B3_CWORDS][16];        // tile: mask words, [word][cell]
@@ -108,9 +131,13 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 #endif
 
     for (;;) {
+#ifdef GHR_B3_CXX_DRAW
         uint32_t cell = 0u;
         if (lane == 0) cell = atomicAdd(&sh.next, 1u);
         cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
+#else
+        const uint32_t cell = lds_draw(lds_addr(&sh.next));
+#endif
         if (cell >= 16u) break;
         // positions at or beyond the cell's largest n_contrib are dead for all its pixels (backward.cu:490-492)
         const uint32_t gm = min(sh.clast[cell], n);

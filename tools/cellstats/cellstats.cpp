@@ -20,7 +20,8 @@ extern "C" {
 // out[0..]: see run.py.  hist_cons / hist_exact: 130 bins of hits per cell (0..128, 129 = more)
 void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* point_list, const float* xy /*[P][2]*/,
                const float* conic_opacity /*[P][4]*/, const uint32_t* n_contrib /*[H*W]*/, double* out,
-               uint64_t* hist_cons, uint64_t* hist_exact, uint64_t* hist_pix /*17 bins: pixels per exact hit*/)
+               uint64_t* hist_cons, uint64_t* hist_exact, uint64_t* hist_pix /*17 bins: pixels per exact hit*/,
+               uint16_t* cell_hits /*[T][16] or NULL: stored-mask hits per cell*/)
 {
     using namespace ghr;
     const int gx = (W + 15) / 16, gy = (H + 15) / 16, T = gx * gy;
@@ -85,6 +86,7 @@ void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* 
             }
             for (int r = 0; r < 8; r++) he8[r] += ex8[r];
         }
+        if (cell_hits) for (int c = 0; c < 16; c++) cell_hits[(size_t)tile * 16 + c] = (uint16_t)(hc[c] > 65535u ? 65535u : hc[c]);
         uint32_t sc = 0, se = 0;
         for (int band = 0; band < 4; band++) {
             uint32_t bc = 0, be = 0;

@@ -49,7 +49,7 @@ def main():
         p = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
         ranges = np.ascontiguousarray(st.ranges, np.uint32)
         L.cellstats(ctypes.c_int(spec.W), ctypes.c_int(spec.H), p(ranges), p(st.point_list), p(st.xy),
-                    p(st.conic_opacity), p(st.n_contrib), p(res), p(hc), p(he), p(hp))
+                    p(st.conic_opacity), p(st.n_contrib), p(res), p(hc), p(he), p(hp), ctypes.c_void_p(0))
         r = dict(zip(NAMES, res))
         R = st.num_rendered
         print("== %s  P=%d  R=%d  tiles with work=%d" % (spec.name, st.P, R, int((ranges[:, 1] > ranges[:, 0]).sum())))
