@@ -119,8 +119,11 @@ def inspect_fused(renders_packed, P, W, H, R):
     tensors its autograd node saved (gaussian_renderer/fused.py: ..., radii, geom, img, binb)."""
     saved = renders_packed.grad_fn.saved_tensors
     radii, geom, img, binb = saved[-4], saved[-3], saved[-2], saved[-1]
+    # the binning workspace is laid out by the CAPACITY stage 2 ran with (a speculative launch uses the previous frames'
+    # guess, include/ghr.h), which the autograd node remembers; R itself only bounds what is read back
+    cap = int(getattr(renders_packed.grad_fn, "cap", R))
     v = _lib.WsView()
-    _lib.check(_lib.lib().ghr_ws_inspect(P, W, H, 0, R, _ptr(geom), _ptr(img), _ptr(binb) if R else None,
+    _lib.check(_lib.lib().ghr_ws_inspect(P, W, H, 0, cap, _ptr(geom), _ptr(img), _ptr(binb) if R else None,
                                          ctypes.byref(v)))
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     return dict(

@@ -31,6 +31,7 @@ class _OracleRasterize(torch.autograd.Function):
                                                   rs.image_height, rs.image_width, **kw)
         ctx.st, ctx.rs, ctx.kw = st, rs, kw
         LAST["state"] = st  # tests that compare stage by stage read the oracle's K1 / binning / K7 state here
+        LAST["colors"] = _np(colors)
         ctx.save_for_backward(means3D, colors, scales, rotations, cov3D, conic)
         r = torch.from_numpy(radii)
         ctx.mark_non_differentiable(r)
