@@ -26,8 +26,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libghr_oracle.so")
+_SO64 = os.path.join(_HERE, "_build", "libghr_oracle64.so")  # the compositing walk in double (ghr_oracle64.c)
 _SRC = os.path.join(_HERE, "ghr_oracle.c")
 _lib = None
+_lib64 = None
 
 NUM_CHANNELS = 10  # R:cuda_rasterizer/config.h:15
 FRAG_EPS = 2e-5  # relative decision margin used to flag "fragile" pixels (see ghro_render_forward)
@@ -35,7 +37,7 @@ FRAG_EPS = 2e-5  # relative decision margin used to flag "fragile" pixels (see g
 
 def build(force: bool = False) -> str:
     """Compile the C oracle with gcc (recipe: oracle/Makefile)."""
-    stale = (not os.path.exists(_SO)) or os.path.getmtime(_SO) < os.path.getmtime(_SRC)
+    stale = any((not os.path.exists(so)) or os.path.getmtime(so) < os.path.getmtime(_SRC) for so in (_SO, _SO64))
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
     return _SO
@@ -221,3 +223,49 @@ def mark_visible(means3D, viewmatrix, projmatrix):
 
 def num_threads() -> int:
     return int(lib().ghro_num_threads())
+
+
+# ---- the compositing walk in IEEE double (ghr_oracle64.c): arbiter between two fp32 implementations ---------------
+def lib64() -> ctypes.CDLL:
+    global _lib64
+    if _lib64 is None:
+        build()
+        _lib64 = ctypes.CDLL(_SO64)
+    return _lib64
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def render_forward64(ranges, point_list, xy, features, conic_opacity, bg, H, W):
+    """K7 in double over GIVEN lists (normally the fp32 oracle's).  Returns (out[C,H,W], final_T[N], n_contrib[N])."""
+    L = lib64()
+    features = _f64(features)
+    C = features.shape[1]
+    out = np.zeros((C, H, W), np.float64)
+    final_T = np.zeros(H * W, np.float64)
+    n_contrib = np.zeros(H * W, np.uint32)
+    plist = point_list if point_list.size else np.zeros(1, np.uint32)
+    L.ghro64_render_forward(ctypes.c_int(W), ctypes.c_int(H), ctypes.c_int(C), _p(np.ascontiguousarray(ranges, np.uint32)),
+                            _p(plist), _p(_f64(xy)), _p(features), _p(_f64(conic_opacity)), _p(_f64(bg)), _p(out),
+                            _p(final_T), _p(n_contrib), ctypes.c_void_p(0), ctypes.c_double(0.0))
+    return out, final_T, n_contrib
+
+
+def render_backward64(ranges, point_list, bg, xy, conic_opacity, colors, final_T, n_contrib, dL_dout, H, W):
+    """K8 in double.  Returns dict(dL_dmeans2D[P,3], dL_dconic[P,2,2], dL_dopacity[P,1], dL_dcolors[P,C])."""
+    L = lib64()
+    colors = _f64(colors)
+    P, C = colors.shape
+    g_mean2D = np.zeros((P, 3), np.float64)
+    g_conic = np.zeros((P, 4), np.float64)
+    g_opac = np.zeros((P, 1), np.float64)
+    g_col = np.zeros((P, C), np.float64)
+    plist = point_list if point_list.size else np.zeros(1, np.uint32)
+    L.ghro64_render_backward(ctypes.c_int(P), ctypes.c_int(W), ctypes.c_int(H), ctypes.c_int(C),
+                             _p(np.ascontiguousarray(ranges, np.uint32)), _p(plist), _p(_f64(bg)), _p(_f64(xy)),
+                             _p(_f64(conic_opacity)), _p(colors), _p(_f64(final_T)),
+                             _p(np.ascontiguousarray(n_contrib, np.uint32)), _p(_f64(dL_dout)), _p(g_mean2D), _p(g_conic),
+                             _p(g_opac), _p(g_col))
+    return dict(dL_dmeans2D=g_mean2D, dL_dconic=g_conic.reshape(P, 2, 2), dL_dopacity=g_opac, dL_dcolors=g_col)

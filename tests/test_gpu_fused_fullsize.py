@@ -11,7 +11,9 @@ tile rect, cull): those Gaussians are COUNTED (bound 1e-4 of P) and the pixels o
 together with the oracle's fragile pixels (alpha / T within 2e-5 of a threshold); the mask is applied by giving those
 pixels zero weight in the loss on BOTH sides, which removes them exactly.  Everything else must agree:
 K1 state bit for bit (depth keys, pixel means) or to 1e-5 (conic, opacity), the sorted tile lists exactly, the image to
-1e-4, every raw-parameter gradient to 1e-4 * (|ref| + largest |ref| of its row) plus a floor for cancellation noise.
+1e-4, every raw-parameter gradient to 1e-4 * (|ref| + largest |ref| of its row) plus a floor for cancellation noise
+(leg A: seeded random dL/dout).  Leg B (the real stage-1 loss) is arbitrated by the same chain evaluated in IEEE double
+(oracle/ghr_oracle64.c): |HIP - f64| <= 3 |oracle32 - f64| + the row criterion, for every element.
 """
 import math
 from types import SimpleNamespace
@@ -32,24 +34,10 @@ PARAMS = ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf",
 FLOOR = 2e-6  # of the tensor's largest |ref|: fp32 cancellation noise of rows whose own gradient is ~0
 
 
-def _row_close(a, b, tol=hp.TOL, floor=FLOOR, row_tol=None):
+def _row_close(a, b, tol=hp.TOL, floor=FLOOR):
     a, b = a.reshape(len(a), -1), b.reshape(len(b), -1)
     rows = np.abs(b).max(axis=1, keepdims=True)
-    t = tol if row_tol is None else row_tol.reshape(-1, 1)
-    return np.abs(a - b) <= t * (np.abs(b) + rows) + floor * np.abs(b).max()
-
-
-def _row_tolerance(model, conic_rel):
-    """Per-Gaussian tolerance for the smooth-loss leg.  The reference walks T <- T / (1 - alpha) (backward.cu:507) and
-    divides by (1 - alpha) again in dL/dalpha (:535-538): a relative difference eps in alpha comes out as
-    eps alpha / (1 - alpha) in every term the splat's brightest pixels contribute, up to 99 eps at the 0.99 clamp.  The
-    two chains' fp32 projections agree in the conic to `conic_rel` (measured above, ~2e-6), i.e. in alpha = o exp(power)
-    to |power| conic_rel <= ln(255) conic_rel inside the 1/255 contour.  With a random dL/dpixel (leg A) these errors
-    have random signs and vanish in the row sum; under a smooth loss they add up.  The bound is therefore
-    1e-4 + ln(255) conic_rel / (1 - min(0.99, opacity)): 1e-4 for faint splats, ~1.5e-3 for the opaque strand Gaussians
-    (opacity 0.999) -- the conditioning of the fp32 algorithm, not a property of either implementation."""
-    op = model.get_opacity.detach().cpu().numpy().reshape(-1).astype(np.float64)
-    return hp.TOL + math.log(255.0) * conic_rel / (1.0 - np.minimum(0.99, op))
+    return np.abs(a - b) <= tol * (np.abs(b) + rows) + floor * np.abs(b).max()
 
 
 def _assert_rows(name, a, b, tol=hp.TOL, floor=FLOOR):
@@ -254,24 +242,39 @@ def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg):
     print("fullsize", cfg, stats, flush=True)
     assert stats["dL_err_of_max"] < 1e-4, stats
     gc, gg = _grads(mc, pc), _grads(mg, pg)
-    # Primary criterion: the conditioning-aware per-row tolerance.  It accounts for a Gaussian's OWN opacity only; the
-    # transmittance in front of it is a product over the other splats of its rays, each contributing its own
-    # eps alpha / (1 - alpha).  Elements beyond the row tolerance are therefore counted, not ignored: at most 1e-4 of a
-    # tensor (measured: 7e-5 on the 100k overlapping blobs of cfg2, 0 .. 3e-6 on the strand models), none further than
-    # 20 x the row tolerance (+ the cancellation floor).
-    bad, outliers = {}, {}
-    row_tol = _row_tolerance(mc, stats["conic_rel"])
+    # ---- the arbiter: the SAME chain evaluated in IEEE double -- PyTorch projection in float64 from
+    # the same raw parameters, the oracle's compositing walk compiled in double (oracle/ghr_oracle64.c) over the fp32
+    # oracle's lists, the same loss in double, the same masked pixels.  The reference's T <- T / (1 - alpha) turns a
+    # relative difference eps in alpha into eps alpha / (1 - alpha) (x 99 at the clamp), which a smooth loss sums
+    # coherently: two fp32 chains may differ by 1e-3 of a row there and both be right.  Round 2 argued that with a
+    # conditioning-aware tolerance; here it is measured: the HIP path must be no further from the double result than
+    # 3 x the fp32 oracle chain is, plus the 1e-4 row criterion (+ the cancellation floor) -- for EVERY element.
+    from tests import oracle_backend as ob
+    st32 = ob.LAST["state"]
+    m64, c64 = ob.double_chain(mc, cc, mc.filter_points(cc))
+    with ob.oracle_rasterizer64(st32):
+        p64 = render(c64, m64, GENERIC, syn.background("cpu").double())
+    okpx = ~mask.numpy().reshape(-1)
+    assert (ob.LAST["n_contrib64"][okpx] == st32.n_contrib[okpx]).all(), "the double walk took other decisions"
+    packed_64 = torch.where(mask[None], frozen.double(), p64.renders_packed)
+    loss_64 = view_loss(_package(packed_64, p64["viewspace_points"], p64["radii"]), c64, opt, fused=False)
+    assert abs(float(loss_64.detach()) - float(loss_c.detach())) <= 2e-5 * abs(float(loss_64.detach()))
+    loss_64.backward()
+    g64 = {n: getattr(m64, n).grad.detach().numpy() for n in PARAMS}
+    g64["viewspace"] = p64["viewspace_points"].grad.detach().numpy()
+    bad, worst = {}, {}
     for k in gc:
-        ok = _row_close(gg[k], gc[k], row_tol=row_tol)
-        if not ok.all():
-            ok20 = _row_close(gg[k], gc[k], row_tol=20 * row_tol, floor=20 * FLOOR)
-            a2, b2 = gg[k].reshape(len(gg[k]), -1), gc[k].reshape(len(gc[k]), -1)
-            r, c = np.unravel_index(np.argmax(np.abs(a2 - b2) * ~ok), ok.shape)
-            rec = (int((~ok).sum()), int(r), int(c), float(a2[r, c]), float(b2[r, c]), float(np.abs(b2[r]).max()),
-                   float(np.abs(b2).max()))
-            outliers[k] = rec
-            if (~ok).sum() > max(1, int(1e-4 * ok.size)) or not ok20.all():
-                bad[k] = rec
-    print("fullsize", cfg, "legB outliers (count, row, col, got, ref, row max, tensor max):", outliers, flush=True)
-    assert not bad, bad
-    print("fullsize", cfg, stats, "loss", float(loss_c))
+        a, b, r = (x.reshape(len(x), -1).astype(np.float64) for x in (gg[k], gc[k], g64[k]))
+        rows = np.abs(r).max(axis=1, keepdims=True)
+        bar = 3.0 * np.abs(b - r) + hp.TOL * (np.abs(r) + rows) + FLOOR * np.abs(r).max()
+        off = np.abs(a - r) > bar
+        # how far each fp32 chain is from the double one, in units of the plain row criterion (reported, not judged)
+        unit = hp.TOL * (np.abs(r) + rows) + FLOOR * np.abs(r).max()
+        worst[k] = (float((np.abs(a - r) / unit).max()), float((np.abs(b - r) / unit).max()))
+        if off.any():
+            i, j = np.unravel_index(np.argmax(np.abs(a - r) - bar), off.shape)
+            bad[k] = (int(off.sum()), int(i), int(j), float(a[i, j]), float(b[i, j]), float(r[i, j]), float(rows[i, 0]))
+    print("fullsize", cfg, "legB distance from the double chain in units of the 1e-4 row criterion (HIP, fp32 oracle chain):",
+          {k: (round(v[0], 2), round(v[1], 2)) for k, v in worst.items()}, flush=True)
+    assert not bad, "further from the double chain than 3 x the fp32 oracle chain + 1e-4 (count, row, col, HIP, oracle32, f64, row max): %s" % bad
+    print("fullsize", cfg, stats, "loss", float(loss_c.detach()))

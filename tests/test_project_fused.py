@@ -71,16 +71,16 @@ def test_fused_projection_forward_and_backward(hostsim, cfg, deg):
     pix = np.stack([((means2D[:, 0].detach().numpy() + 1) * W - 1) * 0.5,
                     ((means2D[:, 1].detach().numpy() + 1) * H - 1) * 0.5], -1)
 
-    def close(x, ref, tol=2e-4):
+    def close(x, ref, tol=5e-6):
         x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
         err = np.abs(x - ref) / (np.abs(ref).max(axis=-1, keepdims=True) + 1e-6)
-        assert np.quantile(err, 0.999) < tol and err.max() < 50 * tol, (np.quantile(err, 0.999), err.max())
+        assert err.max() < tol, err.max()   # every element (measured: <= 1.2e-6)
 
-    close(m2d[:, :2], means2D[:, :2].detach().numpy(), 1e-5)
-    close(rec[both, 0:2], pix[both], 1e-5)
-    close(rec[both, 2:5], conic.detach().numpy()[both], 2e-3)  # fp32 cancellation in thin strands vs fp64
-    close(rec[both, 5:6], opac.detach().numpy()[both], 1e-5)
-    close(rec[both, 6:16], colors.detach().numpy()[both], 2e-4)
+    close(m2d[:, :2], means2D[:, :2].detach().numpy())
+    close(rec[both, 0:2], pix[both])
+    close(rec[both, 2:5], conic.detach().numpy()[both])  # fp32 cancellation in thin strands vs fp64
+    close(rec[both, 5:6], opac.detach().numpy()[both])
+    close(rec[both, 6:16], colors.detach().numpy()[both])
 
     # ---- backward: random cotangents on (conic, mean2D, colours, opacity) of the visible Gaussians
     g = torch.Generator().manual_seed(17)
@@ -121,7 +121,7 @@ def test_fused_projection_forward_and_backward(hostsim, cfg, deg):
         rowscale = np.abs(r.reshape(P, -1)).max(axis=1, keepdims=True).reshape((P,) + (1,) * (r.ndim - 1))
         err = np.abs(got - r) / (rowscale + 1e-3 * scale)
         # fp32 kernel vs fp64 autograd: per-row relative; thin strands amplify rounding in the conic chain
-        assert np.quantile(err, 0.995) < 5e-3 and np.isfinite(got).all(), (k, np.quantile(err, 0.995), err.max())
+        assert err.max() < 1e-4 and np.isfinite(got).all(), (k, err.max())   # every element (measured: <= 1.5e-5)
     assert np.array_equal(outs["d_means2D"][:, :2], gacc[:, 0:2])
 
 
@@ -190,15 +190,15 @@ def test_fused_projection_explicit_mode_matches_strand_pipeline(hostsim):
     assert (vis == keep).mean() > 0.999 and vis.sum() > 100
     both = vis & keep
 
-    def close(x, ref, tol=2e-4):
+    def close(x, ref, tol=5e-6):
         x, ref = np.asarray(x, np.float64), np.asarray(ref, np.float64)
         err = np.abs(x - ref) / (np.abs(ref).max(axis=-1, keepdims=True) + 1e-6)
-        assert np.quantile(err, 0.999) < tol and err.max() < 50 * tol, (np.quantile(err, 0.999), err.max())
+        assert err.max() < tol, err.max()   # every element (measured: <= 1.2e-6)
 
-    close(m2d[:, :2], means2D[:, :2].detach().numpy(), 1e-5)
-    close(rec[both, 2:5], conic.detach().numpy()[both], 2e-3)
+    close(m2d[:, :2], means2D[:, :2].detach().numpy())
+    close(rec[both, 2:5], conic.detach().numpy()[both])
     assert np.all(rec[both, 5] == 1.0) and np.all(rec[both, 9] == 1.0) and np.all(rec[both, 10] == 1.0)
-    close(rec[both, 6:16], colors.detach().numpy()[both], 2e-4)
+    close(rec[both, 6:16], colors.detach().numpy()[both])
 
     # ---- backward
     g = torch.Generator().manual_seed(23)
@@ -236,4 +236,4 @@ def test_fused_projection_explicit_mode_matches_strand_pipeline(hostsim):
         scale = np.abs(r).max() + 1e-30
         rowscale = np.abs(r.reshape(P, -1)).max(axis=1, keepdims=True).reshape((P,) + (1,) * (r.ndim - 1))
         err = np.abs(got - r) / (rowscale + 1e-3 * scale)
-        assert np.quantile(err, 0.995) < 5e-3 and np.isfinite(got).all(), (k, np.quantile(err, 0.995), err.max())
+        assert err.max() < 1e-4 and np.isfinite(got).all(), (k, err.max())   # every element (measured: <= 1.5e-5)

@@ -42,12 +42,12 @@ def test_projection_helpers_match_reference(cfg):
         assert np.abs(m.cov2d.numpy() - ref2d).max() <= 2e-4 * np.abs(ref2d).max(axis=1, keepdims=True).max() + 1e-4
         refc = G[cfg + "/conic"]
         rel = np.abs(conic.numpy() - refc) / (np.abs(refc).max(axis=1, keepdims=True) + 1e-6)
-        assert np.quantile(rel, 0.999) < 5e-3
+        assert rel.max() < 1e-5, rel.max()   # every row (same torch ops as the reference's Python: 0 on the golden's machine)
         close(m.get_mean_2d(cam).numpy(), G[cfg + "/mean2d"], rtol=2e-5, atol=2e-6)
         close(m.get_depths(cam).numpy(), G[cfg + "/depths"])
         close(m.get_direction_2d(cam).numpy(), G[cfg + "/dir2d"], rtol=1e-4, atol=1e-4)
         mask = m.filter_points(cam).numpy()
-        assert (mask == G[cfg + "/mask"]).mean() > 0.999
+        assert (mask == G[cfg + "/mask"]).all()
         K = 16
         shs_view = m.get_features.transpose(1, 2).reshape(-1, 3, K)
         d = m.get_xyz - cam.camera_center[None]
@@ -100,11 +100,11 @@ def test_strand_model_matches_reference_strands_module():
         assert np.abs(m.cov2d.numpy() - ref2d).max() <= 2e-4 * np.abs(ref2d).max() + 1e-4
         refc = G["strands/conic"]
         rel = np.abs(conic.numpy() - refc) / (np.abs(refc).max(axis=1, keepdims=True) + 1e-6)
-        assert np.quantile(rel, 0.999) < 5e-3
+        assert rel.max() < 1e-5, rel.max()   # every row (same torch ops as the reference's Python: 0 on the golden's machine)
         close(m.get_mean_2d(cam).numpy(), G["strands/mean2d"], rtol=2e-5, atol=2e-6)
         close(m.get_depths(cam).numpy(), G["strands/depths"])
         close(m.get_direction_2d(cam).numpy(), G["strands/dir2d"], rtol=1e-4, atol=1e-4)
-        assert (m.filter_points(cam).numpy() == G["strands/mask"]).mean() > 0.999
+        assert (m.filter_points(cam).numpy() == G["strands/mask"]).all()
         close(m.get_opacity.numpy(), G["strands/opacity"])
         close(m.get_label.numpy(), G["strands/label"])
         close(m.get_orient_conf.numpy(), G["strands/orient_conf"])
