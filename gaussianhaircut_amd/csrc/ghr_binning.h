@@ -71,12 +71,22 @@ __device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* ds
 // tile_count[T] -> tile_start[T+1] (exclusive scan; tile_count is reset to 0 so k_scatter can reuse it as the per-tile
 // append cursor; publishes R = tile_start[T]) and, in place, slot_blk[nblk] -> exclusive prefix of the gradient slots
 // used by the K1 workgroups.
+// Also leaves tile_order[xcd_grid(T)] (round 3): the tile each workgroup of the tile sort and of K7 takes (K8 balances its
+// cells inside a tile and gains nothing: measured, MI355X, cfg3 / cfg5 / cfg2: K7 0.115 -> 0.100 / 0.320 -> 0.276 /
+// 0.131 -> 0.124 ms, K8 0.190 -> 0.189 / 0.499 -> 0.485 / 0.310 -> 0.313 ms; single-view step 0.930 -> 0.909 ms).
+// Workgroup b runs on XCD b % 8 and keeps the tiles xcd_tile() deals to that XCD (neighbouring tiles -- which share
+// Gaussians -- stay on one L2), but within the XCD the HEAVIEST lists go first (64 classes of n / 16, counting sort): a
+// launch is ~5 rounds of workgroups per CU and in raster order its last round is of average weight -- the model of
+// tools/cellstats/schedule_sim.py puts the launch at 1.16x (cfg3) / 1.10x (cfg2) of perfect packing, heaviest-first per
+// XCD at 1.09x / 1.04x.  The order inside a class comes from LDS atomics: it changes which workgroup takes a tile, never
+// a result.  Padding workgroups get 0xffffffff.
 __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
                                                               uint32_t* R_out, uint32_t* slot_blk, int nblk,
-                                                              uint32_t* R_mapped)
+                                                              uint32_t* R_mapped, uint32_t* tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
+    __shared__ uint32_t s_hist[8][64];
     const uint32_t total = scan_1024(T, tile_count, tile_start, true, s_part);
     if (threadIdx.x == 0) {
         tile_start[T] = total;
@@ -86,6 +96,36 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
         if (R_mapped) *R_mapped = total;
     }
     scan_1024(nblk, slot_blk, slot_blk, false, s_part);
+    if (tile_order) {
+        const uint32_t grid = xcd_grid((uint32_t)T);
+        for (uint32_t i = threadIdx.x; i < 8u * 64u; i += GHR_SCAN_BLOCK) (&s_hist[0][0])[i] = 0u;
+        __syncthreads();  // (also: tile_start[T] of thread 0 above is visible to the workgroup)
+        auto cls = [&](uint32_t t) -> uint32_t { return 63u - min((tile_start[t + 1] - tile_start[t]) >> 4, 63u); };
+        for (uint32_t b = threadIdx.x; b < grid; b += GHR_SCAN_BLOCK) {
+            const uint32_t t = xcd_tile(b, (uint32_t)T);
+            if (t < (uint32_t)T) atomicAdd(&s_hist[b & 7u][cls(t)], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 8 * 64) {  // wave x: exclusive scan of XCD x's 64 class counts -> first slot of each class
+            const int x = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            const uint32_t c = s_hist[x][lane];
+            uint32_t incl = c;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += v;
+            }
+            s_hist[x][lane] = incl - c;
+            // the XCD's slots behind its last tile belong to padding workgroups
+            if (lane == 63)
+                for (uint32_t k = incl; k < grid / 8u; k++) tile_order[8u * k + (uint32_t)x] = 0xffffffffu;
+        }
+        __syncthreads();
+        for (uint32_t b = threadIdx.x; b < grid; b += GHR_SCAN_BLOCK) {
+            const uint32_t t = xcd_tile(b, (uint32_t)T);
+            if (t < (uint32_t)T) tile_order[8u * atomicAdd(&s_hist[b & 7u][cls(t)], 1u) + (b & 7u)] = t;
+        }
+    }
 #endif
 }
 
@@ -206,10 +246,11 @@ GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* re
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                          uint32_t* tile_cursor, const rect4* __restrict__ rects,
-                                                         uint32_t* inst_line, int gx, float* ginst)
+                                                         uint32_t* inst_line, int gx, float* ginst,
+                                                         const uint32_t* __restrict__ tile_order)
 {
     __shared__ uint64_t s_keys[GHR_SORT_CAP];
-    const uint32_t tile = xcd_tile(blockIdx.x, T);
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T);  // heaviest first (k_tile_scan)
     if (tile >= T) return;  // grid padding
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;

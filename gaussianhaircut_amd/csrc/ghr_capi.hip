@@ -35,6 +35,18 @@ hipEvent_t g_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // fwd start/stop, b
 //       form's 32-bit byte offsets do not reach (b3_fits: >= 2^26 rows / instances).
 int g_deterministic = 0;  // ghr_set_deterministic
 
+// Which per-tile kernels take their tiles in k_tile_scan's heaviest-first order instead of the XCD-interleaved raster
+// order (xcd_tile): bit 0 tile sort, bit 1 K7, bit 2 K8.  GHR_TILE_ORDER=<mask> overrides (A/B knob, like GHR_K8).
+#ifndef GHR_TILE_ORDER_DEFAULT
+#define GHR_TILE_ORDER_DEFAULT 3
+#endif
+const uint32_t* order_ptr(const uint32_t* p, int bit)
+{
+    const char* e = std::getenv("GHR_TILE_ORDER");
+    const int mask = e ? std::atoi(e) : GHR_TILE_ORDER_DEFAULT;
+    return (mask >> bit) & 1 ? p : nullptr;
+}
+
 int k8_variant()
 {
     const char* e = std::getenv("GHR_K8");
@@ -44,7 +56,8 @@ int k8_variant()
 int launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint32_t T_tiles, const uint32_t* tile_start,
                const uint32_t* point_list, const ghr::f4* rec, const float* bg, const float* final_T,
                const uint32_t* n_contrib, const float* dL_dpix, const ghr::rect4* rects, float* ginst, uint32_t cap,
-               const unsigned long long* cell_mask, const uint32_t* cell_last, bool prezeroed)
+               const unsigned long long* cell_mask, const uint32_t* cell_last, bool prezeroed,
+               const uint32_t* tile_order)
 {
     const dim3 grid(ghr::xcd_grid(T)), block(GHR_BLOCK);
     int v = k8_variant();
@@ -57,7 +70,7 @@ int launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint
     case 2:
         hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic,
-                           prezeroed ? 1 : 0);
+                           prezeroed ? 1 : 0, tile_order);
         break;
     default:
         hipLaunchKernelGGL(ghr::k_render_bwd, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
@@ -109,6 +122,7 @@ struct Img {
     uint32_t* tile_start;  // [T+1]
     uint32_t* R_dev;
     uint32_t* cell_last;   // [16 T]: largest n_contrib of each 4x4-pixel cell
+    uint32_t* tile_order;  // [xcd_grid(T)]: tile of each workgroup of the per-tile kernels (k_tile_scan: heaviest first)
 };
 struct Bin {
     uint64_t* keys;
@@ -139,7 +153,8 @@ size_t carve_img(char* base, size_t N, size_t T, Img* im)
     uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
     uint32_t* R_dev = (uint32_t*)take(4);
     uint32_t* cell_last = (uint32_t*)take(T * 16 * 4);
-    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev, cell_last};
+    uint32_t* tile_order = (uint32_t*)take((size_t)ghr::xcd_grid((uint32_t)T) * 4);
+    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev, cell_last, tile_order};
     return off + ALIGN;
 }
 size_t carve_bin(char* base, size_t R, size_t T, Bin* b)
@@ -239,7 +254,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     hipLaunchKernelGGL(ghr::k_preprocess, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, pa);
     uint32_t* R_mapped = mapped_word(R_host);
     hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
-                       g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK, R_mapped);
+                       g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK, R_mapped, im.tile_order);
     if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, a->debug);
 }
@@ -278,12 +293,13 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
                                im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
         hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
-                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, grad_scratch);
+                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, grad_scratch,
+                           order_ptr(im.tile_order, 0));
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                        (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
-                       im.n_contrib, R, b.cell_mask, im.cell_last);
+                       im.n_contrib, R, b.cell_mask, im.cell_last, order_ptr(im.tile_order, 1));
     if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }
@@ -317,7 +333,8 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
         launch_k8((size_t)a->P, (uint32_t)T, s, a->W, a->H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
                   (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, a->background, (const float*)im.final_T,
                   (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
-                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0))
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0,
+                  order_ptr((const uint32_t*)im.tile_order, 2)))
         return fail(GHR_E_INVALID, GHR_E_DETERMINISTIC_MSG);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     ghr::GeomBwdArgs ga;
@@ -411,7 +428,7 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
     uint32_t* R_mapped = mapped_word(R_host);
     hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
-                       g.slot_blk, n_blocks(rows_total), R_mapped);
+                       g.slot_blk, n_blocks(rows_total), R_mapped, im.tile_order);
     if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, debug);
 }
@@ -444,7 +461,8 @@ int ghr_render_backward(void* stream, int32_t rows_total, int32_t W, int32_t H, 
     if (launch_k8((size_t)rows_total, (uint32_t)T, s, W, H, gx, (uint32_t)T, (const uint32_t*)im.tile_start,
                   (const uint32_t*)b.point_list, (const ghr::f4*)g.rec, background, (const float*)im.final_T,
                   (const uint32_t*)im.n_contrib, dL_dpix, (const ghr::rect4*)g.rects, grad_scratch, R,
-                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0))
+                  (const unsigned long long*)b.cell_mask, (const uint32_t*)im.cell_last, prezeroed != 0,
+                  order_ptr((const uint32_t*)im.tile_order, 2)))
         return fail(GHR_E_INVALID, GHR_E_DETERMINISTIC_MSG);
     if (g_ev[3]) GHR_HIP(hipEventRecord(g_ev[3], s));
     return finish(s, 0);

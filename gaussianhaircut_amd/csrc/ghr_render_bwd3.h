@@ -413,11 +413,11 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
                                                                 uint32_t cap,
                                                                 const unsigned long long* __restrict__ cell_mask,
                                                                 const uint32_t* __restrict__ cell_last, int ordered,
-                                                                int prezeroed)
+                                                                int prezeroed, const uint32_t* __restrict__ tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ B3Shared sh;
-    const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_tiles);  // heaviest first (k_tile_scan)
     if (tile >= T_tiles) return;  // grid padding
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;

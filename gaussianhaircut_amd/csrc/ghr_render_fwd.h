@@ -65,12 +65,13 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           float* __restrict__ out_color, float* __restrict__ final_T,
                                                           uint32_t* __restrict__ n_contrib, uint32_t cap,
                                                           unsigned long long* __restrict__ cell_mask,
-                                                          uint32_t* __restrict__ cell_last)
+                                                          uint32_t* __restrict__ cell_last,
+                                                          const uint32_t* __restrict__ tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
 
-    const uint32_t tile = xcd_tile(blockIdx.x, T_tiles);
+    const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_tiles);  // heaviest first (k_tile_scan)
     if (tile >= T_tiles) return;  // grid padding
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = lane >> 4, l = lane & 15;
