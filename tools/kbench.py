@@ -75,6 +75,12 @@ def main():
               " waves=%d cycles_per_wave mean %.0f p50 %.0f p99 %.0f max %.0f  count7=%d p4_cycles_per_count=%.0f" %
               (used.sum(), v[used, 6].mean(), np.percentile(v[used, 6], 50), np.percentile(v[used, 6], 99),
                v[used, 6].max(), int(tot[7]), tot[4] / max(tot[7], 1)))
+        wg = v[: (v.shape[0] // 4) * 4, 6].reshape(-1, 4)
+        wg = wg[wg.max(axis=1) > 0]
+        print("PROF workgroups: %d working; slot-cycles of a workgroup = 4 x its slowest wave: %.3g against %.3g summed over "
+              "its waves (%.2fx); mean of the slowest wave %.0f, of all working waves %.0f" %
+              (len(wg), 4 * wg.max(axis=1).sum(), wg.sum(), 4 * wg.max(axis=1).sum() / wg.sum(), wg.max(axis=1).mean(),
+               wg[wg > 0].mean()))
     tf.sort(), tb.sort()
     print("KBENCH %s lib=%s P=%d R=%d  k_render_fwd med %.4f min %.4f ms   k_render_bwd med %.4f min %.4f ms" %
           (cfg, _lib.LIB_PATH.split("/")[-1], P, run.R, tf[len(tf) // 2], tf[0], tb[len(tb) // 2], tb[0]))
