@@ -1,0 +1,47 @@
+"""Build-time guard for the hand-counted `s_waitcnt vmcnt(N)` of k_render_bwd_cells (csrc/ghr_render_bwd3.h).
+
+The kernel issues its record gathers as LDS-DMA two chunks ahead and waits for them with immediates that count the vector
+memory operations issued since -- which is only right if the compiler adds none of its own.  A register spill is a scratch
+access, scratch counts in vmcnt, and a spill inside the chunk loop lets LDS reads overtake their gathers: wrong gradients
+and a "faster" kernel (seen in a round-3 experiment build).  So: the kernel must compile without scratch and without
+spills at the occupancy it is tuned for.  Cross-compiles the device code to assembly (no GPU needed) and reads the
+kernel descriptors."""
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+from gaussianhaircut_amd import _lib
+
+
+def _descriptors():
+    hipcc = _lib._hipcc()
+    if hipcc is None:
+        pytest.skip("hipcc not found")
+    flags = [f for f in _lib.HIPCC_FLAGS if f not in ("-fPIC", "-shared")]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "k.s")
+        subprocess.run([hipcc] + flags + ["-I" + os.path.join(os.path.dirname(_lib.CSRC), "..", "include"), "-S",
+                                          "--cuda-device-only", "-o", out, os.path.join(_lib.CSRC, "ghr_capi.hip")],
+                       check=True, capture_output=True)
+        txt = open(out).read()
+    meta = {}
+    for blk in txt.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk)
+        if name:
+            meta[name.group(1)] = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*\n", blk)}
+    return meta
+
+
+def test_gradient_walk_compiles_without_scratch_and_within_its_register_budget():
+    meta = _descriptors()
+    k8 = [v for k, v in meta.items() if "k_render_bwd_cells" in k]
+    assert len(k8) == 1, list(meta)
+    k8 = k8[0]
+    assert k8["private_segment_fixed_size"] == 0 and k8["vgpr_spill_count"] == 0 and k8["sgpr_spill_count"] == 0, k8
+    assert k8["vgpr_count"] <= 96, k8          # five waves per SIMD (512 / 5, granule 8)
+    assert k8["group_segment_fixed_size"] <= 32768, k8   # five workgroups per CU of 160 KiB LDS
+    k7 = [v for k, v in meta.items() if "k_render_fwd" in k][0]
+    assert k7["private_segment_fixed_size"] == 0 and k7["vgpr_count"] <= 80, k7   # six waves per SIMD
