@@ -85,29 +85,112 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
                                                               uint32_t* R_mapped, uint32_t* tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    // One workgroup, latency-bound: everything a thread needs is requested in ONE round trip (8 consecutive counts as two
+    // 16-B loads; the gradient-slot counts of the K1 workgroups with them), scanned in registers, and the heaviest-first
+    // order is built from the counts while they are still there (round 3: 21 -> see DESIGN.md 7; the first form re-read
+    // tile_start for the order and walked the lists one element per load).
     __shared__ uint32_t s_part[GHR_SCAN_BLOCK];
     __shared__ uint32_t s_hist[8][64];
-    const uint32_t total = scan_1024(T, tile_count, tile_start, true, s_part);
-    if (threadIdx.x == 0) {
-        tile_start[T] = total;
-        *R_out = total;
-        // the host's copy of the count, stored straight into its pinned (device-mapped) word: visible to the host
-        // when the kernel retires, without a separate 4-byte copy command between this kernel and k_scatter
-        if (R_mapped) *R_mapped = total;
-    }
-    scan_1024(nblk, slot_blk, slot_blk, false, s_part);
-    if (tile_order) {
-        const uint32_t grid = xcd_grid((uint32_t)T);
-        for (uint32_t i = threadIdx.x; i < 8u * 64u; i += GHR_SCAN_BLOCK) (&s_hist[0][0])[i] = 0u;
-        __syncthreads();  // (also: tile_start[T] of thread 0 above is visible to the workgroup)
-        auto cls = [&](uint32_t t) -> uint32_t { return 63u - min((tile_start[t + 1] - tile_start[t]) >> 4, 63u); };
-        for (uint32_t b = threadIdx.x; b < grid; b += GHR_SCAN_BLOCK) {
-            const uint32_t t = xcd_tile(b, (uint32_t)T);
-            if (t < (uint32_t)T) atomicAdd(&s_hist[b & 7u][cls(t)], 1u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t grid = xcd_grid((uint32_t)T);
+    if (tile_order)
+        for (uint32_t i = tid; i < 8u * 64u; i += GHR_SCAN_BLOCK) (&s_hist[0][0])[i] = 0u;
+    // block-wide exclusive scan of one value per thread (s_part: 2 x 16 wave totals); returns the exclusive prefix, *total
+    auto block_scan = [&](uint32_t sum, uint32_t* total) -> uint32_t {
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+            if (lane >= off) incl += v;
+        }
+        __syncthreads();  // s_part may still be read by a previous call
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t w = lane < GHR_SCAN_BLOCK / 64 ? s_part[lane] : 0u;
+#pragma unroll
+            for (int off = 1; off < GHR_SCAN_BLOCK / 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)w, off);
+                if (lane >= off) w += v;
+            }
+            if (lane < GHR_SCAN_BLOCK / 64) s_part[64 + lane] = w;  // inclusive prefix of the wave totals
         }
         __syncthreads();
-        if (threadIdx.x < 8 * 64) {  // wave x: exclusive scan of XCD x's 64 class counts -> first slot of each class
-            const int x = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        *total = s_part[64 + GHR_SCAN_BLOCK / 64 - 1];
+        return incl - sum + (wave ? s_part[64 + wave - 1] : 0u);
+    };
+    // ---- the K1 workgroups' gradient-slot counts (in place), requested first, used last
+    const int per_b = (nblk + GHR_SCAN_BLOCK - 1) / GHR_SCAN_BLOCK;
+    uint32_t sb[4] = {0u, 0u, 0u, 0u};
+    const bool sb_regs = per_b <= 4;  // up to 4096 K1 workgroups (1 M Gaussians) in registers
+    if (sb_regs)
+#pragma unroll
+        for (int i = 0; i < 4; i++) sb[i] = (i < per_b && tid * per_b + i < nblk) ? slot_blk[tid * per_b + i] : 0u;
+    // ---- tile counts -> tile_start, rounds of 8192 tiles (one at 1080p)
+    uint32_t carry = 0u;
+    for (uint32_t base = 0; base < (uint32_t)T; base += 8u * GHR_SCAN_BLOCK) {
+        const uint32_t t0 = base + 8u * (uint32_t)tid;
+        uint32_t c[8];
+        if (t0 + 8u <= (uint32_t)T) {  // (tile_count / tile_start are 256-B aligned sub-allocations: 32-B accesses)
+            const uint4 a = *reinterpret_cast<const uint4*>(tile_count + t0), b = *reinterpret_cast<const uint4*>(tile_count + t0 + 4);
+            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
+            const uint4 z = {0u, 0u, 0u, 0u};   // the counts become k_scatter's append cursors
+            *reinterpret_cast<uint4*>(tile_count + t0) = z;
+            *reinterpret_cast<uint4*>(tile_count + t0 + 4) = z;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                c[i] = t0 + i < (uint32_t)T ? tile_count[t0 + i] : 0u;
+                if (t0 + i < (uint32_t)T) tile_count[t0 + i] = 0u;
+            }
+        }
+        uint32_t sum = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) sum += c[i];
+        uint32_t total;
+        uint32_t run = carry + block_scan(sum, &total);
+        uint32_t st[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { st[i] = run; run += c[i]; }
+        if (t0 + 8u <= (uint32_t)T) {   // tile_start[T + 1]: index t0 + 7 <= T - 1
+            *reinterpret_cast<uint4*>(tile_start + t0) = uint4{st[0], st[1], st[2], st[3]};
+            *reinterpret_cast<uint4*>(tile_start + t0 + 4) = uint4{st[4], st[5], st[6], st[7]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (t0 + i < (uint32_t)T) tile_start[t0 + i] = st[i];
+        }
+        if (tile_order) {   // count the tiles of every (XCD, class of n / 16); see k_tile_scan's header comment
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (t0 + i < (uint32_t)T) atomicAdd(&s_hist[((t0 + i) / GHR_XCD_RUN) & 7u][63u - min(c[i] >> 4, 63u)], 1u);
+        }
+        carry += total;
+    }
+    if (tid == 0) {
+        tile_start[T] = carry;
+        *R_out = carry;
+        // the host's copy of the count, stored straight into its pinned (device-mapped) word: visible to the host
+        // when the kernel retires, without a separate 4-byte copy command between this kernel and k_scatter
+        if (R_mapped) *R_mapped = carry;
+    }
+    // ---- gradient-slot prefix of the K1 workgroups
+    if (sb_regs) {
+        uint32_t total;
+        uint32_t run = block_scan(sb[0] + sb[1] + sb[2] + sb[3], &total);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i < per_b && tid * per_b + i < nblk) slot_blk[tid * per_b + i] = run;
+            run += sb[i];
+        }
+    } else {
+        scan_1024(nblk, slot_blk, slot_blk, false, s_part);
+    }
+    // ---- heaviest-first order per XCD (counting sort; the second pass re-reads the counts from tile_start)
+    if (tile_order) {
+        __syncthreads();  // histogram complete; tile_start (and tile_start[T]) of this workgroup visible
+        if (tid < 8 * 64) {  // wave x: exclusive scan of XCD x's 64 class counts -> first slot of each class
+            const int x = tid >> 6;
             const uint32_t c = s_hist[x][lane];
             uint32_t incl = c;
 #pragma unroll
@@ -117,13 +200,13 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
             }
             s_hist[x][lane] = incl - c;
             // the XCD's slots behind its last tile belong to padding workgroups
-            if (lane == 63)
-                for (uint32_t k = incl; k < grid / 8u; k++) tile_order[8u * k + (uint32_t)x] = 0xffffffffu;
+            const uint32_t total_x = (uint32_t)__shfl((int)incl, 63);
+            for (uint32_t k = total_x + (uint32_t)lane; k < grid / 8u; k += 64u) tile_order[8u * k + (uint32_t)x] = 0xffffffffu;
         }
         __syncthreads();
-        for (uint32_t b = threadIdx.x; b < grid; b += GHR_SCAN_BLOCK) {
-            const uint32_t t = xcd_tile(b, (uint32_t)T);
-            if (t < (uint32_t)T) tile_order[8u * atomicAdd(&s_hist[b & 7u][cls(t)], 1u) + (b & 7u)] = t;
+        for (uint32_t t = tid; t < (uint32_t)T; t += GHR_SCAN_BLOCK) {
+            const uint32_t x = (t / GHR_XCD_RUN) & 7u;
+            tile_order[8u * atomicAdd(&s_hist[x][63u - min((tile_start[t + 1] - tile_start[t]) >> 4, 63u)], 1u) + x] = t;
         }
     }
 #endif
