@@ -82,15 +82,19 @@ __device__ __forceinline__ uint32_t lds_addr(T* p)
 // line atomics and gathers at every cell draw.
 __device__ __forceinline__ uint32_t lds_draw(uint32_t addr)
 {
+    // (the address arrives in a scalar register and the result register doubles as the address operand: nothing of the
+    // draw is live in a VGPR across a cell)
     uint32_t ret, one = 1u;
     unsigned long long saved;
+    const uint32_t addr_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)addr);
     asm volatile("s_mov_b64 %1, exec\n\t"
                  "s_mov_b64 exec, 1\n\t"
-                 "ds_add_rtn_u32 %0, %2, %3\n\t"
+                 "v_mov_b32 %0, %2\n\t"
+                 "ds_add_rtn_u32 %0, %0, %3\n\t"
                  "s_mov_b64 exec, %1\n\t"
                  "s_waitcnt lgkmcnt(0)"
                  : "=&v"(ret), "=&s"(saved)
-                 : "v"(addr), "v"(one));   // (no "memory": the word is touched by nothing else between two barriers)
+                 : "s"(addr_s), "v"(one));   // (no "memory": the word is touched by nothing else between two barriers)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)ret);
 }
 
@@ -115,7 +119,8 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                                         const rect4* __restrict__ rects, float* ginst, uint32_t cap,
                                         const unsigned long long* __restrict__ cell_mask, size_t word0)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = lane >> 4, m = lane & 15;
+    // (wave: pinned to a scalar register -- the per-wave LDS bases then are scalar too instead of lane-constant VGPRs)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), k = lane >> 4, m = lane & 15;
     const float wx0 = (float)(tx * GHR_TILE_X);
     GHR_PROF_DECL;
     const uint32_t plane = 4u * (uint32_t)(W * H);  // bytes
@@ -417,10 +422,10 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ B3Shared sh;
+    const int tid = threadIdx.x;
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_tiles);  // heaviest first (k_tile_scan)
     if (tile >= T_tiles) return;  // grid padding
     const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
     const uint32_t beg = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - beg;  // see k_render_bwd for `cap`
     if (n == 0) return;
@@ -442,7 +447,8 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
     if (small)
         for (uint32_t i = tid; i < 16u * ((n + 63u) >> 6); i += GHR_BLOCK) (&sh.mask[0][0])[i] = cell_mask[word0 * 16 + i];
     if (tid < 16) sh.clast[tid] = cell_last[16u * tile + tid];
-    if (tid == 0) sh.next = 0u;
+    // (volatile: the cell draws are asm the compiler cannot see)
+    if (tid == 0) *(volatile uint32_t*)&sh.next = 0u;
     __syncthreads();  // orders the zero-fill (vmcnt(0) + workgroup fence) before the atomics below
     // ghr_set_deterministic: one wave draws all sixteen cells, in index order -- the additions into a line (issued by one
     // wave to one address) then happen in program order
