@@ -546,6 +546,32 @@ __global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, flo
 }
 }  // namespace ghr
 
+// The marching form of the loss kernels (ghr_loss.h) needs 16-B aligned image rows
+// Rows of a strip per wave.  Measured on 1080p (profiles/r03h): 16 .. 40 rows give the same kernel time, 64 is 6 % slower,
+// 128 10 %, 272 60 % -- the kernels live on the number of waves in flight, the ten extra rows a segment filters for its
+// first output row are cheap
+static int loss_march_seg(const ghr_loss_args* l, bool backward)
+{
+    const char* e = std::getenv(backward ? "GHR_LOSS_SEG_B" : "GHR_LOSS_SEG_F");  // measurement knob
+    int seg = e ? atoi(e) : 0;
+    if (seg <= 0) seg = 32;
+    (void)l;
+    return (seg + GHR_LM_ROWS - 1) / GHR_LM_ROWS * GHR_LM_ROWS;
+}
+static dim3 loss_march_grid(const ghr_loss_args* l, int seg)
+{
+    return dim3(8 * (((l->W + GHR_LM_TW - 1) / GHR_LM_TW + 7) / 8), (l->H + seg - 1) / seg, 3);
+}
+static bool loss_vec_ok(const ghr_loss_args* l, const void* p0 = nullptr, const void* p1 = nullptr)
+{
+    const bool off = std::getenv("GHR_LOSS_SCALAR") != nullptr;  // test / measurement knob (read per call): the tile kernels
+    if (off || (l->W & 3) || (size_t)l->W * (size_t)l->H >= ((size_t)1 << 30)) return false;
+    const void* ps[] = {l->image, l->gt_image, l->gt_mask, l->gt_stats, p0, p1};
+    for (const void* p : ps)
+        if (((uintptr_t)p & 15u) != 0) return false;
+    return true;
+}
+
 int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* sums, float* loss_out)
 {
     if (!l || l->W <= 0 || l->H <= 0 || !l->image || !l->mask || !l->gt_image || !l->gt_mask || !maps || !sums || !loss_out)
@@ -556,10 +582,18 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
     hipStream_t s = (hipStream_t)stream;
     GHR_HIP(hipMemsetAsync(sums, 0, GHR_LOSS_SUMS * sizeof(float), s));
     ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
-                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums, l->gt_stats, nullptr};
+                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums, l->gt_stats, nullptr,
+                    loss_march_seg(l, false)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    if (l->gt_stats) hipLaunchKernelGGL(ghr::k_loss_fwd_cached, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
+    const bool vec = loss_vec_ok(l, maps);
+    const dim3 grid_v = loss_march_grid(l, a.seg);
+    if (l->gt_stats) {
+        if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_cached_v, grid_v, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(ghr::k_loss_fwd_cached, grid, dim3(256), 0, s, a);
+    } else {
+        if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_v, grid_v, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
+    }
     hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, l->w_l1, l->w_ssim, l->w_mask,
                        orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
                        loss_out);
@@ -572,9 +606,10 @@ int ghr_loss_gt_stats(void* stream, const ghr_loss_args* l, float* stats_out)
         return fail(GHR_E_INVALID, "ghr_loss_gt_stats: bad args");
     hipStream_t s = (hipStream_t)stream;
     ghr::LossArgs a{l->W, l->H, l->gt_image, nullptr, nullptr, nullptr, l->gt_image, l->gt_mask, nullptr, nullptr,
-                    l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out};
+                    l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out, loss_march_seg(l, false)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    hipLaunchKernelGGL(ghr::k_loss_gt_stats, grid, dim3(256), 0, s, a);
+    if (loss_vec_ok(l, stats_out)) hipLaunchKernelGGL(ghr::k_loss_gt_stats_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(ghr::k_loss_gt_stats, grid, dim3(256), 0, s, a);
     return finish(s, 0);
 }
 
@@ -593,9 +628,10 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
                        l->gt_mask, l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps,
                        sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
                        grad_loss, l->w_l1, l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, d_image, d_mask, d_dir2d,
-                       d_orient_conf, zero_plane_a, zero_plane_b};
+                       d_orient_conf, zero_plane_a, zero_plane_b, loss_march_seg(l, true)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    hipLaunchKernelGGL(ghr::k_loss_bwd, grid, dim3(256), 0, s, a);
+    if (loss_vec_ok(l, maps)) hipLaunchKernelGGL(ghr::k_loss_bwd_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(ghr::k_loss_bwd, grid, dim3(256), 0, s, a);
     return finish(s, 0);
 }
 

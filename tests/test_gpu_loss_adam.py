@@ -241,6 +241,46 @@ def test_cached_ground_truth_window_moments_give_bit_identical_loss(H, W, mask_c
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("H,W,mask_colours,cached", [(48, 64, True, False), (52, 100, False, True), (270, 480, True, True),
+                                                      (1080, 1920, True, True), (1080, 1920, True, False)])
+def test_vector_loss_kernels_equal_the_scalar_ones_bit_for_bit(H, W, mask_colours, cached, monkeypatch):
+    """Images with 16-B aligned rows (W % 4 == 0) take the vector form of the loss kernels (csrc/ghr_loss.h: aligned float4
+    window loads, a block marching down a strip of 32 columns, DPP wave sums); GHR_LOSS_SCALAR=1 (read per call) forces the
+    tile kernels.  Same arithmetic in the same order per output: the image / mask gradients and the cached window moments
+    are the same bits; the loss value and the orientation term's normaliser differ only by the order their partial sums are
+    added in."""
+    from gaussianhaircut_amd.fused_loss import gt_ssim_stats, stage1_loss
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11 * H + W)
+    gt = torch.rand(3, H, W, generator=g)
+    r = torch.rand(10, H, W, generator=g)
+    r[5:8] = torch.randn(3, H, W, generator=g) * 0.3
+    r[8] = r[8] * 2 + 0.05
+    gt_mask = (torch.rand(2, H, W, generator=g) > 0.35).float()
+    gt_angle, gt_oconf = torch.rand(1, H, W, generator=g), torch.rand(1, H, W, generator=g)
+    consts = [t.to(dev) for t in (gt, gt_mask, gt_angle, gt_oconf)]
+    outs = []
+    for scalar in (True, False):
+        if scalar:
+            monkeypatch.setenv("GHR_LOSS_SCALAR", "1")
+        else:
+            monkeypatch.delenv("GHR_LOSS_SCALAR", raising=False)
+        st = gt_ssim_stats(consts[0], consts[1], mask_colours) if cached else None
+        a = r.to(dev).requires_grad_(True)
+        loss = stage1_loss(a, *consts, 0.8, 0.2, 0.2, 0.1, mask_colours=mask_colours, gt_stats=st)
+        (loss * 0.37).backward()
+        torch.cuda.synchronize()
+        outs.append((float(loss.detach()), a.grad.clone(), st))
+    assert abs(outs[0][0] - outs[1][0]) <= 2e-6 * abs(outs[0][0])
+    ga, gb = outs[0][1], outs[1][1]
+    assert torch.equal(ga[:5], gb[:5]) and torch.equal(ga[7], gb[7]) and torch.equal(ga[9], gb[9])
+    # the orientation gradients carry 1 / sum(weights): a sum of per-block partial sums, i.e. order-dependent in its last bit
+    for c in (5, 6, 8):
+        assert float((ga[c] - gb[c]).abs().max()) <= 3e-7 * float(ga[c].abs().max())
+    if cached:
+        assert torch.equal(outs[0][2], outs[1][2])
+
+
 def test_step_after_optimizer_surgery_passes_the_replaced_groups_by_like_torch_adam():
     """surgery (densify / prune / opacity reset) sits between backward() and optimizer.step() in the
     reference's loop (train_gaussians.py:158-181).  The nn.Parameters it creates have grad None, so torch.optim.Adam's
