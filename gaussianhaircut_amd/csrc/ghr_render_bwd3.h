@@ -172,12 +172,28 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
         // second ones, ...: the chunk's reads below (16 entries side by side) are free of bank conflicts.
         auto issue = [&](uint32_t t) {
             const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
+#ifndef GHR_B3_ENTRY_MAJOR  // lane L gathers quarter L >> 4 of entry L & 15 (64 separate 16-B accesses)
             const uint32_t e = min((uint32_t)lane & 15u, cnt - 1u);
             const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
             const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
             const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
             gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][t % GHR_B3_NBUF][0]);
             if (lane < 16) sh.cslot[wave][t % GHR_B3_NBUF][lane] = slot;
+#else
+            // (measured in round 3, profiles/r03i: parity-green, 0.193 ms against 0.190 -- not kept as the default)
+            // the four lanes 4e .. 4e+3 gather the four quarters of entry e: one 64-B access of the L1 per record instead of
+            // four 16-B ones from lanes 16 apart.  The LDS-DMA puts
+            // lane L's 16 B at slot L, i.e. the record of entry e at 64 e: reading one quarter of 16 entries side by side
+            // would be a 4-way bank conflict, so the quarters of entry e are rotated by e >> 2 inside the record's four slots
+            // (lane 4e + s fetches quarter (s - (e >> 2)) & 3): slot 4e + ((q + (e >> 2)) & 3) is a different one of the
+            // sixteen 16-B bank slots for each of the sixteen entries, for every q.
+            const uint32_t es = (uint32_t)lane >> 2, e = min(es, cnt - 1u);
+            const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
+            const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
+            const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
+            gather16_to_lds(rec, 64u * id + 16u * ((((uint32_t)lane & 3u) - (es >> 2)) & 3u), &sh.rec[wave][t % GHR_B3_NBUF][0]);
+            if ((lane & 3) == 0) sh.cslot[wave][t % GHR_B3_NBUF][es] = slot;
+#endif
         };
         build();
         while (n_c == 0 && w_hi >= GHR_B3_SEG_WORDS) { w_hi -= GHR_B3_SEG_WORDS; build(); }
@@ -278,14 +294,25 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 #else
                 const bool valid = (uint32_t)m < cnt;
                 const uint32_t j = min((uint32_t)m, cnt - 1u);  // lanes past the end recompute the last entry, masked
+                const int f0 = 6 + k, f1 = 10 + k, f2 = 6 + kc2;            // colours k, 4 + k, 8 + k
+#ifndef GHR_B3_ENTRY_MAJOR
                 // field f of entry j sits at float (f >> 2) * 64 + 4 j + (f & 3): quarter-major, see the gather
                 const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * j;
                 const f4 r0 = *reinterpret_cast<const f4*>(R);              // x y a b
                 const f2b r1 = *reinterpret_cast<const f2b*>(R + 64);       // c o
-                const float ex = r0.x, ey = r0.y, ca = r0.z, cb = r0.w, cc = r1.x, o = r1.y;
-                const int f0 = 6 + k, f1 = 10 + k, f2 = 6 + kc2;            // colours k, 4 + k, 8 + k
                 const float col0 = R[(f0 >> 2) * 64 + (f0 & 3)], col1 = R[(f1 >> 2) * 64 + (f1 & 3)],
                             col2 = k < 2 ? R[(f2 >> 2) * 64 + (f2 & 3)] : 0.f;
+#else
+                // field f of entry j sits at float 16 j + 4 (((f >> 2) + (j >> 2)) & 3) + (f & 3): see the gather
+                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 16u * j;
+                const uint32_t rot = j >> 2;
+                const f4 r0 = *reinterpret_cast<const f4*>(R + 4u * (rot & 3u));               // x y a b
+                const f2b r1 = *reinterpret_cast<const f2b*>(R + 4u * ((1u + rot) & 3u));      // c o
+                const float col0 = R[4u * ((((uint32_t)f0 >> 2) + rot) & 3u) + ((uint32_t)f0 & 3u)],
+                            col1 = R[4u * ((((uint32_t)f1 >> 2) + rot) & 3u) + ((uint32_t)f1 & 3u)],
+                            col2 = k < 2 ? R[4u * ((((uint32_t)f2 >> 2) + rot) & 3u) + ((uint32_t)f2 & 3u)] : 0.f;
+#endif
+                const float ex = r0.x, ey = r0.y, ca = r0.z, cb = r0.w, cc = r1.x, o = r1.y;
                 const uint32_t pos = 64u * w_lo + list[hi - 1u - j];
                 // colour . dL/dpixel for the lane's four pixels
                 f4 cd = {0.f, 0.f, 0.f, 0.f};
