@@ -14,7 +14,9 @@
 // 1080p on MI355X = 69 % of the step once projection was fused).  Here: one forward kernel (separable 11-tap window
 // staged through LDS, 32x16 pixel tiles with a 5-pixel halo) that also emits the three per-pixel partial derivatives
 // of the SSIM map, and one backward kernel that convolves those maps back (same window, adjoint of a symmetric
-// zero-padded convolution) and adds the L1 terms.  HBM-bound: ~25 B/pixel/channel forward, ~30 B backward.
+// zero-padded convolution) and adds the L1 terms.  ~25 B/pixel/channel forward, ~30 B backward.
+// Two forms of each kernel, bit-identical per output: 32 x 16 tiles (any image) and, for 16-B aligned rows, one wave
+// marching down a 32-column strip (second half of this file; the one the trainer's 1080p images take).
 #pragma once
 #include "ghr_device.h"
 

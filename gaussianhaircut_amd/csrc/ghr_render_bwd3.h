@@ -434,6 +434,9 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 }
 #endif
 
+#ifdef GHR_B3_VGPRS  // experiment: waves per SIMD the register allocator must make room for (6 -> 80 VGPRs)
+__attribute__((amdgpu_waves_per_eu(GHR_B3_VGPRS, GHR_B3_VGPRS)))
+#endif
 __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(int W, int H, int gx, uint32_t T_tiles,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ point_list,
