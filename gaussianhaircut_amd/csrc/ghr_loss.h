@@ -478,13 +478,21 @@ template <typename T>
 __device__ __forceinline__ T ldb(const void* base, uint32_t byte_off)
 {
     asm("" : "+v"(byte_off));
+#ifdef GHR_LOSS_NT_LOADS
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+#else
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
 }
 template <typename T>
 __device__ __forceinline__ void stb(void* base, uint32_t byte_off, T v)
 {
     asm("" : "+v"(byte_off));
+#ifdef GHR_LOSS_NT_STORES
+    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off));
+#else
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
+#endif
 }
 // acc = fma(w, x, acc) with the (uniform) window weight in a scalar register, as ONE v_fmac_f32.  Written out because the
 // SLP vectoriser otherwise pairs the window FMAs into v_pk_fma_f32, which on this chip costs 1.65 plain instructions for two
@@ -615,7 +623,8 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
     const float* m = a.gt_mask + N;  // gt_mask[1]
     const bool masked = a.mask_colours != 0;  // uniform
 
-    // input rows r0 .. r0 + nvec / 8 - 1 -> rows 0.. of s_x (render x mask) and s_y (ground truth x mask), in two halves:
+    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // |image-gt|*m, ssim, |mask-gt_mask|, orientation num, den
+    // input rows r0 .. r0 + nvec / 12 - 1 -> rows 0.. of s_x (render x mask) and s_y (ground truth x mask), in two halves:
     // fetch() issues the loads of a batch while the previous one is still being worked on (the registers below are carried
     // around the loop), commit() stores it once the staging rows are free
     WinPos wp[2];
@@ -629,13 +638,21 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
             vg[it] = ldb<f4>(gt, wp[it].off);
         }
     };
-    auto commit = [&](int nvec) {
+    // r0: image row of the batch's first row.  The L1 term |image - gt| * m is summed HERE, from the batch's own loads (every
+    // pixel of the segment's rows and the strip's columns is fetched exactly once as part of a batch): three loads per pixel
+    // less in the epilogue -- the kernel is bound by its L1 accesses (profiles/r03h)
+    auto commit = [&](int nvec, int r0) {
 #pragma unroll
         for (int it = 0; it < 2; it++) {
             const f4 mm = sel4(wp[it].in, vm[it]);
             f4 x = {0.f, 0.f, 0.f, 0.f};
             if (HAVE_X) {
                 x = sel4(wp[it].in, vi[it]);
+                const int gy = r0 + wp[it].row;
+                const bool own = wp[it].in && wp[it].q >= 2 && wp[it].q < 2 + GHR_LM_TW / 4 && gy >= y0 && gy < y1;
+                const f4 gg = sel4(wp[it].in, vg[it]);
+                const float l1 = (fabsf(x.x - gg.x) * mm.x + fabsf(x.y - gg.y) * mm.y) + (fabsf(x.z - gg.z) * mm.z + fabsf(x.w - gg.w) * mm.w);
+                sums[0] += own ? l1 : 0.f;
                 x = f4{x.x * mm.x, x.y * mm.y, x.z * mm.z, x.w * mm.w};
             }
             f4 g = sel4(wp[it].in, vg[it]);
@@ -690,20 +707,18 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
     const int tx = lane & 31, rg = lane >> 5;
     const int gx = bx + tx;
     const bool orient = MODE != 2 && CH2 && a.dir2d != nullptr;  // uniform
-    float sums[5] = {0.f, 0.f, 0.f, 0.f, 0.f};  // |image-gt|*m, ssim, |mask-gt_mask|, orientation num, den
-
     // The loop is rotated so that a batch is committed at the END of the pass before it, in straight-line code behind the
     // pass's stores: the wait for its loads then is an exact count (vmcnt = the stores issued since) instead of a drain of
     // every outstanding store at the top of each pass (which is what the counter arithmetic at a loop header amounts to).
     // the ten input rows above the segment -> filtered rows 0..9
     fetch(y0 - GHR_SSIM_R, 2 * GHR_SSIM_R * GHR_LM_WQ);
-    commit(2 * GHR_SSIM_R * GHR_LM_WQ);
+    commit(2 * GHR_SSIM_R * GHR_LM_WQ, y0 - GHR_SSIM_R);
     wave_lds_fence();
     hpass(2 * GHR_SSIM_R, 0);
     hpass(2 * GHR_SSIM_R, 0, 8);
     fetch(y0 + GHR_SSIM_R, GHR_LM_ROWS * GHR_LM_WQ);
     wave_lds_fence();
-    commit(GHR_LM_ROWS * GHR_LM_WQ);
+    commit(GHR_LM_ROWS * GHR_LM_WQ, y0 + GHR_SSIM_R);
     for (int yb = y0; yb < y1; yb += GHR_LM_ROWS) {
         wave_lds_fence();
         hpass(GHR_LM_ROWS, 2 * GHR_SSIM_R);
@@ -722,7 +737,7 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
             ok[o] = gx < W && gy < y1;
             p4[o] = ok[o] ? 4u * ((uint32_t)gy * (uint32_t)W + (uint32_t)gx) : 0u;
         }
-        float l_mu2[4], l_e22[4], l_im[4], l_g[4], l_m[4], l_mk[4], l_gmk[4];
+        float l_mu2[4], l_e22[4], l_mk[4], l_gmk[4];
         if (MODE != 2) {
 #pragma unroll
             for (int o = 0; o < 4; o++) {
@@ -730,9 +745,6 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
                     l_mu2[o] = ldb<float>(a.gt_stats + (size_t)(0 * 3 + ch) * N, p4[o]);
                     l_e22[o] = ldb<float>(a.gt_stats + (size_t)(1 * 3 + ch) * N, p4[o]);
                 }
-                l_im[o] = ldb<float>(img, p4[o]);
-                l_g[o] = ldb<float>(gt, p4[o]);
-                l_m[o] = masked ? ldb<float>(m, p4[o]) : 1.0f;
                 if (!CH2) {
                     l_mk[o] = ldb<float>(a.mask + (size_t)ch * N, p4[o]);
                     l_gmk[o] = ldb<float>(a.gt_mask + (size_t)ch * N, p4[o]);
@@ -759,7 +771,6 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
                 const float e22 = MODE == 1 ? l_e22[o] : acc[o][PYY];
                 const float sv = ssim_point(acc[o][PX], mu2, acc[o][PXX], e22, acc[o][PXY], d0[o], d1[o], d2[o]);
                 sums[1] += ok[o] ? sv : 0.f;
-                sums[0] += ok[o] ? fabsf(l_im[o] - l_g[o]) * l_m[o] : 0.f;
                 if (!CH2) sums[2] += ok[o] ? fabsf(l_mk[o] - l_gmk[o]) : 0.f;
             }
             if (CH2 && orient) {  // the waves of the third colour channel also carry the orientation term (before the stores:
@@ -790,7 +801,7 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
         }
         wave_lds_fence();  // every read of the vertical pass and of the last horizontal pass is done
         if (more) keep_last_rows<NM>(s_h, lane);
-        commit(more ? GHR_LM_ROWS * GHR_LM_WQ : 0);
+        commit(more ? GHR_LM_ROWS * GHR_LM_WQ : 0, yb + GHR_LM_ROWS + GHR_SSIM_R);
     }
     if (MODE == 2) return;
 #pragma unroll

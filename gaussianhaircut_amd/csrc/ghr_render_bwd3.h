@@ -62,12 +62,16 @@ __device__ __forceinline__ T ld32(const T* base, uint32_t byte_off)
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// cache policy bits of the record gathers (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef GHR_B3_GATHER_AUX
+#define GHR_B3_GATHER_AUX 0
+#endif
 // 16 B per lane from `base + byte_off` to `lds_dst + 16 * lane` (lds_dst wave-uniform), asynchronously: counted in vmcnt
 __device__ __forceinline__ void gather16_to_lds(const void* base, uint32_t byte_off, void* lds_dst)
 {
     __builtin_amdgcn_global_load_lds(
         (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + byte_off),
-        (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+        (__attribute__((address_space(3))) void*)lds_dst, 16, 0, GHR_B3_GATHER_AUX);
 }
 #define GHR_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 
