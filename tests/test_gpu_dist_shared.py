@@ -204,3 +204,47 @@ def test_one_rank_on_rccl_through_the_collective_branch_is_bit_identical_to_the_
         assert r["params_equal"] and r["v_equal"] and r["steps"] == (STEPS, STEPS) and r["finite"], r
         assert r["moved"] > 0
     assert res["skipped"]
+
+
+def _empty_rank_worker(rank, world, port, q):
+    """rank 1 holds NO views; between the first and the second step both ranks reset the opacities (optimizer surgery:
+    the replaced group is marked `skip next step` until fresh gradients arrive)"""
+    import torch.distributed as dist
+    from gaussianhaircut_amd.parallel import param_checksum
+    from gaussianhaircut_amd.trainer import training_step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model, cams, bg, opt = _scene(dev, 3)
+    mine = cams[:4] if rank == 0 else []
+    training_step(model, mine, bg, opt, 1, global_views=4)
+    model.reset_opacity()
+    before = model.optimizer.flat_param.detach().clone()
+    training_step(model, mine, bg, opt, 2, global_views=4)
+    torch.cuda.synchronize()
+    o = model.optimizer
+    q.put(dict(rank=rank, checksum=param_checksum(model.leaf_parameters()), step=int(o.state_dev[0]),
+               skipped=int(o.state_dev[1]), moved=float((o.flat_param - before).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_a_rank_without_views_stays_a_bit_identical_replica_across_optimizer_surgery():
+    """a rank that holds no views in a step still takes part in the collectives and in the update; the
+    `parameters replaced since the last backward` marks that optimizer surgery leaves are cleared by training_step on
+    EVERY rank (not only where a backward ran), otherwise that rank's step would be a no-op and the replicas diverge."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_empty_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=800) for _ in range(2)], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0]["checksum"] == res[1]["checksum"], "replicas diverged"
+    assert res[0]["step"] == res[1]["step"] == 2 and res[0]["skipped"] == res[1]["skipped"] == 0
+    assert res[0]["moved"] > 0 and res[0]["moved"] == res[1]["moved"]
