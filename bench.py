@@ -204,12 +204,13 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "gradient walk bound by VALU issue and memory latency, not by bandwidth (profiles/r02b: "
-                        "SQ_ACTIVE_INST_VALU 55 %% of the SIMD cycles at 5 waves per SIMD, half the VALU instructions of "
-                        "round 1's kernel; every L2 atomic is written through to HBM, hence traffic > algorithmic "
-                        "bytes; the zero-fill of the gradient lines runs under the forward pass's tile sort); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T of the measured "
-                        "view; kernel duration from HIP events the library records around the kernel on its launch "
-                        "stream, %d solo passes" % n_ev}
+                "note": "gradient walk bound by the misses a CU keeps in flight, not by bandwidth (profiles/r03i, r03j: VALU "
+                        "issue 57 %% of the SIMD cycles at 5 waves per SIMD, TA busy 60 %%, L1 stalled on pending misses 55 %% "
+                        "of the kernel: removing the chunk arithmetic saves 17 %%, the atomics 7 %%; every L2 atomic is written "
+                        "through to HBM, hence traffic > algorithmic bytes; the zero-fill of the gradient lines runs under "
+                        "the forward pass's tile sort); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T "
+                        "of the measured view; kernel duration from HIP events the library records around the kernel on its "
+                        "launch stream, %d solo passes" % n_ev}
 
     out = {
         "metric": "gaussians_per_sec_grad_step_500k_strands_1080p", "value": round(value, 1), "unit": "Gaussians/s",

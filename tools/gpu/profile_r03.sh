@@ -22,7 +22,7 @@ for f in glob.glob('/tmp/prof_kt/**/*kernel_stats.csv', recursive=True):
         print('KT %-60s calls %5s avg %9.1f us' % (r['Name'][:60], r['Calls'], float(r['AverageNs']) / 1e3))
 PY
 for cfg in cfg3 cfg5; do for ctr in FETCH_SIZE WRITE_SIZE; do
-  ( cd /tmp && rm -rf /tmp/pmc_${cfg}_$ctr && timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${cfg}_$ctr -o p -- python $R/tools/kbench.py $cfg 5 ) > $P/${TAG}_pmc_${cfg}_$ctr.log 2>&1; echo "pmc $cfg $ctr rc=$?"
+  ( cd /tmp && rm -rf /tmp/pmc_${cfg}_$ctr && timeout 150 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/pmc_${cfg}_$ctr -o p -- python $R/tools/kbench.py $cfg 5 ) > $P/${TAG}_pmc_${cfg}_$ctr.log 2>&1; echo "pmc $cfg $ctr rc=$?"
 done; done
 python - <<PY
 import csv, glob, json
