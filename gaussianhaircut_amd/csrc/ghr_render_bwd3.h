@@ -139,8 +139,14 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
     float abl = 0.f;
 #endif
 
+#ifdef GHR_B3_STATIC_CELLS
+    uint32_t my_cell = (uint32_t)wave;
+#endif
     for (;;) {
-#ifdef GHR_B3_CXX_DRAW
+#ifdef GHR_B3_STATIC_CELLS  // experiment: wave w takes the cells w, w + 4, w + 8, w + 12 (no draw, no balancing)
+        const uint32_t cell = my_cell;
+        my_cell += 4u;
+#elif defined(GHR_B3_CXX_DRAW)
         uint32_t cell = 0u;
         if (lane == 0) cell = atomicAdd(&sh.next, 1u);
         cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
