@@ -86,3 +86,9 @@ class GaussianModelStrands(GaussianModel):
             {'params': [self._features_rest], 'lr': training_args.feature_lr / 20.0, "name": "f_rest"},
             {'params': [self._orient_conf], 'lr': training_args.orient_conf_lr, "name": "orient_conf"},
         ]
+
+
+# The reference's latent stage (src/scene/gaussian_model_latent_strands.py) has the same projection helpers line for line;
+# what differs is where the strand polylines come from (a latent texture decoded by an un-vendored strand prior: out of
+# scope).  For the hot path the two classes are the same object.
+GaussianModelLatentStrands = GaussianModelStrands
