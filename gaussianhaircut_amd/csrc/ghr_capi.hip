@@ -68,7 +68,7 @@ int launch_k8(size_t rows, uint32_t T, hipStream_t s, int W, int H, int gx, uint
     }
     switch (v) {
     case 2:
-        hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, block, 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
+        hipLaunchKernelGGL(ghr::k_render_bwd_cells, grid, dim3(GHR_B3_THREADS), 0, s, W, H, gx, T_tiles, tile_start, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, rects, ginst, cap, cell_mask, cell_last, g_deterministic,
                            prezeroed ? 1 : 0, tile_order);
         break;

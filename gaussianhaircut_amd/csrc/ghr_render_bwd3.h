@@ -44,6 +44,10 @@ namespace ghr {
 #ifndef GHR_B3_WAVES
 #define GHR_B3_WAVES 5                           // waves per SIMD the register budget is set for
 #endif
+#ifndef GHR_B3_NW
+#define GHR_B3_NW 4                              // waves of a tile's workgroup (they share the tile's 16 cells)
+#endif
+#define GHR_B3_THREADS (64 * GHR_B3_NW)
 
 // Largest sizes the 32-bit offsets cover (bytes < 4 GiB): checked on the host, which falls back to k_render_bwd
 GHR_HD bool b3_fits(size_t rows, size_t R, size_t W, size_t H)
@@ -106,9 +110,9 @@ struct B3Shared {
     uint32_t id[GHR_B3_CACHE];                         // tile: Gaussian of each list position (tiles of <= GHR_B3_CACHE)
     unsigned long long mask[GHR_B3_CWORDS][16];        // tile: mask words, [word][cell]
     uint32_t clast[16];                                // tile: largest n_contrib of each cell
-    uint16_t list[4][GHR_B3_LIST];                     // per wave: hit positions of the segment, ascending
-    f4 rec[4][GHR_B3_NBUF][64];                        // per wave: gathered records, 16 entries x 64 B per buffer
-    uint32_t cslot[4][GHR_B3_NBUF][16];                // per wave: ... and their gradient lines
+    uint16_t list[GHR_B3_NW][GHR_B3_LIST];                     // per wave: hit positions of the segment, ascending
+    f4 rec[GHR_B3_NW][GHR_B3_NBUF][64];                        // per wave: gathered records, 16 entries x 64 B per buffer
+    uint32_t cslot[GHR_B3_NW][GHR_B3_NBUF][16];                // per wave: ... and their gradient lines
     uint32_t next;                                     // next cell of the tile nobody has taken yet
 };
 
@@ -140,7 +144,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 #endif
 
 #ifdef GHR_B3_STATIC_CELLS
-    uint32_t my_cell = (uint32_t)wave;
+    uint32_t my_cell = (uint32_t)wave;  // (with GHR_B3_NW == 4)
 #endif
     for (;;) {
 #ifdef GHR_B3_STATIC_CELLS  // experiment: wave w takes the cells w, w + 4, w + 8, w + 12 (no draw, no balancing)
@@ -447,7 +451,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 #ifdef GHR_B3_VGPRS  // experiment: waves per SIMD the register allocator must make room for (6 -> 80 VGPRs)
 __attribute__((amdgpu_waves_per_eu(GHR_B3_VGPRS, GHR_B3_VGPRS)))
 #endif
-__global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(int W, int H, int gx, uint32_t T_tiles,
+__global__ void __launch_bounds__(GHR_B3_THREADS, GHR_B3_WAVES) k_render_bwd_cells(int W, int H, int gx, uint32_t T_tiles,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ point_list,
                                                                 const f4* __restrict__ rec, const float* __restrict__ bg,
@@ -465,6 +469,9 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
     const int tid = threadIdx.x;
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_tiles);  // heaviest first (k_tile_scan)
     if (tile >= T_tiles) return;  // grid padding
+#ifdef GHR_B3_ONLY_EVERY  // experiment (wrong results): only every n-th workgroup works -- how the launch time scales with the work
+    if ((blockIdx.x >> 3) % GHR_B3_ONLY_EVERY != 0) return;  // (per XCD: workgroup b runs on XCD b % 8)
+#endif
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t beg = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - beg;  // see k_render_bwd for `cap`
@@ -474,7 +481,7 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
 
     // ---- tile prologue: zero the gradient lines of all the tile's instances (k_geom_bwd / k_project_bwd read every
     //      line of a Gaussian) and bring what every cell needs from the lists into LDS
-    for (uint32_t i = tid; i < n; i += GHR_BLOCK) {
+    for (uint32_t i = tid; i < n; i += GHR_B3_THREADS) {
         if (small) sh.id[i] = point_list[beg + i];
         // the lines lie in list order (the per-Gaussian gather finds them through the sort's inst_line): plain
         // consecutive stores, nothing to look up
@@ -485,7 +492,7 @@ __global__ void __launch_bounds__(GHR_BLOCK, GHR_B3_WAVES) k_render_bwd_cells(in
         }
     }
     if (small)
-        for (uint32_t i = tid; i < 16u * ((n + 63u) >> 6); i += GHR_BLOCK) (&sh.mask[0][0])[i] = cell_mask[word0 * 16 + i];
+        for (uint32_t i = tid; i < 16u * ((n + 63u) >> 6); i += GHR_B3_THREADS) (&sh.mask[0][0])[i] = cell_mask[word0 * 16 + i];
     if (tid < 16) sh.clast[tid] = cell_last[16u * tile + tid];
     // (volatile: the cell draws are asm the compiler cannot see)
     if (tid == 0) *(volatile uint32_t*)&sh.next = 0u;

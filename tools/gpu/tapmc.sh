@@ -6,7 +6,7 @@ out=$1; cfg=${2:-cfg3}; shift; shift
 export TMPDIR=/tmp
 R=$PWD
 i=0
-for set in "GRBM_GUI_ACTIVE TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_INSTS_VMEM" "GRBM_GUI_ACTIVE TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TCP_TCC_ATOMIC_WITHOUT_RET_REQ_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
+for set in "GRBM_GUI_ACTIVE TA_BUSY_avr TA_TA_BUSY_sum TCP_PENDING_STALL_CYCLES_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum SQ_INSTS_VMEM"; do
   i=$((i+1)); rm -rf /tmp/ta$i
   ( cd /tmp && env "$@" timeout 90 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/ta$i -o p -- python $R/tools/kbench.py $cfg 5 ) > /tmp/ta$i.log 2>&1
   python - <<PY >> $out
