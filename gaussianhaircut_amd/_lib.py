@@ -49,6 +49,12 @@ def _stale() -> bool:
 
 def build_library(force: bool = False, verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 into ``csrc/libghr_hip.so`` (cross-compiles without a GPU)."""
+    if os.environ.get("GHR_LIB_PATH"):
+        # an experiment library is used as it is: rebuilding it from the tree's sources (it is always "stale" after the
+        # next edit) would silently turn an A/B into a comparison of the product with itself
+        if not os.path.exists(LIB_PATH):
+            raise GhrError("GHR_LIB_PATH=%s does not exist" % LIB_PATH)
+        return LIB_PATH
     if not force and not _stale():
         return LIB_PATH
     hipcc = _hipcc()

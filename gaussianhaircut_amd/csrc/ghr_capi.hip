@@ -546,6 +546,9 @@ __global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, flo
 }
 }  // namespace ghr
 
+#ifndef GHR_ADAM_BLOCKS
+#define GHR_ADAM_BLOCKS 65536
+#endif
 // The marching form of the loss kernels (ghr_loss.h) needs 16-B aligned image rows
 // Rows of a strip per wave.  Measured on 1080p (profiles/r03h): 16 .. 40 rows give the same kernel time, 64 is 6 % slower,
 // 128 10 %, 272 60 % -- the kernels live on the number of waves in flight, the ten extra rows a segment filters for its
@@ -654,7 +657,17 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
         const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
         if (nan_guard == 1)
             hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
-        hipLaunchKernelGGL(ghr::k_adam, dim3(blocks), dim3(256), 0, s, a);
+        // four elements per thread where the range and the buffers allow 16-B accesses (GHR_ADAM_SCALAR: the scalar kernel)
+        const bool v4 = (begin & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15u) == 0 &&
+                        std::getenv("GHR_ADAM_SCALAR") == nullptr;
+        if (v4) {
+            const long long n4 = (count + 3) / 4;
+            const long long cap4 = GHR_ADAM_BLOCKS;
+            const int blocks4 = (int)((n4 + 255) / 256 < cap4 ? (n4 + 255) / 256 : cap4);
+            hipLaunchKernelGGL(ghr::k_adam_v4, dim3(blocks4 > 0 ? blocks4 : 1), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(ghr::k_adam, dim3(blocks), dim3(256), 0, s, a);
+        }
     }
     if (last && n > 0) hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state, skip_mask, n_groups);
     return finish(s, 0);

@@ -184,8 +184,7 @@ def _use_fused_hair(pc, pc_hair, pipe, cam=None) -> bool:
     """Fused strand-stage path: a ``GaussianModel`` head with its ``*_precomp`` attributes and a
     ``GaussianModelStrands`` on a ROCm device, constant camera (anything else takes the generic path)."""
     from ..scene.gaussian_model import GaussianModel
-    from ..scene.gaussian_model_strands import GaussianModelStrands
-    from ..scene.gaussian_model_latent_strands import GaussianModelLatentStrands
+    from ..scene.gaussian_model_strands import GaussianModelLatentStrands, GaussianModelStrands
     return (type(pc) is GaussianModel and type(pc_hair) in (GaussianModelStrands, GaussianModelLatentStrands) and
             getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view") and
             not (cam is not None and camera_requires_grad(cam)))

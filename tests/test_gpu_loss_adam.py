@@ -74,6 +74,39 @@ def test_fused_adam_matches_torch_adam_and_nan_guard():
     assert float(fa.flat_grad.abs().sum()) == 0.0
 
 
+def test_vector_adam_kernel_equals_the_scalar_one_bit_for_bit(monkeypatch):
+    """k_adam_v4 (four elements per thread, 16-B accesses) against k_adam (GHR_ADAM_SCALAR=1, read per call): group
+    boundaries that fall inside a float4 (P = 1001), a tail that is not a multiple of four, a skipped group after surgery,
+    torch.optim.Adam as the third party."""
+    from gaussianhaircut_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    P = 1001
+    shapes = [(P, 3), (P, 1, 3), (P, 15, 3), (P, 1), (P, 4), (P, 1)]
+    lrs = [1.6e-4, 2.5e-3, 1.25e-4, 0.05, 1e-3, 5e-3]
+    g = torch.Generator().manual_seed(3)
+    init = [torch.randn(*s, generator=g) for s in shapes]
+    runs = []
+    for scalar in (True, False):
+        if scalar:
+            monkeypatch.setenv("GHR_ADAM_SCALAR", "1")
+        else:
+            monkeypatch.delenv("GHR_ADAM_SCALAR", raising=False)
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        fa = FusedAdam([{"params": [p], "lr": lr, "name": str(i)} for i, (p, lr) in enumerate(zip(ps, lrs))], eps=1e-15)
+        gg = torch.Generator().manual_seed(4)
+        for it in range(4):
+            for p, s_ in zip(ps, shapes):
+                p.grad.copy_(torch.randn(*s_, generator=gg).to(dev))
+            if it == 2:
+                fa._skip_next = 0b000100  # group 2 sits this step out (as after optimizer surgery)
+            fa.step()
+        torch.cuda.synchronize()
+        runs.append((fa.flat_param.clone(), fa.exp_avg.clone(), fa.exp_avg_sq.clone(), fa.state_dev.clone(), fa.flat_grad.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
+    assert float(runs[1][4].abs().sum()) == 0.0 and runs[1][0].numel() % 4 != 0
+
+
 @pytest.mark.parametrize("chunks", [1, 3, 4, 7])
 def test_chunked_adam_equals_whole_buffer_adam_bit_for_bit(chunks):
     """FusedAdam.step_chunked (the update applied range by range, as the chunks of the gradient all-reduce arrive) must
