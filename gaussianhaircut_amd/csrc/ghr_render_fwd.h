@@ -163,7 +163,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
         final_T[pix] = st.T;
         n_contrib[pix] = st.last;
 #pragma unroll
+#ifdef GHR_K7_NT_OUT  // (measured: no change -- the loss reads these planes next)
+        for (int c = 0; c < GHR_C; c++) __builtin_nontemporal_store(st.C[c] + st.T * bg[c], out_color + c * plane + pix);
+#else
         for (int c = 0; c < GHR_C; c++) out_color[c * plane + pix] = st.C[c] + st.T * bg[c];
+#endif
     }
     GHR_PROF(5);
 #ifdef GHR_K7_PROF
