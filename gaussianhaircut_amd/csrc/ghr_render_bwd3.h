@@ -65,6 +65,16 @@ __device__ __forceinline__ T ld32(const T* base, uint32_t byte_off)
 {
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// ... for data a workgroup reads once (the cell's pixels)
+template <typename T>
+__device__ __forceinline__ T ld32_once(const T* base, uint32_t byte_off)
+{
+#ifdef GHR_B3_PIX_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
+#else
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
+}
 
 // cache policy bits of the record gathers (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
 #ifndef GHR_B3_GATHER_AUX
@@ -236,18 +246,18 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 #pragma unroll
             for (int q = 0; q < 4; q++) {  // clamped addresses, then a select: no load under a branch
                 const uint32_t pix = 4u * ((uint32_t)W * (uint32_t)min(py0 + q, H - 1) + pxc);  // byte offset
-                Tf[q] = ld32(final_T, pix);
-                last[q] = ld32(n_contrib, pix);
-                phiW[q] = ld32(dL_dpix, hmc * plane + pix);  // B operand of the colour MFMAs: dL/dpixel[m - 6] of pixel q
+                Tf[q] = ld32_once(final_T, pix);
+                last[q] = ld32_once(n_contrib, pix);
+                phiW[q] = ld32_once(dL_dpix, hmc * plane + pix);  // B operand of the colour MFMAs: dL/dpixel[m - 6] of pixel q
             }
             // A operand of the colour-dot MFMAs: row i = m of the product is the cell pixel (x = m >> 2, y = m & 3), so
             // that lane (k, e) finds the dots of ITS pixels (k, 0..3) in its four result registers
             const int ax = tx * GHR_TILE_X + 4 * g + (hm >> 2), ay = py0 + (hm & 3);
             const uint32_t hkc2 = hk < 2 ? (uint32_t)(8 + hk) : 0u;
             const uint32_t pixa = 4u * ((uint32_t)W * (uint32_t)min(ay, H - 1) + (uint32_t)min(ax, W - 1));
-            dLA0 = ld32(dL_dpix, (uint32_t)hk * plane + pixa);
-            dLA1 = ld32(dL_dpix, (uint32_t)(4 + hk) * plane + pixa);
-            dLA2 = ld32(dL_dpix, hkc2 * plane + pixa);
+            dLA0 = ld32_once(dL_dpix, (uint32_t)hk * plane + pixa);
+            dLA1 = ld32_once(dL_dpix, (uint32_t)(4 + hk) * plane + pixa);
+            dLA2 = ld32_once(dL_dpix, hkc2 * plane + pixa);
             // the background, as the "colour" of one more splat behind the list (backward.cu:535-538): bg . dL/dpixel of
             // the lane's four pixels from the same three MFMAs as the colour dots
             float bgA0 = ld32(bg, 4u * (uint32_t)hk), bgA1 = ld32(bg, 4u * (uint32_t)(4 + hk)), bgA2 = ld32(bg, 4u * hkc2);
