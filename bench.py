@@ -234,7 +234,7 @@ def main():
     # ---- BASELINE configs[3]'s per-GPU shard: VS views per GPU per global step (every N; same model, continues training)
     if VS > 0 and VS != V:
         it0 = Wm + K
-        for i in range(3):
+        for i in range(5):  # (untimed: the 4-view step's own buffer sizes and capacity guesses settle)
             training_step(model, shard_cams[:VS], bg, opt, it0 + i + 1, global_views=VS * world, streams=args.streams)
         torch.cuda.synchronize()
         if world > 1:
@@ -243,7 +243,7 @@ def main():
         t1 = time.perf_counter()
         K4 = max(5, K // 2)
         for i in range(K4):
-            training_step(model, shard_cams[:VS], bg, opt, it0 + 3 + i + 1, global_views=VS * world, streams=args.streams)
+            training_step(model, shard_cams[:VS], bg, opt, it0 + 5 + i + 1, global_views=VS * world, streams=args.streams)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
