@@ -309,6 +309,15 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed)
 {
+    return ghr_backward_ex(stream, a, R, radii, geom_ws, img_ws, bin_ws, dL_dpix, grad_scratch, dL_dmeans2D, dL_dconic,
+                           dL_dopacity, dL_dcolors, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drotations, prezeroed, nullptr);
+}
+
+int ghr_backward_ex(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
+                    const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                    float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                    float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed, float* dL_dconic3)
+{
     // backward reads colours / opacity from the packed records in geom_ws, not from `a`
     if (int rc = check_dims(a)) return rc;
     if (a->P > 0 && (!a->means3D || !a->viewmatrix || !a->projmatrix || !a->background))
@@ -345,7 +354,7 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
     ga.focal_x = a->W / (2.0f * a->tan_fovx);
     ga.ginst = grad_scratch; ga.inst_line = b.inst_line; ga.ginst_rows = R;
     ga.rects = g.rects; ga.rec = g.rec; ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
-    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
+    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dconic3 = dL_dconic3; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     hipLaunchKernelGGL(ghr::k_geom_bwd, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, ga);
     return finish(s, a->debug);

@@ -29,6 +29,7 @@ struct GeomBwdArgs {
     float half_w, half_h;  // 0.5 W, 0.5 H (backward.cu:464-465)
     float* dL_dmeans2D;  // [P][3]
     float* dL_dconic;    // [P][4]
+    float* dL_dconic3;   // [P][3] or NULL: (d/da, d/db, d/dc) -- what the reference's Python wrapper restacks dL_dconic into
     float* dL_dopacity;  // [P]
     float* dL_dcolors;   // [P][C]
     float* dL_dmeans3D;  // [P][3]
@@ -86,6 +87,11 @@ GHR_HD void geom_bwd_one(const GeomBwdArgs& a, int idx, const float* g)
     a.dL_dconic[4 * idx + 1] = gcb;
     a.dL_dconic[4 * idx + 2] = 0.f;
     a.dL_dconic[4 * idx + 3] = gcc;
+    if (a.dL_dconic3 != nullptr) {  // diff_gaussian_rasterization/__init__.py:149-153: [xx, 2 * xy, yy]
+        a.dL_dconic3[3 * idx] = gca;
+        a.dL_dconic3[3 * idx + 1] = 2.f * gcb;
+        a.dL_dconic3[3 * idx + 2] = gcc;
+    }
     a.dL_dopacity[idx] = g[5];
 #pragma unroll
     for (int c = 0; c < GHR_C; c++) a.dL_dcolors[(size_t)GHR_C * idx + c] = g[6 + c];

@@ -277,6 +277,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_means3D = torch.empty((P, 3), **f32)
             grad_cov3Ds_precomp = torch.empty((P, 6), **f32)
             grad_conic = torch.empty((P, 2, 2), **f32)
+            grad_conics_precomp = torch.empty((P, 3), **f32)  # [xx, 2 * xy, yy]: written by the library (ghr_backward_ex)
             grad_scales = torch.empty((P, 3), **f32)
             grad_rotations = torch.empty((P, 4), **f32)
             scratch = getattr(ctx, "scratch", None)  # one line per instance; zeroed by the forward pass if it made it
@@ -300,20 +301,22 @@ class _RasterizeGaussians(torch.autograd.Function):
                                                 imgBuffer, rs.debug))
             try:
                 if P > 0:
-                    _lib.check(L.ghr_backward(_stream(), ctypes.byref(args), ctx.bin_cap, _ptr(radii),
+                    _lib.check(L.ghr_backward_ex(_stream(), ctypes.byref(args), ctx.bin_cap, _ptr(radii),
                                               _ptr(geomBuffer), _ptr(imgBuffer), _ptr(binningBuffer), _ptr(dL),
                                               _ptr(scratch), _ptr(grad_means2D), _ptr(grad_conic),
                                               _ptr(grad_opacities), _ptr(grad_colors_precomp), _ptr(grad_means3D),
                                               _ptr(grad_cov3Ds_precomp), _ptr(grad_scales), _ptr(grad_rotations),
-                                              prezeroed))
+                                              prezeroed, _ptr(grad_conics_precomp)))
             except Exception as ex:
                 if cpu_args is not None:
                     torch.save(cpu_args, "snapshot_bw.dump")
                     print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
                 raise ex
 
-        # __init__.py:149-153: the kernel stores half of d/d(conic.y) (backward.cu:554); the wrapper doubles it
-        grad_conics_precomp = torch.stack([grad_conic[:, 0, 0], 2 * grad_conic[:, 0, 1], grad_conic[:, 1, 1]], dim=-1)
+        # __init__.py:149-153: the kernel stores half of d/d(conic.y) (backward.cu:554) and the reference's wrapper restacks
+        # [xx, 2 * xy, yy] with three slices, a doubling and a stack; ghr_backward_ex writes that tensor itself
+        if P == 0:
+            grad_conics_precomp.zero_()
 
         def opt(g, ref):
             return g if ref.numel() != 0 else None

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 13
+#define GHR_ABI_VERSION 14
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -121,6 +121,14 @@ int ghr_backward(void* stream, const ghr_view_args* a, uint32_t R, const int32_t
                  const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                  float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
                  float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed);
+/* ABI 14: ghr_backward with one more (optional) output, dL_dconic3 [P,3] = (dL_dconic[0][0], 2 * dL_dconic[0][1],
+ * dL_dconic[1][1]): the gradient w.r.t. conic_precomp as the reference's Python wrapper hands it to autograd
+ * (diff_gaussian_rasterization/__init__.py:149-153 restacks dL_dconic with three slices, a doubling and a stack: two more
+ * kernels per backward pass of the drop-in op).  NULL: exactly ghr_backward. */
+int ghr_backward_ex(void* stream, const ghr_view_args* a, uint32_t R, const int32_t* radii, const void* geom_ws,
+                    const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
+                    float* dL_dmeans2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_dmeans3D,
+                    float* dL_dcov3D, float* dL_dscales, float* dL_drotations, int32_t prezeroed, float* dL_dconic3);
 
 /* ---- fused model path ------------------------------------------------------------------------
  * One kernel computes, from the RAW parameters of the reference's GaussianModel, everything render() would build with

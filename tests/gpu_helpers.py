@@ -105,12 +105,17 @@ class GpuRun:
         if scratch is None:
             scratch = torch.full((max(self.R, 1), 16), nan, **f)
         dL = dL.to(dev).float().contiguous()
-        _lib.check(self.L.ghr_backward(_stream(), ctypes.byref(self.args), self.R, _ptr(self.radii), _ptr(self.geom),
-                                       _ptr(self.img), _ptr(self.bin) if self.R else None, _ptr(dL), _ptr(scratch),
-                                       _ptr(o["dL_dmeans2D"]), _ptr(o["dL_dconic"]), _ptr(o["dL_dopacity"]),
-                                       _ptr(o["dL_dcolors"]), _ptr(o["dL_dmeans3D"]), _ptr(o["dL_dcov3D"]),
-                                       _ptr(o["dL_dscales"]), _ptr(o["dL_drotations"]), int(prezeroed)))
+        # through ghr_backward_ex (ABI 14: ghr_backward is the same call with dL_dconic3 = NULL); the extra output must be
+        # the reference wrapper's restack of dL_dconic (diff_gaussian_rasterization/__init__.py:149-153), bit for bit
+        conic3 = torch.full((P, 3), nan, **f)
+        _lib.check(self.L.ghr_backward_ex(_stream(), ctypes.byref(self.args), self.R, _ptr(self.radii), _ptr(self.geom),
+                                          _ptr(self.img), _ptr(self.bin) if self.R else None, _ptr(dL), _ptr(scratch),
+                                          _ptr(o["dL_dmeans2D"]), _ptr(o["dL_dconic"]), _ptr(o["dL_dopacity"]),
+                                          _ptr(o["dL_dcolors"]), _ptr(o["dL_dmeans3D"]), _ptr(o["dL_dcov3D"]),
+                                          _ptr(o["dL_dscales"]), _ptr(o["dL_drotations"]), int(prezeroed), _ptr(conic3)))
         torch.cuda.synchronize()
+        c = o["dL_dconic"]
+        assert torch.equal(conic3, torch.stack([c[:, 0, 0], 2 * c[:, 0, 1], c[:, 1, 1]], dim=-1))
         return {k: v.cpu().numpy() for k, v in o.items()}
 
 

@@ -207,7 +207,7 @@ void ghrsim_backward(void* h, const ghr_view_args* a, const float* dL_dpix, floa
     ga.ginst = ginst.data(); ga.inst_line = inst_line.data(); ga.ginst_rows = (uint32_t)s->R;
     ga.rects = s->rects.data(); ga.rec = s->rec.data();
     ga.half_w = 0.5f * a->W; ga.half_h = 0.5f * a->H;
-    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
+    ga.dL_dmeans2D = dL_dmeans2D; ga.dL_dconic = dL_dconic; ga.dL_dconic3 = nullptr; ga.dL_dopacity = dL_dopacity; ga.dL_dcolors = dL_dcolors;
     ga.dL_dmeans3D = dL_dmeans3D; ga.dL_dcov3D = dL_dcov3D; ga.dL_dscales = dL_dscales; ga.dL_drots = dL_drotations;
     for (int idx = 0; idx < P; idx++) {
         float g16[16];
