@@ -60,6 +60,7 @@ class FusedAdam:
         # surgery through the fused renderer clears the marks again (note_direct_backward), a caller that fills .grad any
         # other way before stepping calls ``cancel_skip()``.
         self._skip_next = 0
+        self._deferred = None  # see step(zero_grad="defer")
         # number of higher-order SH coefficients (rows of f_rest's middle axis) that can carry a gradient, i.e.
         # (active_sh_degree + 1)^2 - 1; None = all.  Set by trainer.training_step; only shortens the all-reduce.
         self.active_rest_coeffs = None
@@ -82,12 +83,38 @@ class FusedAdam:
     # another loss, zero_(), an all-reduce) bumps the tensor's version counter, which withdraws the fact.
     def _mark_zero(self):
         self._zero_version = self.flat_grad._version
+        self._deferred = None
 
     def take_known_zero(self) -> bool:
+        if getattr(self, "_deferred", None) is not None:  # see step(zero_grad="defer"): this backward defines them
+            self._check_untouched()
+            self._deferred = None
+            self._zero_version = None
+            return True
         ok = (self._zero_version is not None and self.flat_grad._version == self._zero_version and
               self._direct_backwards == 0)
         self._zero_version = None
         return ok
+
+    # ---- "the gradients are UNDEFINED until the next fused backward assigns them" (step(zero_grad="defer")).  The step of
+    # trainer.training_step is always followed by another training_step whose first backward ASSIGNS every element of the
+    # buffer (k_project_bwd writes all P rows of every group), so zero-filling 4 B per parameter in the Adam pass (an
+    # eighth of its traffic) buys nothing there.  Everything else that could consume the buffer goes through
+    # resolve_deferred() first -- it zero-fills then, which is what the eager step would have left -- and an in-place write
+    # by anyone else while the buffer is undefined (autograd accumulating another loss into .grad) is detected through the
+    # tensor's version counter and fails loudly instead of stepping on garbage.
+    def _check_untouched(self):
+        if self.flat_grad._version != self._deferred:
+            raise RuntimeError("FusedAdam: the gradient buffer was written in place while its contents were undefined "
+                               "(the previous step ran with zero_grad='defer', as trainer.training_step does on the fused "
+                               "path); call optimizer.zero_grad() before accumulating gradients by other means")
+
+    def resolve_deferred(self):
+        """Make the gradient buffer hold zeros if the last step left it undefined (no-op otherwise)."""
+        if getattr(self, "_deferred", None) is not None:
+            self._check_untouched()
+            self.flat_grad.zero_()
+            self._mark_zero()
 
     # ---- gradient-bucket interface (same as parallel.FlatGradBucket)
     @property
@@ -103,6 +130,7 @@ class FusedAdam:
         self._mark_zero()
 
     def all_reduce(self, average_over=None, async_op=False):
+        self.resolve_deferred()
         work = None
         if collectives_on():
             if not async_op and self.active_rest_coeffs is not None:
@@ -121,6 +149,7 @@ class FusedAdam:
         return work
 
     def has_nan(self):
+        self.resolve_deferred()
         return torch.isnan(self.flat_grad).any()
 
     # ---- optimizer-state surgery for densification (reference: gaussian_model.py:581-658 on torch.optim.Adam state)
@@ -183,6 +212,7 @@ class FusedAdam:
     def replace(self, tensor: torch.Tensor, name: str):
         """``replace_tensor_to_optimizer`` (gaussian_model.py:581-594): new values, zeroed moments, for one group."""
         out = {}
+        self.resolve_deferred()  # (the group's gradient is zeroed in place below)
         for i, (g, p, m, v) in enumerate(self._group_views()):
             if g["name"] == name:
                 p.data.copy_(tensor.detach().reshape(p.shape))
@@ -223,6 +253,9 @@ class FusedAdam:
         """``nan_scan=False``: every gradient of this step was produced by the fused renderer's backward on THIS rank
         (which maintains the NaN flag), so the guard needs no pass over the gradients.  Must stay True after an
         all-reduce (another rank's NaN arrives through the sum) or when other losses touched ``.grad``."""
+        self.resolve_deferred()  # (a step without a backward since a deferred one: its gradients are zeros)
+        defer = isinstance(zero_grad, str)
+        assert not defer or zero_grad == "defer"
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 0 if not self.nan_guard else (1 if nan_scan or self._direct_backwards == 0 else 2)
         self._direct_backwards = 0
@@ -232,11 +265,19 @@ class FusedAdam:
             _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                                                self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), skip))
-        if zero_grad:
+                                                self.betas[0], self.betas[1], self.eps, guard,
+                                                0 if defer else int(bool(zero_grad)), skip))
+        self._after_step(zero_grad, defer)
+
+    def _after_step(self, zero_grad, defer):
+        if defer:
+            self._zero_version = None
+            self._deferred = self.flat_grad._version  # undefined until the next fused backward assigns them
+        elif zero_grad:
             self._mark_zero()  # (the kernel zeroes the gradients whether or not the guard lets the update through)
         else:
             self._zero_version = None
+            self._deferred = None
 
     def _chunk_ranges(self, chunks: int):
         n = self.flat_param.numel()
@@ -282,6 +323,9 @@ class FusedAdam:
         +inf on one rank and -inf on another cannot meet as a NaN only inside the sum -- and is OR-ed over the ranks
         first (4 bytes).  Only valid when every gradient of the step came through the fused renderer's direct backward
         (as with ``nan_scan=False``)."""
+        self.resolve_deferred()
+        defer = isinstance(zero_grad, str)
+        assert not defer or zero_grad == "defer"
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 2 if self.nan_guard else 0
         self._direct_backwards = 0
@@ -313,11 +357,9 @@ class FusedAdam:
                 _lib.check(_lib.lib().ghr_adam_step_range(
                     _stream(), n, a, b - a, _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
                     _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(plan) - 1), skip))
-        if zero_grad:
-            self._mark_zero()  # every range of the plan has been through the kernel, which zeroes its gradients
-        else:
-            self._zero_version = None
+                    self.betas[0], self.betas[1], self.eps, guard, 0 if defer else int(bool(zero_grad)),
+                    int(i == len(plan) - 1), skip))
+        self._after_step(zero_grad, defer)  # (every range of the plan has been through the kernel)
 
     def _param_ranges(self):
         off = 0

@@ -28,6 +28,7 @@ def _one_like(loss):
 
 
 OVERLAP_ALL_REDUCE_WITH_ADAM = os.environ.get("GHR_OVERLAP_AR_ADAM", "1") != "0"
+DEFER_GRAD_ZEROING = os.environ.get("GHR_DEFER_GRAD_ZEROING", "1") != "0"
 CACHE_GT_SSIM_STATS = True  # keep the SSIM window moments of every camera's ground truth (2*3*H*W floats per camera)
 
 
@@ -161,6 +162,14 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                    not getattr(pipe, "debug", False))
     n_streams = (2 if streams is None else int(streams)) if can_overlap else 0
     fused_sink = (sink is not None and sink.direct_grads and background.is_cuda and not getattr(pipe, "debug", False))
+    # every view of this step goes through the fused renderer's direct backward (render() decides per camera: a camera
+    # whose tensors require grad takes the generic path, whose gradients arrive through autograd)
+    from .gaussian_renderer import _use_fused
+    all_direct = bool(fused_sink and cams and all(_use_fused(gaussians, pipe, c) for c in cams))
+    if isinstance(getattr(gaussians, "optimizer", None), FusedAdam) and not all_direct:
+        # the previous step may have left the gradient buffer undefined (zero_grad="defer" below): only a fused backward
+        # redefines it -- a rank without views, or the generic / autograd path, needs the zeros the eager step leaves
+        gaussians.optimizer.resolve_deferred()
     defer = fused_sink and (True if defer_counts is None else bool(defer_counts))
     run_pipe = pipe
     if defer:
@@ -192,6 +201,10 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         # every view's gradients went through the fused renderer's direct backward (which keeps the NaN flag) and no
         # other rank contributes: the guard needs no scan over the gradients
         direct_local = gaussians.optimizer._direct_backwards == len(cams)
+        # On the fused path the next training_step's first backward ASSIGNS the whole gradient buffer, so the Adam pass
+        # need not zero it (an eighth of its traffic): FusedAdam.step(zero_grad="defer").  Anything else that touches the
+        # buffer first either gets the zeros (resolve_deferred) or fails loudly (optim.py).
+        zg = "defer" if (all_direct and direct_local and DEFER_GRAD_ZEROING) else True
         # The choice below must be the same on every rank (it decides the sequence of collectives): it only depends on
         # the configuration (`fused_sink`), and a rank whose gradients did not all come through the direct backward
         # fails loudly instead of silently taking the other branch.
@@ -201,10 +214,10 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                 raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
                                    (gaussians.optimizer._direct_backwards, len(cams)))
             # all-reduce in chunks, each chunk's Adam update as soon as its sum is there (FusedAdam.step_chunked)
-            gaussians.optimizer.step_chunked(chunks=4, zero_grad=True, reduce=True)
+            gaussians.optimizer.step_chunked(chunks=4, zero_grad=zg, reduce=True)
             return total
         gaussians.optimizer.all_reduce()
-        gaussians.optimizer.step(zero_grad=True, nan_scan=not (direct_local and not collectives_on()))
+        gaussians.optimizer.step(zero_grad=zg, nan_scan=not (direct_local and not collectives_on()))
         return total
     if bucket is not None:
         bucket.all_reduce()

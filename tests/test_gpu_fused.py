@@ -618,3 +618,78 @@ def test_training_step_after_surgery_is_not_a_skipped_step(pipe):
     assert int(m.optimizer.state_dev[0]) == step0 + 1
     assert int(m.optimizer.state_dev[2:2 + len(m.optimizer.param_groups)].abs().sum()) == 0  # no group sat the step out
     assert (m.optimizer.flat_param != before).float().mean() > 0.2
+
+
+def test_deferred_gradient_zeroing_is_invisible_or_loud():
+    """trainer.training_step on the fused path steps with FusedAdam.step(zero_grad="defer"): the Adam pass leaves the
+    gradient buffer undefined because the next step's first backward ASSIGNS all of it.  (a) Three steps are bit-identical
+    to the eager run (GHR_DEFER_GRAD_ZEROING=0 semantics: trainer.DEFER_GRAD_ZEROING = False); (b) a step() without a
+    backward in between sees zeros; (c) optimizer surgery in between (reset_opacity) works; (d) accumulating gradients by
+    other means while the buffer is undefined fails loudly at the next step instead of stepping on garbage; (e) a step
+    that cannot take the fused path (trainable camera) gets the zeros first."""
+    import gaussianhaircut_amd.trainer as tr
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny_strands"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    cams = ring_cameras(4, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, cams, bg)
+    _lib.lib().ghr_set_deterministic(1)  # two RUNS are compared bit for bit
+    try:
+        runs = []
+        for defer in (True, False):
+            tr.DEFER_GRAD_ZEROING = defer
+            model = syn.make_model(spec, dev)
+            model.training_setup(opt)
+            o = model.optimizer
+            for it in range(3):
+                training_step(model, cams[:2], bg, opt, it + 1)
+                assert (o._deferred is not None) == defer
+            o.step()                                        # (b) no backward since: zeros, whichever way
+            assert o._deferred is None and float(o.flat_grad.abs().sum()) == 0.0
+            training_step(model, cams[:2], bg, opt, 4)
+            model.reset_opacity()                           # (c) surgery between two steps
+            training_step(model, cams[:2], bg, opt, 5)
+            torch.cuda.synchronize()
+            runs.append((o.flat_param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), o.state_dev.clone()))
+        for a, b in zip(*runs):
+            assert torch.equal(a, b)
+        # (d)
+        tr.DEFER_GRAD_ZEROING = True
+        model = syn.make_model(spec, dev)
+        model.training_setup(opt)
+        training_step(model, cams[:2], bg, opt, 1)
+        assert model.optimizer._deferred is not None
+        (model._xyz.sum() * 1.0).backward()                 # autograd accumulates into the undefined buffer
+        with pytest.raises(RuntimeError, match="undefined"):
+            model.optimizer.step()
+        model.optimizer.zero_grad()                         # the documented way out
+        model.optimizer.step()
+        # (e)
+        model = syn.make_model(spec, dev)
+        model.training_setup(opt)
+        ref = syn.make_model(spec, dev)
+        ref.training_setup(opt)
+        training_step(model, cams[:1], bg, opt, 1)
+        tr.DEFER_GRAD_ZEROING = False
+        training_step(ref, cams[:1], bg, opt, 1)
+        tr.DEFER_GRAD_ZEROING = True
+        for m in (model, ref):
+            cam = _trainable_camera(spec, dev)              # a fresh graph per model: full_proj = f(view matrix)
+            with torch.no_grad():
+                make_ground_truth(gt, [cam], bg)
+            training_step(m, [cam], bg, opt, 2)             # generic path: gradients through autograd
+        torch.cuda.synchronize()
+        assert model.optimizer._deferred is None
+        assert torch.equal(model.optimizer.flat_param, ref.optimizer.flat_param)
+    finally:
+        tr.DEFER_GRAD_ZEROING = True
+        _lib.lib().ghr_set_deterministic(0)
