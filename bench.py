@@ -204,7 +204,7 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "gradient walk bound by the misses a CU keeps in flight, not by bandwidth (profiles/r03i, r03j: VALU "
+                "note": "gradient walk bound by the misses a CU keeps in flight, not by bandwidth (profiles/r03i, r03m: VALU "
                         "issue 57 %% of the SIMD cycles at 5 waves per SIMD, TA busy 60 %%, L1 stalled on pending misses 55 %% "
                         "of the kernel: removing the chunk arithmetic saves 17 %%, the atomics 7 %%; every L2 atomic is written "
                         "through to HBM, hence traffic > algorithmic bytes; the zero-fill of the gradient lines runs under "
