@@ -45,3 +45,27 @@ def test_gradient_walk_compiles_without_scratch_and_within_its_register_budget()
     assert k8["group_segment_fixed_size"] <= 32768, k8   # five workgroups per CU of 160 KiB LDS
     k7 = [v for k, v in meta.items() if "k_render_fwd" in k][0]
     assert k7["private_segment_fixed_size"] == 0 and k7["vgpr_count"] <= 80, k7   # six waves per SIMD
+
+
+def test_marching_loss_and_adam_kernels_stay_within_their_occupancy_steps():
+    """The marching loss kernels (csrc/ghr_loss.h) are one wave per workgroup with 12-14 KB of LDS and live on the number
+    of waves in flight; their loops must not spill (a spill is a scratch access inside a loop whose prefetched batch the
+    compiler's waits count).  With the SLP vectoriser's packed FMAs they once spilled 50-80 SCALAR registers into VGPR
+    lanes: the window FMAs are single v_fmac_f32 with the weight in an SGPR since -- a handful of scalar spills in the
+    prologue are tolerated, no vector ones."""
+    meta = _descriptors()
+
+    def one(sub):
+        ks = [v for k, v in meta.items() if sub in k]
+        assert len(ks) == 1, (sub, [k for k in meta if sub in k])
+        return ks[0]
+
+    fwd, bwd, adam = one("k_loss_fwd_cached_v"), one("k_loss_bwd_v"), one("k_adam_v4")
+    for k in (fwd, bwd, adam):
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0, k
+    assert fwd["sgpr_spill_count"] <= 32 and bwd["sgpr_spill_count"] <= 32, (fwd, bwd)
+    assert fwd["vgpr_count"] <= 128, fwd                     # four waves per SIMD
+    assert bwd["vgpr_count"] <= 168, bwd                     # three
+    assert fwd["group_segment_fixed_size"] <= 12288, fwd     # 13 waves per CU
+    assert bwd["group_segment_fixed_size"] <= 14336, bwd     # 11
+    assert adam["vgpr_count"] <= 64, adam
