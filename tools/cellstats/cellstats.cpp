@@ -31,9 +31,10 @@ void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* 
     double cells_cons = 0, cells_exact = 0, one_chunk_cons = 0, one_chunk_exact = 0;
     double fp_margin = 0, fp_sat = 0;   // false positives: no pixel passes the alpha test / passes but all pixels are done
     double half_cons = 0, half_exact = 0;  // tail chunks at most half full
+    double steps64_cell = 0, steps64_tile = 0;  // wave steps of 64 CONTRIBUTING pairs, packed per cell / per tile
 #pragma omp parallel for schedule(dynamic, 8) reduction(+ : pairs, h_cons, h_exact, h_cons_uncut, ch_cons, ch_exact, \
     ch_exact_band, ch_exact_tile, ch_cons_tile, ch_cons_band, ch8_exact, cells_cons, cells_exact, one_chunk_cons,      \
-    one_chunk_exact, fp_margin, fp_sat, half_cons, half_exact)
+    one_chunk_exact, fp_margin, fp_sat, half_cons, half_exact, steps64_cell, steps64_tile)
     for (int tile = 0; tile < T; tile++) {
         const int tx = tile % gx, ty = tile / gx;
         const uint32_t beg = ranges[2 * tile], end = ranges[2 * tile + 1];
@@ -48,6 +49,7 @@ void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* 
             if (last[p] > clast[cell]) clast[cell] = last[p];
         }
         uint32_t hc[16] = {0}, he[16] = {0};
+        uint64_t pc[16] = {0};  // contributing pairs per cell
         uint32_t he8[8] = {0};
         for (uint32_t pos = 0; pos < n; pos++) {
             const uint32_t id = point_list[beg + pos];
@@ -79,6 +81,7 @@ void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* 
                 if (npix > 0) {
                     he[cell]++;
                     pairs += npix;
+                    pc[cell] += (uint64_t)npix;
                     ex8[band * 2 + (g >> 1)] = true;
 #pragma omp atomic
                     hist_pix[npix]++;
@@ -106,12 +109,13 @@ void cellstats(int W, int H, const uint32_t* ranges /*[T][2]*/, const uint32_t* 
             sc += bc; se += be;
         }
         for (int r = 0; r < 8; r++) ch8_exact += (he8[r] + 7) / 8;
+        { uint64_t tp = 0; for (int c = 0; c < 16; c++) { steps64_cell += (double)((pc[c] + 63) / 64); tp += pc[c]; } steps64_tile += (double)((tp + 63) / 64); }
         ch_cons_tile += (sc + 15) / 16; ch_exact_tile += (se + 15) / 16;
     }
     double* o = out;
     *o++ = pairs; *o++ = h_cons; *o++ = h_exact; *o++ = h_cons_uncut; *o++ = ch_cons; *o++ = ch_exact;
     *o++ = ch_cons_band; *o++ = ch_exact_band; *o++ = ch_cons_tile; *o++ = ch_exact_tile; *o++ = ch8_exact;
     *o++ = cells_cons; *o++ = cells_exact; *o++ = one_chunk_cons; *o++ = one_chunk_exact; *o++ = fp_margin; *o++ = fp_sat;
-    *o++ = half_cons; *o++ = half_exact;
+    *o++ = half_cons; *o++ = half_exact; *o++ = steps64_cell; *o++ = steps64_tile;
 }
 }

@@ -32,7 +32,8 @@ def build():
 
 NAMES = ["pairs", "hits_cons", "hits_exact", "hits_cons_uncut", "chunks_cons", "chunks_exact", "chunks_cons_band",
          "chunks_exact_band", "chunks_cons_tile", "chunks_exact_tile", "chunks8_exact_8x4", "cells_cons", "cells_exact",
-         "one_chunk_cells_cons", "one_chunk_cells_exact", "fp_margin", "fp_saturated", "half_tail_cons", "half_tail_exact"]
+         "one_chunk_cells_cons", "one_chunk_cells_exact", "fp_margin", "fp_saturated", "half_tail_cons", "half_tail_exact",
+         "pair_steps64_per_cell", "pair_steps64_per_tile"]
 
 
 def main():
@@ -72,6 +73,11 @@ def main():
               (r["chunks_cons"], r["chunks_exact"] / r["chunks_cons"], r["chunks_exact_band"] / r["chunks_cons"],
                r["chunks_exact_tile"] / r["chunks_cons"], r["chunks_cons_band"] / r["chunks_cons"],
                r["chunks8_exact_8x4"] / r["chunks_cons"]))
+        print("  lanes bound to contributing pairs (DESIGN.md 11): wave steps of 64 pairs packed per cell %.0f (fill %.3f), per "
+              "tile %.0f; today's chunks hold 256 pair slots each: %.0f wave steps of 64 slots -> %.2fx / %.2fx fewer" %
+              (r["pair_steps64_per_cell"], r["pairs"] / 64 / r["pair_steps64_per_cell"], r["pair_steps64_per_tile"],
+               4 * r["chunks_cons"], 4 * r["chunks_cons"] / r["pair_steps64_per_cell"],
+               4 * r["chunks_cons"] / r["pair_steps64_per_tile"]))
         cum = np.cumsum(he[1:].astype(np.float64)) / max(he[1:].sum(), 1)
         print("  hits per working cell (exact): p50 %d p90 %d p99 %d" % tuple(1 + int(np.searchsorted(cum, q)) for q in (.5, .9, .99)))
         print("  histogram hits/cell exact (0..32):", " ".join(str(int(x)) for x in he[:33]))
