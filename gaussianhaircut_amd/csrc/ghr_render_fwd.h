@@ -136,11 +136,24 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                     (128u * (uint32_t)(mask_word0(beg, tile) + ((base + sub) >> 6)) + 8u * (uint32_t)(4 * wave + grp))) = todo;
 #endif
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
+#ifdef GHR_K7_HALVES  // experiment (round 3): the 64-bit list mask walked as two 32-bit halves -- 4 VALU less per step, but the
+                      // groups of a wave now wait for each other twice per 64 entries: cfg3 0.1038 against 0.0997 ms, cfg2 0.1202 against 0.1228
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                uint32_t t32 = (uint32_t)(todo >> (32 * hf));
+                while (t32) {
+                    const uint32_t j = sub + 32u * hf + (uint32_t)__builtin_ctz(t32);
+                    t32 &= t32 - 1;
+                    done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
+                }
+            }
+#else
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
             }
+#endif
             GHR_PROF(4);
         }
     }
