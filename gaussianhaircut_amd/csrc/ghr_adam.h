@@ -113,13 +113,8 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
             while (g3 < a.n_groups - 1 && i + 3 >= a.end[g3]) g3++;
             const bool any = g0 != g3 || !((a.skip_mask >> g0) & 1u);
             if (any) {
-#ifndef GHR_ADAM_CACHED
                 const f4 P = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.p + i)), M = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.m + i)),
                          V = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.v + i)), G = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g + i));
-#else
-                const f4 P = *reinterpret_cast<const f4*>(a.p + i), M = *reinterpret_cast<const f4*>(a.m + i),
-                         V = *reinterpret_cast<const f4*>(a.v + i), G = *reinterpret_cast<const f4*>(a.g + i);
-#endif
                 float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
                 const float gg[4] = {G.x, G.y, G.z, G.w};
 #pragma unroll
@@ -128,22 +123,12 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
                     if (g0 != g3) while (gi < a.n_groups - 1 && i + e >= a.end[gi]) gi++;
                     if (!((a.skip_mask >> gi) & 1u)) adam_update(pp[e], gg[e], mm[e], vv[e], s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
                 }
-#ifndef GHR_ADAM_CACHED
                 __builtin_nontemporal_store(f4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f4*>(a.p + i));
                 __builtin_nontemporal_store(f4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f4*>(a.m + i));
                 __builtin_nontemporal_store(f4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f4*>(a.v + i));
-#else
-                *reinterpret_cast<f4*>(a.p + i) = f4{pp[0], pp[1], pp[2], pp[3]};
-                *reinterpret_cast<f4*>(a.m + i) = f4{mm[0], mm[1], mm[2], mm[3]};
-                *reinterpret_cast<f4*>(a.v + i) = f4{vv[0], vv[1], vv[2], vv[3]};
-#endif
             }
         }
-#ifndef GHR_ADAM_CACHED
         if (a.zero_grad) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(a.g + i));
-#else
-        if (a.zero_grad) *reinterpret_cast<f4*>(a.g + i) = zero;
-#endif
     }
     // the last (n - begin) % 4 elements
     if (blockIdx.x == 0 && threadIdx.x < 4) {

@@ -345,12 +345,8 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     // (the backward render kernel then starts accumulating at once: -10 % of its time inside the step).
     if (ginst != nullptr) {
         const f4 zero = {0.f, 0.f, 0.f, 0.f};
-#ifndef GHR_SORT_CACHED_ZERO  // non-temporal: 83 MB of zeros that nothing reads before K8's L2 atomics, four kernels later
                              // (same call: K8 190.9 -> 189.4 us, loss forward 69.2 -> 66.2, step 0.857 -> 0.850 ms)
         for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
-#else
-        for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) reinterpret_cast<f4*>(ginst)[4 * (size_t)s + i] = zero;
-#endif
     }
     const bool sorted_already = tile_cursor[tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
     __syncthreads();

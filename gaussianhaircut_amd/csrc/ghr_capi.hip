@@ -737,6 +737,12 @@ int ghr_debug_prof(unsigned long long* out, int n_slots, int reset)
     }
     return GHR_OK;
 }
+int ghr_debug_timeline(unsigned long long* out, int n_slots)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return GHR_E_HIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ghr::g_k8_tl), 16 * (size_t)n_slots) != hipSuccess) return GHR_E_HIP;
+    return GHR_OK;
+}
 #endif
 
 int ghr_ws_inspect(int32_t P, int32_t W, int32_t H, int32_t mode_b, uint32_t R, const void* geom_ws,

@@ -316,6 +316,7 @@ GHR_HD size_t mask_groups(size_t R, size_t T) { return (R >> 6) + T + 1; }
 #ifdef GHR_K8_PROF
 #define GHR_PROF_SLOTS 65536
 __device__ unsigned long long g_k8_prof[8 * GHR_PROF_SLOTS];
+__device__ unsigned long long g_k8_tl[2 * GHR_PROF_SLOTS];  // per wave: start timestamp, HW_ID | XCC_ID << 32
 #define GHR_PROF_DECL                                                           \
     unsigned long long prof_t = __builtin_amdgcn_s_memtime(), prof_t0 = prof_t; \
     unsigned long long prof_a[8] = {0, 0, 0, 0, 0, 0, 0, 0}
@@ -330,8 +331,12 @@ __device__ unsigned long long g_k8_prof[8 * GHR_PROF_SLOTS];
     do {                                                                                  \
         prof_a[i] = __builtin_amdgcn_s_memtime() - prof_t0;                               \
         const uint32_t w_ = (blockIdx.x * 4u + (threadIdx.x >> 6)) % GHR_PROF_SLOTS;      \
-        if ((threadIdx.x & 63) == 0)                                                      \
+        if ((threadIdx.x & 63) == 0) {                                                    \
             for (int q_ = 0; q_ < 8; q_++) g_k8_prof[8 * w_ + q_] = prof_a[q_];           \
+            g_k8_tl[2 * w_] = prof_t0;                                                    \
+            g_k8_tl[2 * w_ + 1] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |  \
+                                  ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); \
+        }                                                                                 \
     } while (0)
 #else
 #define GHR_PROF_DECL

@@ -478,21 +478,13 @@ template <typename T>
 __device__ __forceinline__ T ldb(const void* base, uint32_t byte_off)
 {
     asm("" : "+v"(byte_off));
-#ifdef GHR_LOSS_NT_LOADS
-    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
-#else
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-#endif
 }
 template <typename T>
 __device__ __forceinline__ void stb(void* base, uint32_t byte_off, T v)
 {
     asm("" : "+v"(byte_off));
-#ifdef GHR_LOSS_NT_STORES
-    __builtin_nontemporal_store(v, reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off));
-#else
     *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off) = v;
-#endif
 }
 // acc = fma(w, x, acc) with the (uniform) window weight in a scalar register, as ONE v_fmac_f32.  Written out because the
 // SLP vectoriser otherwise pairs the window FMAs into v_pk_fma_f32, which on this chip costs 1.65 plain instructions for two

@@ -559,11 +559,7 @@ __device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src
 #pragma unroll
     for (int it = 0; it < GHR_SLAB_IT; it++) {
         const uint32_t i = tid + GHR_BLOCK * it;
-#ifndef GHR_SLAB_CACHED_LOAD  // non-temporal: read once per kernel (k_project 52.1 -> 50.1 us, k_project_bwd 99.5 -> 96.3)
         if (i < n4) v[it] = __builtin_nontemporal_load(s4 + i);
-#else
-        if (i < n4) v[it] = s4[i];
-#endif
     }
 }
 // registers -> LDS (+ the scalar tail of a partial last block straight from global)
@@ -600,11 +596,7 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
         if (i < n4) {
             f4 v = s4[i];
             if (accumulate) v += old[it];
-#ifdef GHR_SLAB_NT_STORE  // (measured: no gain, and the Adam pass that reads these next gets slower)
-            __builtin_nontemporal_store(v, d4 + i);
-#else
             d4[i] = v;
-#endif
             bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
         }
     }

@@ -29,9 +29,7 @@
 #pragma once
 #include "ghr_device.h"
 
-#ifndef GHR_COMMON_MIN
 #define GHR_COMMON_MIN 8  // batch entries common to a strip's four cells from which the wave-wide path pays
-#endif
 
 namespace ghr {
 

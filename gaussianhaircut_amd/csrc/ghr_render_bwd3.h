@@ -32,21 +32,13 @@
 
 namespace ghr {
 
-#ifndef GHR_B3_SEG_WORDS
 #define GHR_B3_SEG_WORDS 8                       // mask words (of 64 list positions) expanded at a time
-#endif
 #define GHR_B3_LIST (64 * GHR_B3_SEG_WORDS)      // ... hence at most this many hits per segment
-#ifndef GHR_B3_CACHE
 #define GHR_B3_CACHE 2048                        // tiles with at most this many instances keep ids and masks in LDS
-#endif
 #define GHR_B3_CWORDS (GHR_B3_CACHE / 64)
 #define GHR_B3_NBUF 3                            // gather buffers per wave (chunk t, t+1, t+2)
-#ifndef GHR_B3_WAVES
 #define GHR_B3_WAVES 5                           // waves per SIMD the register budget is set for
-#endif
-#ifndef GHR_B3_NW
 #define GHR_B3_NW 4                              // waves of a tile's workgroup (they share the tile's 16 cells)
-#endif
 #define GHR_B3_THREADS (64 * GHR_B3_NW)
 
 // Largest sizes the 32-bit offsets cover (bytes < 4 GiB): checked on the host, which falls back to k_render_bwd
@@ -69,17 +61,11 @@ __device__ __forceinline__ T ld32(const T* base, uint32_t byte_off)
 template <typename T>
 __device__ __forceinline__ T ld32_once(const T* base, uint32_t byte_off)
 {
-#ifdef GHR_B3_PIX_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off));
-#else
     return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
-#endif
 }
 
 // cache policy bits of the record gathers (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef GHR_B3_GATHER_AUX
 #define GHR_B3_GATHER_AUX 0
-#endif
 // 16 B per lane from `base + byte_off` to `lds_dst + 16 * lane` (lds_dst wave-uniform), asynchronously: counted in vmcnt
 __device__ __forceinline__ void gather16_to_lds(const void* base, uint32_t byte_off, void* lds_dst)
 {
@@ -149,24 +135,9 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
     const float phi3 = m == 3 ? 1.f : 0.f;                   // a = sum_q Q dx v_q  -> L3
     const float phi4 = m == 4 ? 1.f : 0.f;                   // a = sum_q Q dy v_q  -> L4
     const float phi5 = m == 5 ? 1.f : 0.f;                   // a = sum_q Q         -> L5
-#ifdef GHR_B3_NOATOM
-    float abl = 0.f;
-#endif
 
-#ifdef GHR_B3_STATIC_CELLS
-    uint32_t my_cell = (uint32_t)wave;  // (with GHR_B3_NW == 4)
-#endif
     for (;;) {
-#ifdef GHR_B3_STATIC_CELLS  // experiment: wave w takes the cells w, w + 4, w + 8, w + 12 (no draw, no balancing)
-        const uint32_t cell = my_cell;
-        my_cell += 4u;
-#elif defined(GHR_B3_CXX_DRAW)
-        uint32_t cell = 0u;
-        if (lane == 0) cell = atomicAdd(&sh.next, 1u);
-        cell = (uint32_t)__builtin_amdgcn_readfirstlane((int)cell);
-#else
         const uint32_t cell = lds_draw(lds_addr(&sh.next));
-#endif
         if (cell >= 16u) break;
         // positions at or beyond the cell's largest n_contrib are dead for all its pixels (backward.cu:490-492)
         const uint32_t gm = min(sh.clast[cell], n);
@@ -196,28 +167,12 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
         // second ones, ...: the chunk's reads below (16 entries side by side) are free of bank conflicts.
         auto issue = [&](uint32_t t) {
             const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
-#ifndef GHR_B3_ENTRY_MAJOR  // lane L gathers quarter L >> 4 of entry L & 15 (64 separate 16-B accesses)
             const uint32_t e = min((uint32_t)lane & 15u, cnt - 1u);
             const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
             const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
             const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
             gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][t % GHR_B3_NBUF][0]);
             if (lane < 16) sh.cslot[wave][t % GHR_B3_NBUF][lane] = slot;
-#else
-            // (measured in round 3, profiles/r03i: parity-green, 0.193 ms against 0.190 -- not kept as the default)
-            // the four lanes 4e .. 4e+3 gather the four quarters of entry e: one 64-B access of the L1 per record instead of
-            // four 16-B ones from lanes 16 apart.  The LDS-DMA puts
-            // lane L's 16 B at slot L, i.e. the record of entry e at 64 e: reading one quarter of 16 entries side by side
-            // would be a 4-way bank conflict, so the quarters of entry e are rotated by e >> 2 inside the record's four slots
-            // (lane 4e + s fetches quarter (s - (e >> 2)) & 3): slot 4e + ((q + (e >> 2)) & 3) is a different one of the
-            // sixteen 16-B bank slots for each of the sixteen entries, for every q.
-            const uint32_t es = (uint32_t)lane >> 2, e = min(es, cnt - 1u);
-            const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
-            const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
-            const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
-            gather16_to_lds(rec, 64u * id + 16u * ((((uint32_t)lane & 3u) - (es >> 2)) & 3u), &sh.rec[wave][t % GHR_B3_NBUF][0]);
-            if ((lane & 3) == 0) sh.cslot[wave][t % GHR_B3_NBUF][es] = slot;
-#endif
         };
         build();
         while (n_c == 0 && w_hi >= GHR_B3_SEG_WORDS) { w_hi -= GHR_B3_SEG_WORDS; build(); }
@@ -298,13 +253,9 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                     // [t >= 1: the gather of chunk t+1 if there is one, the four atomics of chunk t-1] [t == 0: the
                     // gather of chunk 1 if there is one; the pixel loads of a first segment have been waited for above]
                     const bool more = t + 1 < nch;
-#ifdef GHR_B3_NOATOM
-                    if (more) GHR_VMCNT(1); else GHR_VMCNT(0);
-#else
                     if (t >= 2) { if (more) GHR_VMCNT(9); else GHR_VMCNT(8); }
                     else if (t == 1) { if (more) GHR_VMCNT(5); else GHR_VMCNT(4); }
                     else { if (more) GHR_VMCNT(1); else GHR_VMCNT(0); }
-#endif
                 } else {
                     issue(t);
                     GHR_VMCNT(0);
@@ -313,29 +264,15 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 GHR_PROF(3);
                 GHR_PROF_COUNT(7, 1);
 
-#ifdef GHR_B3_NOARITH  // ablation (tools/kbench.py): the chunk's memory skeleton without its arithmetic
-                const f4 d = *reinterpret_cast<const f4*>(reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * (uint32_t)m);
-#else
                 const bool valid = (uint32_t)m < cnt;
                 const uint32_t j = min((uint32_t)m, cnt - 1u);  // lanes past the end recompute the last entry, masked
                 const int f0 = 6 + k, f1 = 10 + k, f2 = 6 + kc2;            // colours k, 4 + k, 8 + k
-#ifndef GHR_B3_ENTRY_MAJOR
                 // field f of entry j sits at float (f >> 2) * 64 + 4 j + (f & 3): quarter-major, see the gather
                 const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * j;
                 const f4 r0 = *reinterpret_cast<const f4*>(R);              // x y a b
                 const f2b r1 = *reinterpret_cast<const f2b*>(R + 64);       // c o
                 const float col0 = R[(f0 >> 2) * 64 + (f0 & 3)], col1 = R[(f1 >> 2) * 64 + (f1 & 3)],
                             col2 = k < 2 ? R[(f2 >> 2) * 64 + (f2 & 3)] : 0.f;
-#else
-                // field f of entry j sits at float 16 j + 4 (((f >> 2) + (j >> 2)) & 3) + (f & 3): see the gather
-                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 16u * j;
-                const uint32_t rot = j >> 2;
-                const f4 r0 = *reinterpret_cast<const f4*>(R + 4u * (rot & 3u));               // x y a b
-                const f2b r1 = *reinterpret_cast<const f2b*>(R + 4u * ((1u + rot) & 3u));      // c o
-                const float col0 = R[4u * ((((uint32_t)f0 >> 2) + rot) & 3u) + ((uint32_t)f0 & 3u)],
-                            col1 = R[4u * ((((uint32_t)f1 >> 2) + rot) & 3u) + ((uint32_t)f1 & 3u)],
-                            col2 = k < 2 ? R[4u * ((((uint32_t)f2 >> 2) + rot) & 3u) + ((uint32_t)f2 & 3u)] : 0.f;
-#endif
                 const float ex = r0.x, ey = r0.y, ca = r0.z, cb = r0.w, cc = r1.x, o = r1.y;
                 const uint32_t pos = 64u * w_lo + list[hi - 1u - j];
                 // colour . dL/dpixel for the lane's four pixels
@@ -401,7 +338,6 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 db = mfma16(wB.x, phiW[2], db);
                 da = mfma16(wB.y, phiW[3], da);
                 const f4 d = da + db;
-#endif
                 // the gather of chunk t+2 goes out before this chunk's atomics (see GHR_VMCNT above)
                 if (SMALL && t + 2 < nch) issue(t + 2);
                 // a DPP row adds one whole 64-B line per register: resolved in this XCD's L2 (only this workgroup ever
@@ -420,9 +356,6 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                     const unsigned long long has = rows >= 4u ? ~0ull : ((1ull << (16u * rows)) - 1ull);
                     float val = r == 0 ? d.x : (r == 1 ? d.y : (r == 2 ? d.z : d.w));
                     val = ((has >> lane) & 1ull) ? val : 0.f;  // (only lane 0 can be active without an entry)
-#ifdef GHR_B3_NOATOM  // ablation: the arithmetic stays alive, the memory operation goes
-                    abl += val * (float)(sl[r] & 1u);
-#else
                     const unsigned long long on = has | 1ull;
                     const uint32_t off = 64u * sl[r] + 4u * (uint32_t)m;
                     unsigned long long saved;
@@ -433,7 +366,6 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                                  : "=&s"(saved)
                                  : "s"(on), "v"(off), "v"(val), "s"(ginst)
                                  : "memory");
-#endif
                 }
                 GHR_PROF(4);
             }
@@ -450,17 +382,11 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
             }
         }
     }
-#ifdef GHR_B3_NOATOM
-    if (abl == 12345.678f) ginst[tid] = abl;
-#endif
     GHR_PROF(5);
     GHR_PROF_END(6);
 }
 #endif
 
-#ifdef GHR_B3_VGPRS  // experiment: waves per SIMD the register allocator must make room for (6 -> 80 VGPRs)
-__attribute__((amdgpu_waves_per_eu(GHR_B3_VGPRS, GHR_B3_VGPRS)))
-#endif
 __global__ void __launch_bounds__(GHR_B3_THREADS, GHR_B3_WAVES) k_render_bwd_cells(int W, int H, int gx, uint32_t T_tiles,
                                                                 const uint32_t* __restrict__ tile_start,
                                                                 const uint32_t* __restrict__ point_list,
@@ -479,9 +405,6 @@ __global__ void __launch_bounds__(GHR_B3_THREADS, GHR_B3_WAVES) k_render_bwd_cel
     const int tid = threadIdx.x;
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T_tiles);  // heaviest first (k_tile_scan)
     if (tile >= T_tiles) return;  // grid padding
-#ifdef GHR_B3_ONLY_EVERY  // experiment (wrong results): only every n-th workgroup works -- how the launch time scales with the work
-    if ((blockIdx.x >> 3) % GHR_B3_ONLY_EVERY != 0) return;  // (per XCD: workgroup b runs on XCD b % 8)
-#endif
     const int tx = tile % gx, ty = tile / gx;
     const uint32_t beg = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - beg;  // see k_render_bwd for `cap`

@@ -129,38 +129,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
             GHR_PROF(3);
             // word (base + sub) / 64 of this cell: every position a pixel of the cell can count in n_contrib lies in a
             // word written here (a cell that is finished, or a tile that stops early, has all its n_contrib behind it)
-#ifndef GHR_K7_NOMASK
             // (uniform base + 32-bit byte offset: one address register; the kernel sits at the 80-VGPR occupancy step)
             if (l == 0)
                 *reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(cell_mask) +
                     (128u * (uint32_t)(mask_word0(beg, tile) + ((base + sub) >> 6)) + 8u * (uint32_t)(4 * wave + grp))) = todo;
-#endif
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
-#ifdef GHR_K7_HALVES  // experiment (round 3): the 64-bit list mask walked as two 32-bit halves -- 4 VALU less per step, but the
-                      // groups of a wave now wait for each other twice per 64 entries: cfg3 0.1038 against 0.0997 ms, cfg2 0.1202 against 0.1228
-#pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                uint32_t t32 = (uint32_t)(todo >> (32 * hf));
-                while (t32) {
-                    const uint32_t j = sub + 32u * hf + (uint32_t)__builtin_ctz(t32);
-                    t32 &= t32 - 1;
-                    done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
-                }
-            }
-#else
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
                 const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
                 done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
             }
-#endif
             GHR_PROF(4);
         }
     }
 
 #undef GHR_GATHER
 
-#ifndef GHR_K7_NOLAST
     {   // the cell's largest n_contrib: positions at or beyond it are dead for all its pixels (backward.cu:490-492)
         uint32_t lm = inside ? st.last : 0u;
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 1));
@@ -169,18 +153,13 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
         lm = max(lm, (uint32_t)__shfl_xor((int)lm, 8));
         if (l == 0) *reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(cell_last) + (64u * tile + 4u * (uint32_t)(4 * wave + grp))) = lm;
     }
-#endif
     if (inside) {  // forward.cu:393-399
         const size_t pix = (size_t)W * py + px;
         const size_t plane = (size_t)W * H;
         final_T[pix] = st.T;
         n_contrib[pix] = st.last;
 #pragma unroll
-#ifdef GHR_K7_NT_OUT  // (measured: no change -- the loss reads these planes next)
-        for (int c = 0; c < GHR_C; c++) __builtin_nontemporal_store(st.C[c] + st.T * bg[c], out_color + c * plane + pix);
-#else
         for (int c = 0; c < GHR_C; c++) out_color[c * plane + pix] = st.C[c] + st.T * bg[c];
-#endif
     }
     GHR_PROF(5);
 #ifdef GHR_K7_PROF

@@ -16,7 +16,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from ..scene.cameras import Camera, make_camera
+from ..scene.cameras import Camera, make_camera, parity_camera
 from ..scene.gaussian_model import GaussianModel
 from .general_utils import inverse_sigmoid, parallel_transport
 
@@ -124,17 +124,21 @@ def make_model(spec: WorkloadSpec, device="cpu", sh_degree: int = 3) -> Gaussian
     return m
 
 
-def make_view(spec: WorkloadSpec, device="cpu") -> Camera:
-    return make_camera(spec.W, spec.H, fovy_deg=40.0, distance=4.0, device=device)
+def make_view(spec: WorkloadSpec, device="cpu", cam: str = "front") -> Camera:
+    """``cam``: one of scene.cameras.PARITY_CAMERAS ("front" = the SURVEY 8(d) camera, identity rotation)."""
+    if cam == "front":
+        return make_camera(spec.W, spec.H, fovy_deg=40.0, distance=4.0, device=device)
+    return parity_camera(cam, spec.W, spec.H, device=device)
 
 
 @torch.no_grad()
 def raster_inputs(spec: WorkloadSpec, device="cpu", model: Optional[GaussianModel] = None,
-                  cam: Optional[Camera] = None) -> Dict[str, object]:
+                  cam=None) -> Dict[str, object]:
     """Everything the rasterizer op consumes in pipeline mode (A) for one view, built with the host-side projection
     (same tensors ``render()`` would pass, gaussian_renderer/__init__.py:58-96), without autograd."""
     model = model or make_model(spec, device)
-    cam = cam or make_view(spec, device)
+    if cam is None or isinstance(cam, str):
+        cam = make_view(spec, device, cam or "front")
     conic = model.get_conic(cam)
     means2D = model.get_mean_2d(cam)
     from .sh_utils import eval_sh

@@ -27,8 +27,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-CASES = [("tiny", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"), ("ragged", "A"), ("tiny_strands", "A_sr"),
-         ("cfg1", "A")]
+# (workload, mode, camera): cameras are scene/cameras.py:parity_camera -- "front" (R = I), "ring5" (view 5 of BASELINE
+# configs[3]'s ring) and "ring13roll" (view 13 rolled 20 deg: all nine entries of the view rotation non-trivial, as with the
+# COLMAP poses the reference renders, src/scene/cameras.py:72-80)
+CASES = [("tiny", "A", "front"), ("tiny", "B_sr", "front"), ("tiny", "B_cov", "front"), ("ragged", "A", "front"),
+         ("tiny_strands", "A_sr", "front"), ("cfg1", "A", "front"),
+         ("tiny", "A", "ring13roll"), ("tiny", "B_sr", "ring13roll"), ("tiny", "B_cov", "ring5"),
+         ("ragged", "B_sr", "ring5"), ("tiny_strands", "A_sr", "ring13roll"), ("tiny_strands", "B_sr", "ring5")]
+
+
+def case_tag(cfg, mode, cam):
+    return "%s/%s/" % (cfg if cam == "front" else cfg + "@" + cam, mode)
 
 
 def _ptr(t):
@@ -84,26 +93,39 @@ def run_reference(L, ri, mode, dL, dev):
     return res
 
 
-def main():
-    assert torch.cuda.is_available(), "needs the MI355X box"
-    so = os.path.join(ROOT, "oracle", "_ref", "libghr_ref.so")
+def load_reference(strict=False):
+    """oracle/_ref/libghr_ref.so (the reference's sources with the compiler's defaults, as R:setup.py builds them) or
+    libghr_ref_strict.so (the same sources with -ffp-contract=off: see oracle/Makefile.ref for why rotated cameras need it)."""
+    so = os.path.join(ROOT, "oracle", "_ref", "libghr_ref_strict.so" if strict else "libghr_ref.so")
     assert os.path.exists(so), "build it first in the build container: make -C oracle -f Makefile.ref"
     L = ctypes.CDLL(so)
     L.ghr_ref_last_error.restype = ctypes.c_char_p
+    return L
+
+
+def main():
+    assert torch.cuda.is_available(), "needs the MI355X box"
+    import gaussianhaircut_amd._lib as _lib
+    _lib.lib()  # torch's HIP runtime and the product first: every HIP-linked library shares one runtime
+    # front camera (R = I: fusing a*b+c or not gives the same bits in K1): the default build, as in rounds 1-3; rotated
+    # cameras: the strict build (a contracting compiler's choice of WHICH products to fuse moves the last bit of the depth
+    # keys; tests/test_gpu_reference_live.py compares with the default build up to exactly that)
+    libs = {False: load_reference(False), True: load_reference(True)}
     import oracle
     from gaussianhaircut_amd.utils import synthetic as syn
     from tests import helpers as hp
     dev = torch.device("cuda:0")
     out = {}
-    for cfg, mode in CASES:
+    for cfg, mode, cam in CASES:
         spec = syn.CONFIGS[cfg]
-        ri = syn.raster_inputs(spec)
+        ri = syn.raster_inputs(spec, cam=cam)
         _, _, st_o = hp.oracle_forward(oracle, ri, mode)
         frag = st_o.fragile.astype(bool)
         dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
         dL[:, torch.from_numpy(frag)] = 0.0
-        res = run_reference(L, ri, mode, dL, dev)
-        tag = "%s/%s/" % (cfg, mode)
+        res = run_reference(libs[cam != "front"], ri, mode, dL, dev)
+        tag = case_tag(cfg, mode, cam)
+        out[tag + "in_strict_build"] = np.int64(cam != "front")
         for k in ("means3D", "colors", "opacities", "cov3D", "conic", "scales", "rotations", "bg", "viewmatrix",
                   "projmatrix", "campos"):
             out[tag + "in_" + k] = ri[k].numpy()

@@ -69,11 +69,14 @@ def main():
 
     from gaussianhaircut_amd.utils import synthetic as syn  # our generator only supplies the INPUT tensors
     out = {}
-    for cfg in ("tiny", "tiny_strands"):
+    # cameras: scene/cameras.py:parity_camera -- "front" has R = I; "ring5" / "ring13roll" are rotated / rolled ring views (all
+    # nine entries of W non-trivial, as with the COLMAP poses of src/scene/cameras.py:72-80)
+    for cfg, camname in (("tiny", "front"), ("tiny_strands", "front"), ("tiny", "ring13roll"), ("tiny_strands", "ring5")):
         spec = syn.CONFIGS[cfg]
         p = (syn.random_gaussian_params(spec.P, spec.seed, spec.log_scale_mean) if spec.kind == "random"
              else syn.strand_gaussian_params(spec.n_strands, spec.P, spec.seed))
-        cam = syn.make_view(spec)
+        cam = syn.make_view(spec, cam=camname)
+        cfg = cfg if camname == "front" else cfg + "@" + camname
         m = ref_gm.GaussianModel(3)
         m._xyz, m._scaling, m._rotation = p["xyz"], p["log_scales"], p["rotations"]
         m._opacity, m._label, m._orient_conf = p["opacity_logit"], p["label_logit"], p["orient_conf_log"]
@@ -96,6 +99,14 @@ def main():
             out[cfg + "/sh%d" % deg] = ref_sh.eval_sh(deg, shs_view, d).numpy()
         out[cfg + "/view"] = cam.world_view_transform.numpy()
         out[cfg + "/proj"] = cam.full_proj_transform.numpy()
+        # the same camera built by the REFERENCE's own functions in the order of src/scene/cameras.py:72-80 from (R, T, FoV)
+        wv = torch.tensor(ref_graphics.getWorld2View2(cam.R, cam.T)).transpose(0, 1)
+        pm = ref_graphics.getProjectionMatrix(znear=0.01, zfar=100.0, fovX=cam.FoVx, fovY=cam.FoVy).transpose(0, 1)
+        out[cfg + "/cam_R"], out[cfg + "/cam_T"] = cam.R, cam.T
+        out[cfg + "/cam_fov"] = np.array([float(cam.FoVx), float(cam.FoVy)])
+        out[cfg + "/ref_view"] = wv.numpy()
+        out[cfg + "/ref_proj"] = wv.unsqueeze(0).bmm(pm.unsqueeze(0)).squeeze(0).numpy()
+        out[cfg + "/ref_center"] = wv.inverse()[3, :3].numpy()
 
     # ---- the strand-parametrised model (src/scene/gaussian_model_strands.py): its module imports trimesh / pysdf /
     # NeuralHaircut networks at import time and builds them in __init__; stub the imports, bypass __init__ and drive
@@ -126,14 +137,19 @@ def main():
     out["strands/origins"], out["strands/dirs"], out["strands/features"] = origins.numpy(), dirs.numpy(), feats.numpy()
     out["strands/xyz"], out["strands/rotation"] = m._xyz.numpy(), m._rotation.numpy()
     out["strands/scaling"] = m._scaling.numpy()
-    conic = m.get_conic(cam)
-    out["strands/conic"] = conic.numpy()
-    out["strands/cov2d"] = m.cov.numpy()  # this class caches the 2D covariance in .cov (gaussian_model_strands.py:300)
-    out["strands/cov3D"] = m.get_covariance().numpy()
-    out["strands/mean2d"] = m.get_mean_2d(cam).numpy()
-    out["strands/depths"] = m.get_depths(cam).numpy()
-    out["strands/dir2d"] = m.get_direction_2d(cam).numpy()
-    out["strands/mask"] = m.filter_points(cam).numpy()
+    for camname in ("front", "ring13roll"):
+        cam = syn.make_view(spec, cam=camname)
+        tg = "strands/" if camname == "front" else "strands@" + camname + "/"
+        conic = m.get_conic(cam)
+        out[tg + "conic"] = conic.numpy()
+        out[tg + "cov2d"] = m.cov.numpy()  # this class caches the 2D covariance in .cov (gaussian_model_strands.py:300)
+        out[tg + "cov3D"] = m.get_covariance().numpy()
+        out[tg + "mean2d"] = m.get_mean_2d(cam).numpy()
+        out[tg + "depths"] = m.get_depths(cam).numpy()
+        out[tg + "dir2d"] = m.get_direction_2d(cam).numpy()
+        out[tg + "mask"] = m.filter_points(cam).numpy()
+        out[tg + "view"], out[tg + "proj"] = cam.world_view_transform.numpy(), cam.full_proj_transform.numpy()
+        out[tg + "campos"] = cam.camera_center.numpy()
     out["strands/opacity"], out["strands/label"] = m.get_opacity.numpy(), m.get_label.numpy()
     out["strands/orient_conf"] = m.get_orient_conf.numpy()
 

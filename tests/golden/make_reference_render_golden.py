@@ -33,31 +33,66 @@ def functional(pkg, w):
     return (full * w).sum()
 
 
-def run_render(render_fn, cfg):
+# (workload, camera): scene/cameras.py:parity_camera -- "front" has R = I, the others are rotated / rolled ring views
+RENDER_CASES = [("tiny", "front"), ("tiny_strands", "front"), ("tiny", "ring13roll"), ("tiny_strands", "ring5")]
+HAIR_CAMS = ["front", "ring13roll"]
+
+
+def render_tag(cfg, cam):
+    return "render/%s/" % (cfg if cam == "front" else cfg + "@" + cam)
+
+
+def hair_tag(cam):
+    return "render_hair/" if cam == "front" else "render_hair@%s/" % cam
+
+
+def run_render(render_fn, cfg, cam="front", arbiter=False):
+    """arbiter: also the gradients of the SAME chain evaluated in IEEE double (this repo's render() on float64 copies of
+    the parameters, oracle/ghr_oracle64.c over the fp32 oracle's lists) as "grad64_*": T <- T / (1 - alpha) amplifies
+    last-bit differences of alpha by alpha / (1 - alpha), so on an ill-conditioned row two correct fp32 chains can sit
+    several 1e-4 of the row apart (tiny@ring13roll, Gaussian 1300: the reference's own fp32 chain is 5.6 bars from the
+    double result); the GPU replay is judged against the double result with the fp32 golden's own distance as allowance."""
     from gaussianhaircut_amd.utils import synthetic as syn
     from tests import oracle_backend as ob
     spec = syn.CONFIGS[cfg]
-    model, cam = syn.make_model(spec, "cpu"), syn.make_view(spec, "cpu")
+    model, cam = syn.make_model(spec, "cpu"), syn.make_view(spec, "cpu", cam)
     with ob.oracle_rasterizer():
         pkg = render_fn(cam, model, PIPE, syn.background("cpu"))
-        frag = ob.LAST["state"].fragile.reshape(spec.H, spec.W).astype(bool)
+        st32 = ob.LAST["state"]
+        frag = st32.fragile.reshape(spec.H, spec.W).astype(bool)
+        g64, p64 = {}, None
+        if arbiter:
+            from gaussianhaircut_amd.gaussian_renderer import render as our_render
+            m64, c64 = ob.double_chain(model, cam, model.filter_points(cam))
+            with ob.oracle_rasterizer64(st32):
+                p64 = our_render(c64, m64, PIPE, syn.background("cpu").double())
+                # pixels whose stop decision falls the other way in double leave the functional on every side (they join
+                # the stored "fragile" mask, which the replay applies to its weights)
+                frag = frag | (ob.LAST["n_contrib64"] != st32.n_contrib).reshape(spec.H, spec.W)
         w = weights(spec, 5)
         w[:, torch.from_numpy(frag)] = 0.0
         functional(pkg, w).backward()
+        if arbiter:
+            with ob.oracle_rasterizer64(st32):
+                functional(p64, w.double()).backward()
+            for n in PARAMS:
+                g64["grad64" + n] = getattr(m64, n).grad.numpy().astype(np.float32)   # (rounded once: 6e-8 << the 1e-4 bar)
+            g64["grad64_viewspace"] = p64["viewspace_points"].grad.numpy().astype(np.float32)
     out = {k: pkg[k].detach().numpy() for k in ("render", "mask", "orient_angle", "orient_conf", "viewspace_points",
                                                  "visibility_filter", "radii")}
     out["fragile"] = np.packbits(frag.reshape(-1))
     for n in PARAMS:
         out["grad" + n] = getattr(model, n).grad.numpy()
     out["grad_viewspace"] = pkg["viewspace_points"].grad.numpy()
+    out.update(g64)
     return out
 
 
-def run_render_hair(render_hair_fn):
+def run_render_hair(render_hair_fn, cam="front"):
     from gaussianhaircut_amd.utils import synthetic as syn
     from tests import oracle_backend as ob
     from tests.test_api_cpu import _hair_scene
-    spec, head, hair, cam = _hair_scene("cpu")
+    spec, head, hair, cam = _hair_scene("cpu", cam)
     hair.initialize_gaussians_hair()
     with ob.oracle_rasterizer():
         pkg = render_hair_fn(cam, head, hair, PIPE, syn.background("cpu"))
@@ -79,11 +114,12 @@ def main():
     assert refload.available(), "run in the build container (needs /root/reference)"
     ref = refload.load_reference_renderer()
     out = {}
-    for cfg in ("tiny", "tiny_strands"):
-        for k, v in run_render(ref.render, cfg).items():
-            out["render/%s/%s" % (cfg, k)] = v
-    for k, v in run_render_hair(ref.render_hair).items():
-        out["render_hair/%s" % k] = v
+    for cfg, cam in RENDER_CASES:
+        for k, v in run_render(ref.render, cfg, cam, arbiter=True).items():
+            out[render_tag(cfg, cam) + k] = v
+    for cam in HAIR_CAMS:
+        for k, v in run_render_hair(ref.render_hair, cam).items():
+            out[hair_tag(cam) + k] = v
     dst = os.path.join(HERE, "reference_render_golden.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes;", len(out), "arrays")

@@ -137,7 +137,7 @@ def test_training_step_decreases_loss_with_oracle_backend():
     assert losses[-1] < losses[0]
 
 
-def _hair_scene(dev="cpu"):
+def _hair_scene(dev="cpu", cam="front"):
     """A frozen head (free Gaussians, half of them labelled head) + explicit strands, as src/train_strands.py sets up."""
     from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
     spec = syn.CONFIGS["tiny"]
@@ -152,7 +152,7 @@ def _hair_scene(dev="cpu"):
     dirs = torch.randn(S, n_seg, 3, generator=g) * 0.015 + torch.randn(S, 1, 3, generator=g) * 0.03
     feats = torch.randn(S * n_seg, 16, 3, generator=g) * 0.2
     hair = GaussianModelStrands(3).create_from_strands(origins.to(dev), dirs.to(dev), feats.to(dev))
-    return spec, head, hair, syn.make_view(spec, dev)
+    return spec, head, hair, syn.make_view(spec, dev, cam)
 
 
 def test_render_hair_dict_gradients_and_plumbing_with_oracle_backend():

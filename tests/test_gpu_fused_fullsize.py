@@ -50,7 +50,7 @@ def _assert_rows(name, a, b, tol=hp.TOL, floor=FLOOR):
                              (name, (~ok).sum(), ok.size, r, c, a2[r, c], b2[r, c], np.abs(b2[r]).max(), np.abs(b2).max()))
 
 
-def _chains(cfg, dev, deg=3):
+def _chains(cfg, dev, deg=3, cam="front"):
     """Forward of both chains + the stage-by-stage comparison.  Returns what the loss legs need."""
     from tests import oracle_backend as ob
     from tests.gpu_helpers import inspect_fused
@@ -58,7 +58,7 @@ def _chains(cfg, dev, deg=3):
     W, H = spec.W, spec.H
     mc, mg = syn.make_model(spec, "cpu"), syn.make_model(spec, dev)
     mc.active_sh_degree = mg.active_sh_degree = deg
-    cc, cg = syn.make_view(spec, "cpu"), syn.make_view(spec, dev)
+    cc, cg = syn.make_view(spec, "cpu", cam), syn.make_view(spec, dev, cam)
     with ob.oracle_rasterizer():
         pc = render(cc, mc, GENERIC, syn.background("cpu"))
     st = ob.LAST["state"]
@@ -157,13 +157,16 @@ def _grads(model, pkg):
     return g
 
 
-@pytest.mark.parametrize("cfg", ["cfg2", "cfg3", "cfg5"])
-def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg):
+# cameras: scene/cameras.py:parity_camera (rotated / rolled ring views: k_project's T = W J, the strand direction and the SH
+# view direction all see a full 3x3 view rotation there, as with the COLMAP poses of src/scene/cameras.py:72-80)
+@pytest.mark.parametrize("cfg,cam", [("cfg2", "front"), ("cfg3", "front"), ("cfg5", "front"), ("cfg3", "ring13roll"),
+                                     ("cfg2", "ring5")])
+def test_fused_render_loss_backward_vs_oracle_chain_full_size(oracle_mod, cfg, cam):
     from gaussianhaircut_amd.fused_loss import stage1_loss
     from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
     from gaussianhaircut_amd.trainer import view_loss
     dev = torch.device("cuda:0")
-    spec, (mc, cc, pc), (mg, cg, pg), mask, stats = _chains(cfg, dev)
+    spec, (mc, cc, pc), (mg, cg, pg), mask, stats = _chains(cfg, dev, cam=cam)
     H, W = spec.H, spec.W
 
     # ---- leg A: a seeded linear functional of the 10 output planes (dL/dout ~ N(0,1), SURVEY 8(d) cfg 2), zero on the

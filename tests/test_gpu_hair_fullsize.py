@@ -32,7 +32,7 @@ GENERIC = SimpleNamespace(debug=False, fused_projection=False)
 N_HEAD, STRANDS, SEG = 100_000, 6061, 99
 
 
-def _scene(dev):
+def _scene(dev, cam="front"):
     from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
     spec = syn.WorkloadSpec("hair_head_200k", 2 * N_HEAD, 1920, 1080, 21, "random", np.log(0.008))
     head = syn.make_model(spec, dev)
@@ -55,7 +55,7 @@ def _scene(dev):
                                                        orient_conf_log=conf.to(dev))
     hair.active_sh_degree = 3
     hair.initialize_gaussians_hair()
-    return spec, head, hair, syn.make_view(spec, dev)
+    return spec, head, hair, syn.make_view(spec, dev, cam)
 
 
 def _rects(xy, rad, W, H):
@@ -71,14 +71,15 @@ def _rects(xy, rad, W, H):
     return out
 
 
-def test_render_hair_fused_vs_oracle_chain_at_strand_stage_size(oracle_mod):
+@pytest.mark.parametrize("cam", ["front", "ring13roll"])   # scene/cameras.py:parity_camera (R = I / a rolled ring view)
+def test_render_hair_fused_vs_oracle_chain_at_strand_stage_size(oracle_mod, cam):
     from gaussianhaircut_amd.gaussian_renderer import render_hair
     from tests import oracle_backend as ob
     from tests.gpu_helpers import inspect_fused
     from tests.test_gpu_fused_fullsize import _assert_rows
     dev = torch.device("cuda:0")
-    spec, head_c, hair_c, cam_c = _scene("cpu")
-    _, head_g, hair_g, cam_g = _scene(dev)
+    spec, head_c, hair_c, cam_c = _scene("cpu", cam)
+    _, head_g, hair_g, cam_g = _scene(dev, cam)
     W, H = spec.W, spec.H
     n_head, n_hair = int(head_c.mask_precomp.sum()), hair_c.get_xyz.shape[0]
     assert n_head == N_HEAD and n_hair == STRANDS * SEG

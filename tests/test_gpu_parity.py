@@ -47,15 +47,20 @@ def _check_forward(run, out_o, radii_o, st_o, frag_limit=2e-3):
     return ins
 
 
-CASES = [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"),
-         ("tiny_strands", "A_sr"), ("cfg1", "A"), ("cfg1", "B_sr")]
+# cameras: scene/cameras.py:parity_camera -- the front camera has R = I, under which a transposed view rotation in K1 mode B
+# (forward.cu:74-113) or K9 (backward.cu:144-274) would go unnoticed; "ring5" / "ring13roll" are rotated / rolled ring views
+CASES = [(c, m, "front") for c, m in [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"),
+                                      ("tiny", "B_cov"), ("tiny_strands", "A_sr"), ("cfg1", "A"), ("cfg1", "B_sr")]] + \
+        [("tiny", "A", "ring5"), ("tiny", "B_sr", "ring13roll"), ("tiny", "B_cov", "ring5"), ("tiny", "B_cov", "ring13roll"),
+         ("tiny_strands", "A_sr", "ring13roll"), ("ragged", "B_sr", "ring5"), ("cfg1", "A", "ring13roll"),
+         ("cfg1", "B_sr", "ring5"), ("cfg1", "B_cov", "ring13roll")]
 
 
-@pytest.mark.parametrize("cfg,mode", CASES)
-def test_forward_backward_vs_oracle(oracle_mod, dev, cfg, mode):
+@pytest.mark.parametrize("cfg,mode,cam", CASES)
+def test_forward_backward_vs_oracle(oracle_mod, dev, cfg, mode, cam):
     from tests.gpu_helpers import GpuRun, to_dev
     spec = syn.CONFIGS[cfg]
-    ri = syn.raster_inputs(spec)
+    ri = syn.raster_inputs(spec, cam=cam)
     out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
     run = GpuRun(to_dev(ri, dev), mode)
     _check_forward(run, out_o, radii_o, st_o)
@@ -66,13 +71,15 @@ def test_forward_backward_vs_oracle(oracle_mod, dev, cfg, mode):
     hp.assert_grads_close(got, ref)
 
 
-@pytest.mark.parametrize("mode", ["A", "B_sr"])
-def test_cfg2_full_size_vs_oracle(oracle_mod, dev, mode):
+@pytest.mark.parametrize("mode,cam", [("A", "front"), ("B_sr", "front"), ("A", "ring5"), ("B_sr", "ring13roll"),
+                                      ("B_cov", "ring13roll")])
+def test_cfg2_full_size_vs_oracle(oracle_mod, dev, mode, cam):
     """BASELINE.json configs[1]: 100k Gaussians, 1920x1080, fwd+bwd vs the oracle at full size (tol 1e-4), in pipeline
-    mode (A) and with the covariance computed in the kernel from scales + rotations (B_sr: K9 / K10 / cov3D backward)."""
+    mode (A) and with the covariance computed in the kernel from scales + rotations (B_sr: K9 / K10 / cov3D backward) or
+    from a given 3D covariance (B_cov); through the front camera and through rotated / rolled ring views."""
     from tests.gpu_helpers import GpuRun, to_dev
     spec = syn.CONFIGS["cfg2"]
-    ri = syn.raster_inputs(spec)
+    ri = syn.raster_inputs(spec, cam=cam)
     out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
     run = GpuRun(to_dev(ri, dev), mode, debug=False)
     _check_forward(run, out_o, radii_o, st_o)

@@ -3,8 +3,10 @@
 oracle/_ref/libghr_ref.so is the reference's cuda_rasterizer/* compiled for gfx950 by oracle/Makefile.ref (a checker:
 __graft_entry__.build() makes it where /root/reference exists; the .so travels with the snapshot -- nothing here reads
 /root/reference).  The committed golden (tests/golden/reference_cuda_golden.npz) stops at 9 581 Gaussians @ 256x256
-because a file has to stay small; a live run does not: cfg2 (BASELINE configs[1], 100k blobs @ 1080p: modes A and
-B_sr), cfg3 (configs[2]'s view, 500k strands @ 1080p) and one dense tile with massive depth ties (20 000 instances,
+because a file has to stay small; a live run does not: cfg2 (BASELINE configs[1], 100k blobs @ 1080p: modes A,
+B_sr and B_cov), cfg3 (configs[2], 500k strands @ 1080p: modes A and A_sr, what render_hair() hands the op), cfg5
+(configs[4], 2M strands) -- through the front camera AND through rotated / rolled ring cameras (configs[3]'s view set) -- 
+and one dense tile with massive depth ties (20 000 instances,
 the reference's multi-round `rounds` loops of forward.cu:287-400 / backward.cu:403-561 and our > 2048-instance paths).
 
 Compared directly, no oracle in between: radii, instance count, tile ranges, sorted point lists bit for bit; n_contrib
@@ -26,17 +28,30 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 SO = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref.so")
+SO_STRICT = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref_strict.so")
+
+
+def _load(path):
+    if not os.path.exists(path):
+        pytest.skip("%s is not built (needs /root/reference at build time)" % os.path.relpath(path, hp.ROOT))
+    import gaussianhaircut_amd._lib as _lib
+    _lib.lib()  # torch's HIP runtime and the product first: every HIP-linked library shares one runtime
+    L = ctypes.CDLL(path)
+    L.ghr_ref_last_error.restype = ctypes.c_char_p
+    return L
 
 
 @pytest.fixture(scope="module")
 def ref_lib():
-    if not os.path.exists(SO):
-        pytest.skip("oracle/_ref/libghr_ref.so is not built (needs /root/reference at build time)")
-    import gaussianhaircut_amd._lib as _lib
-    _lib.lib()  # torch's HIP runtime and the product first: every HIP-linked library shares one runtime
-    L = ctypes.CDLL(SO)
-    L.ghr_ref_last_error.restype = ctypes.c_char_p
-    return L
+    """the reference's sources with the compiler's defaults (fp contraction on, as nvcc's are: R:setup.py:29)"""
+    return _load(SO)
+
+
+@pytest.fixture(scope="module")
+def ref_lib_strict():
+    """the same sources with -ffp-contract=off (oracle/Makefile.ref): float results that do not depend on WHICH a*b+c a
+    compiler chose to fuse -- what bit-for-bit comparisons through a rotated camera need"""
+    return _load(SO_STRICT)
 
 
 def _compare(ref_lib, oracle_mod, ri, mode, dL, frag_limit=5e-3):
@@ -74,20 +89,176 @@ def _compare(ref_lib, oracle_mod, ri, mode, dL, frag_limit=5e-3):
     b = ref["out_color"].reshape(10, -1)[:, ok][:, good]
     close = hp.image_close(a, b)
     assert close.all(), "%d px-channels off, max err %g" % ((~close).sum(), np.abs(a - b).max())
-    # ---- gradients (pixels whose n_contrib differs would need dL = 0 on both sides: require there are none then)
-    got = run.backward(dL)
+    # ---- gradients.  Where the reference binary's own exp / contraction moved one of ITS decisions on a pixel the oracle
+    # does not flag (bounded above: <= 1e-5 of the pixels), the two sides walk different lists on that pixel: take those
+    # pixels out of dL/dpixel as well and run BOTH sides again -- the comparison never disappears
     if differ.any():
-        pytest.skip("n_contrib of the reference binary differs on %d unflagged pixels: gradients not comparable" % differ.sum())
+        idx = np.flatnonzero(ok)[differ]
+        dL.view(10, -1)[:, torch.from_numpy(idx)] = 0.0
+        ref = run_reference(ref_lib, ri, mode, dL, dev)
+    got = run.backward(dL)
     hp.assert_grads_close(got, {k: ref[k] for k in got})
     return run.R
 
 
-@pytest.mark.parametrize("cfg,mode", [("cfg2", "A"), ("cfg2", "B_sr"), ("cfg3", "A")])
+def _tile_rects(xy, rad, W, H):
+    """auxiliary.h:46-56 from the reference's own means2D / radii (same operation order)"""
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+
+    def tile(v, g):
+        return np.clip(np.trunc(v / np.float32(16)).astype(np.int64), 0, g)
+    r = rad.astype(np.float32)
+    out = np.stack([tile(xy[:, 0] - r, gx), tile(xy[:, 1] - r, gy), tile(xy[:, 0] + r + np.float32(16) - np.float32(1), gx),
+                    tile(xy[:, 1] + r + np.float32(16) - np.float32(1), gy)], axis=1)
+    out[rad == 0] = 0
+    return out
+
+
+def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
+    """The product against the DEFAULT build of the reference through a rotated camera.  A contracting compiler fuses some
+    of the a*b+c of auxiliary.h:58-77 and not others (oracle/Makefile.ref), so that build's view depths / pixel means differ
+    from any other build's -- and from the product's, which fuses nothing -- in the last bit.  What that may change, and
+    nothing else, is allowed, COUNTED and bounded: depth keys by one ulp; two instances of a tile whose depths are within
+    2 ulp listed in the other order; a tile rect of a Gaussian whose 3-sigma box ends within an ulp of a tile boundary.
+    The pixels of the tiles so affected leave the float comparisons on both sides (dL/dpixel = 0 there); everything else
+    must agree as in _compare."""
+    from tests.golden.make_reference_cuda_golden import run_reference
+    from tests.gpu_helpers import GpuRun, to_dev
+    dev = torch.device("cuda:0")
+    W, H = ri["W"], ri["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    _, _, st_o = hp.oracle_forward(oracle_mod, ri, mode)
+    frag = st_o.fragile.astype(bool).reshape(H, W)
+    assert frag.mean() < 5e-3
+    dL = dL.clone()
+    ref = run_reference(ref_lib, ri, mode, dL, dev)
+    run = GpuRun(to_dev(ri, dev), mode, debug=False)
+    ins = run.inspect()
+    P = run.P
+    # ---- K1: radii, rects, depth keys
+    radii_p, radii_r = run.radii.cpu().numpy(), ref["radii"]
+    rg = ins["rects"]
+    rect_p = np.stack([rg[:, 0] & 0xffff, rg[:, 1] & 0xffff, rg[:, 0] >> 16, rg[:, 1] >> 16], axis=1).astype(np.int64)
+    rect_p[radii_p == 0] = 0
+    rect_r = _tile_rects(ref["st_means2D"].astype(np.float32), radii_r.astype(np.int64), W, H)
+    area_r = (rect_r[:, 2] - rect_r[:, 0]) * (rect_r[:, 3] - rect_r[:, 1])
+    np.testing.assert_array_equal(area_r, ref["st_tiles_touched"].view(np.uint32).astype(np.int64))
+    flipped = (radii_p != radii_r) | (rect_p != rect_r).any(axis=1)
+    n_flip = int(flipped.sum())
+    assert n_flip <= max(2, int(2e-5 * P)), "K1 decisions differ for %d of %d Gaussians" % (n_flip, P)
+    vis = (radii_r > 0) & ~flipped
+    dp, dr = ins["depths"][vis].view(np.int32).astype(np.int64), ref["st_depths"][vis].view(np.int32).astype(np.int64)
+    assert np.abs(dp - dr).max() <= 1, "depth keys more than one ulp apart"
+    ulp_frac = float((dp != dr).mean())
+    xy_err = np.abs(ins["rec"][vis, 0:2].astype(np.float64) - ref["st_means2D"][vis].astype(np.float64)).max()
+    assert xy_err < 4e-4, xy_err  # pixels (1 ulp at 1920 is 1.2e-4)
+    # ---- tile lists: the same instances in every tile; order differences only between depths within 2 ulp
+    def lists(point_list, tile_start_or_ranges, is_ranges):
+        if is_ranges:
+            r = tile_start_or_ranges.view(np.uint32).astype(np.int64)
+            cnt = r[:, 1] - r[:, 0]
+        else:
+            cnt = np.diff(tile_start_or_ranges.astype(np.int64))
+        return point_list.astype(np.int64), np.repeat(np.arange(gx * gy), cnt)
+    pl_p, tl_p = lists(ins["point_list"], ins["tile_start"], False)
+    pl_r, tl_r = lists(ref["st_point_list"].view(np.uint32), ref["st_ranges"], True)
+    kp, kr = ~flipped[pl_p], ~flipped[pl_r]
+    pl_p, tl_p, pl_r, tl_r = pl_p[kp], tl_p[kp], pl_r[kr], tl_r[kr]
+    assert pl_p.size == pl_r.size and np.array_equal(tl_p, tl_r), "tile populations differ beyond the flipped Gaussians"
+    op, orr = np.lexsort((pl_p, tl_p)), np.lexsort((pl_r, tl_r))
+    np.testing.assert_array_equal(pl_p[op], pl_r[orr])                       # same members per tile
+    swapped = pl_p != pl_r
+    dbits = ref["st_depths"].view(np.int32).astype(np.int64)
+    assert (np.abs(dbits[pl_p[swapped]] - dbits[pl_r[swapped]]) <= 2).all(), "order differs between depths > 2 ulp apart"
+    bad_tiles = np.zeros(gx * gy, bool)
+    bad_tiles[tl_p[swapped]] = True
+    for g_ in np.nonzero(flipped)[0]:
+        for rc in (rect_p[g_], rect_r[g_]):
+            for ty in range(rc[1], rc[3]):
+                bad_tiles[ty * gx + rc[0]: ty * gx + rc[2]] = True
+    assert bad_tiles.mean() < 0.05, "%d of %d tiles see a near-tie in the other order" % (bad_tiles.sum(), bad_tiles.size)
+    mask = frag | np.kron(bad_tiles.reshape(gy, gx), np.ones((16, 16), bool))[:H, :W]
+    ok = ~mask.reshape(-1)
+    # ---- K7.  The pixel means of the two builds differ by up to 2 ulp (2.4e-4 px), alpha of a splat therefore by up to
+    # ~1e-3 relative -- beyond the 2e-5 margin of the oracle's `fragile` flag (which covers exp rounding only): on a few pixels
+    # one splat passes alpha >= 1/255 in one build and not in the other, or the stop test falls one entry later.  Those
+    # pixels are COUNTED (<= 2 % of the frame: measured 1.3 % for cfg3's one-pixel-wide strands, whose conics are the
+    # steepest, 0.01 % for cfg2's blobs), their error BOUNDED by two such splats (alpha <= 1.02/255 each, times the
+    # largest feature / background value), and they leave the gradient comparison on both sides.
+    nc, nc_ref = ins["n_contrib"][ok], ref["st_n_contrib"].view(np.uint32)[ok]
+    a, b = run.out.cpu().numpy().reshape(10, -1)[:, ok], ref["out_color"].reshape(10, -1)[:, ok]
+    off = (nc != nc_ref) | ~hp.image_close(ins["final_T"][ok], ref["st_final_T"][ok]) | ~hp.image_close(a, b).all(axis=0)
+    assert off.mean() <= 2e-2, "%d of %d unmasked pixels decide a splat differently" % (off.sum(), off.size)
+    vmax = max(float(ri["colors"].abs().max()), float(ri["bg"].abs().max()))
+    same_walk = off & (nc == nc_ref)
+    if same_walk.any():
+        assert np.abs(a - b)[:, same_walk].max() <= 2 * 1.02 / 255 * vmax
+    ok[np.flatnonzero(ok)[off]] = False
+    n_off = int(off.sum())
+    # ---- K8 .. K10 with dL/dpixel = 0 on everything named above, both sides
+    dL.view(10, -1)[:, torch.from_numpy(~ok)] = 0.0
+    ref = run_reference(ref_lib, ri, mode, dL, dev)
+    got = run.backward(dL)
+    # Gradients: the two sides' INPUTS to K8 differ in the last bits (pixel means), and T <- T / (1 - alpha) amplifies a
+    # relative difference in alpha by alpha / (1 - alpha) (x 99 at the clamp): a handful of rows sit a few 1e-4 of the row
+    # apart although both are right (the strict build, same inputs, agrees to the bar on EVERY element); dL/dmean2D of a
+    # one-pixel-wide strand moves by ~dx / sigma^2 = 8e-4 relative for a 2-ulp dx.  Counted and bounded: at most 1 % of a
+    # tensor's elements beyond the bar of tests/helpers.py (measured: 5 of 2.9e5 for cfg2's blobs, 0.35 % of dL/dmean2D for
+    # cfg3's strands), none beyond 100 x the bar.
+    keep = ~flipped
+    worst = {}
+    for k in got:
+        a, b = got[k][keep], ref[k][keep]
+        assert np.isfinite(a).all(), k
+        ok_el = hp.grad_close(a, b)
+        n_bad = int((~ok_el).sum())
+        worst[k] = n_bad
+        assert n_bad <= max(2, int(1e-2 * ok_el.size)), (k, n_bad, ok_el.size)
+        assert hp.grad_close(a, b, tol=100 * hp.TOL, floor=100 * hp.GRAD_FLOOR).all(), k
+    print("live, default build: gradient elements beyond the bar:", worst, flush=True)
+    print("live, default build: %d K1 flips, %.1f %% of the depth keys one ulp apart, %d swapped list positions in %d tiles, "
+          "%d pixels with a splat decided differently, %.2f %% of the pixels masked" %
+          (n_flip, 100 * ulp_frac, int(swapped.sum()), int(bad_tiles.sum()), n_off, 100 * (1 - ok.mean())), flush=True)
+    return run.R
+
+
+# cameras: scene/cameras.py:parity_camera ("front": R = I; "ring5": view 5 of BASELINE configs[3]'s ring; "ring13roll": view 13
+# rolled 20 deg).  cfg5 = BASELINE configs[4]'s 2M-Gaussian model.  Front camera: the default build of the reference, bit
+# for bit (with R = I and the zeros of the projection matrix, fused and unfused arithmetic give the same K1 bits).  Rotated
+# cameras: bit for bit against the STRICT build ...
+LIVE_FRONT = [("cfg2", "A"), ("cfg2", "B_sr"), ("cfg3", "A")]
+LIVE_ROTATED = [("cfg2", "A", "ring5"), ("cfg2", "B_sr", "ring13roll"), ("cfg2", "B_cov", "ring13roll"), ("cfg2", "B_cov", "ring5"),
+                ("cfg3", "A", "ring13roll"), ("cfg3", "A_sr", "ring5"), ("cfg5", "A", "ring5")]
+# ... and against the default build up to the last-bit effects _compare_up_to_last_bits names
+LIVE_ROTATED_DEFAULT = [("cfg2", "B_sr", "ring13roll"), ("cfg2", "A", "ring5"), ("cfg3", "A", "ring13roll")]
+
+
+@pytest.mark.parametrize("cfg,mode", LIVE_FRONT)
 def test_product_matches_the_live_reference_at_baseline_size(ref_lib, oracle_mod, cfg, mode):
     spec = syn.CONFIGS[cfg]
     ri = syn.raster_inputs(spec)
     dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
     R = _compare(ref_lib, oracle_mod, ri, mode, dL)
+    assert R > 500_000
+
+
+@pytest.mark.parametrize("cfg,mode,cam", LIVE_ROTATED)
+def test_product_matches_the_live_reference_through_rotated_cameras(ref_lib_strict, oracle_mod, cfg, mode, cam):
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec, cam=cam)
+    v = ri["viewmatrix"][:3, :3]
+    assert (v - torch.eye(3)).abs().max() > 0.3 and (v - v.T).abs().max() > 0.1
+    dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
+    R = _compare(ref_lib_strict, oracle_mod, ri, mode, dL)
+    assert R > 500_000
+
+
+@pytest.mark.parametrize("cfg,mode,cam", LIVE_ROTATED_DEFAULT)
+def test_product_matches_the_default_build_of_the_reference_through_rotated_cameras(ref_lib, oracle_mod, cfg, mode, cam):
+    spec = syn.CONFIGS[cfg]
+    ri = syn.raster_inputs(spec, cam=cam)
+    dL = syn.grad_image(spec, 101) * (spec.H * spec.W)
+    R = _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL)
     assert R > 500_000
 
 

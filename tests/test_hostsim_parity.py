@@ -15,11 +15,19 @@ def _ranges_from_tile_start(ts):
     return ranges
 
 
-@pytest.mark.parametrize("cfg,mode", [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"),
-                                      ("tiny", "B_cov"), ("tiny_strands", "A_sr"), ("cfg1", "A")])
-def test_forward_matches_oracle(oracle_mod, hostsim, cfg, mode):
+# rotated / rolled cameras (scene/cameras.py: parity_camera): with the front camera's R = I a transposed view rotation in
+# computeCov2D or its backward would be invisible
+ROTATED = [("tiny", "A", "ring5"), ("tiny", "B_sr", "ring13roll"), ("tiny", "B_cov", "ring5"),
+           ("tiny", "B_cov", "ring13roll"), ("tiny_strands", "A_sr", "ring13roll"), ("ragged", "B_sr", "ring5")]
+FRONT = [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"), ("tiny_strands", "A_sr")]
+FWD_CASES = [c + ("front",) for c in FRONT + [("cfg1", "A")]] + ROTATED
+BWD_CASES = [c + ("front",) for c in FRONT] + ROTATED
+
+
+@pytest.mark.parametrize("cfg,mode,cam", FWD_CASES)
+def test_forward_matches_oracle(oracle_mod, hostsim, cfg, mode, cam):
     spec = syn.CONFIGS[cfg]
-    ri = syn.raster_inputs(spec)
+    ri = syn.raster_inputs(spec, cam=cam)
     out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
     st = hostsim.forward(ri, mode)
     try:
@@ -46,11 +54,10 @@ def test_forward_matches_oracle(oracle_mod, hostsim, cfg, mode):
         hostsim.free(st)
 
 
-@pytest.mark.parametrize("cfg,mode", [("tiny", "A"), ("ragged", "A"), ("tiny_strands", "A"), ("tiny", "B_sr"),
-                                      ("tiny", "B_cov"), ("tiny_strands", "A_sr")])
-def test_backward_matches_oracle(oracle_mod, hostsim, cfg, mode):
+@pytest.mark.parametrize("cfg,mode,cam", BWD_CASES)
+def test_backward_matches_oracle(oracle_mod, hostsim, cfg, mode, cam):
     spec = syn.CONFIGS[cfg]
-    ri = syn.raster_inputs(spec)
+    ri = syn.raster_inputs(spec, cam=cam)
     out_o, radii_o, st_o = hp.oracle_forward(oracle_mod, ri, mode)
     dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)  # O(1) per-pixel gradients
     dL[:, st_o.fragile.astype(bool)] = 0.0

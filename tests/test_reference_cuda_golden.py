@@ -1,8 +1,8 @@
 """The oracle (oracle/ghr_oracle.c) and the HIP product against OUTPUTS OF THE REFERENCE'S OWN RASTERIZER: the CUDA
 sources of /root/reference/ext/diff_gaussian_rasterization_hair/cuda_rasterizer, hipified and compiled for gfx950 by
 oracle/Makefile.ref and run on an MI355X by tests/golden/make_reference_cuda_golden.py ->
-tests/golden/reference_cuda_golden.npz (inputs, forward outputs, internal state, gradients; six cases over modes A /
-A_sr / B_sr / B_cov).  This is what pins the oracle.
+tests/golden/reference_cuda_golden.npz (inputs, forward outputs, internal state, gradients; twelve cases over modes A /
+A_sr / B_sr / B_cov, six of them through rotated / rolled ring cameras).  This is what pins the oracle.
 
 Comparison: integers / indices bit for bit; floats to 1e-6 relative (the reference binary is built with the compiler's
 default fp contraction like nvcc's, the oracle without, so single roundings may differ); gradients are sums of ~1e4
@@ -18,7 +18,7 @@ import pytest
 from tests import helpers as hp
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_cuda_golden.npz")
-CASES = [("tiny", "A"), ("tiny", "B_sr"), ("tiny", "B_cov"), ("ragged", "A"), ("tiny_strands", "A_sr"), ("cfg1", "A")]
+from tests.golden.make_reference_cuda_golden import CASES, case_tag  # noqa: E402  (workload, mode, camera) incl. rotated / rolled views
 
 
 @pytest.fixture(scope="module")
@@ -26,10 +26,10 @@ def gold():
     return np.load(GOLD)
 
 
-def case_inputs(gold, cfg, mode):
+def case_inputs(gold, cfg, mode, cam="front"):
     """The golden's stored inputs as the dict synthetic.raster_inputs() returns (numpy -> torch)."""
     import torch
-    t = "%s/%s/" % (cfg, mode)
+    t = case_tag(cfg, mode, cam)
     ri = {k: torch.from_numpy(gold[t + "in_" + k]) for k in ("means3D", "colors", "opacities", "cov3D", "conic", "scales",
                                                              "rotations", "bg", "viewmatrix", "projmatrix", "campos")}
     W, H, tx, ty = gold[t + "in_scalars"]
@@ -84,9 +84,12 @@ def check_grads(gold, t, got, rel=1e-5, of_max=2e-5):
         assert not bad.any(), (k, int(bad.sum()), float(np.abs(a - b).max()), float(np.abs(b).max()))
 
 
-@pytest.mark.parametrize("cfg,mode", CASES)
-def test_oracle_matches_the_reference_cuda_rasterizer(oracle_mod, gold, cfg, mode):
-    ri, t = case_inputs(gold, cfg, mode)
+@pytest.mark.parametrize("cfg,mode,cam", CASES)
+def test_oracle_matches_the_reference_cuda_rasterizer(oracle_mod, gold, cfg, mode, cam):
+    ri, t = case_inputs(gold, cfg, mode, cam)
+    if cam != "front":
+        v = ri["viewmatrix"].numpy()[:3, :3]
+        assert np.abs(v - np.eye(3)).max() > 0.3 and np.abs(v - v.T).max() > 0.1, "not a rotated view"
     out, radii, st = hp.oracle_forward(oracle_mod, ri, mode)
     dL, frag = case_dL(gold, t, cfg, ri)
     # the stored fragile mask is the oracle's own (same code, same inputs)
@@ -101,12 +104,12 @@ def test_oracle_matches_the_reference_cuda_rasterizer(oracle_mod, gold, cfg, mod
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,mode", CASES)
-def test_hip_rasterizer_matches_the_reference_cuda_rasterizer(gold, cfg, mode):
+@pytest.mark.parametrize("cfg,mode,cam", CASES)
+def test_hip_rasterizer_matches_the_reference_cuda_rasterizer(gold, cfg, mode, cam):
     """The product, through the C ABI, against the same reference outputs (no oracle in between)."""
     import torch
     from tests.gpu_helpers import GpuRun, to_dev
-    ri, t = case_inputs(gold, cfg, mode)
+    ri, t = case_inputs(gold, cfg, mode, cam)
     dL, frag = case_dL(gold, t, cfg, ri)
     run = GpuRun(to_dev(ri, torch.device("cuda:0")), mode)
     ins = run.inspect()

@@ -30,8 +30,9 @@ def gold():
     return np.load(GOLD)
 
 
-def _sub(gold, prefix):
-    return {k[len(prefix):]: gold[k] for k in gold.files if k.startswith(prefix)}
+def _sub(gold, prefix, arbiter=False):
+    """arbiter: keep the "grad64_*" entries (the same chain in IEEE double; make_reference_render_golden.run_render)"""
+    return {k[len(prefix):]: gold[k] for k in gold.files if k.startswith(prefix) and (arbiter or "grad64" not in k)}
 
 
 def _assert_same_dict(got, ref, tol):
@@ -50,15 +51,17 @@ def _assert_same_dict(got, ref, tol):
 def test_reference_render_functions_run_unmodified_on_the_dropin_package(oracle_mod):
     ref = refload.load_reference_renderer()
     assert ref.GaussianRasterizer.__module__.startswith("gaussianhaircut_amd.diff_gaussian_rasterization")
-    for cfg in ("tiny", "tiny_strands"):
-        _assert_same_dict(mk.run_render(ref.render, cfg), mk.run_render(render, cfg), 1e-6)
-    _assert_same_dict(mk.run_render_hair(ref.render_hair), mk.run_render_hair(render_hair), 1e-6)
+    for cfg, cam in mk.RENDER_CASES:
+        _assert_same_dict(mk.run_render(ref.render, cfg, cam), mk.run_render(render, cfg, cam), 1e-6)
+    for cam in mk.HAIR_CAMS:
+        _assert_same_dict(mk.run_render_hair(ref.render_hair, cam), mk.run_render_hair(render_hair, cam), 1e-6)
 
 
 def test_render_equals_the_reference_render_golden_on_cpu(oracle_mod, gold):
-    for cfg in ("tiny", "tiny_strands"):
-        _assert_same_dict(mk.run_render(render, cfg), _sub(gold, "render/%s/" % cfg), 1e-5)
-    _assert_same_dict(mk.run_render_hair(render_hair), _sub(gold, "render_hair/"), 1e-5)
+    for cfg, cam in mk.RENDER_CASES:
+        _assert_same_dict(mk.run_render(render, cfg, cam, arbiter=True), _sub(gold, mk.render_tag(cfg, cam), arbiter=True), 1e-5)
+    for cam in mk.HAIR_CAMS:
+        _assert_same_dict(mk.run_render_hair(render_hair, cam), _sub(gold, mk.hair_tag(cam)), 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -104,17 +107,27 @@ def _check_gpu(pkg, grads, ref, W, H):
             continue  # strand-parameter rows cannot be attributed to single Gaussians; only compared when nothing flipped
         rmax = np.abs(b).max(axis=1, keepdims=True)
         bad = np.abs(a - b) > hp.TOL * (np.abs(b) + rmax) + 2e-6 * np.abs(b).max()
-        assert not bad[rows].any(), (k, int(bad[rows].sum()), np.abs(a - b)[rows].max(), np.abs(b).max())
+        if bad[rows].any() and ("grad64" + k) in ref:
+            # arbitrated by the same chain in IEEE double (make_reference_render_golden.run_render): no further from it than
+            # 3 x the reference's own fp32 chain is, plus the bar
+            r = ref["grad64" + k].reshape(len(b), -1).astype(np.float64)
+            rm = np.abs(r).max(axis=1, keepdims=True)
+            bad = np.abs(a - r) > 3.0 * np.abs(b - r) + hp.TOL * (np.abs(r) + rm) + 2e-6 * np.abs(r).max()
+        if bad[rows].any():
+            r_ = np.nonzero(bad.any(axis=1) & rows)[0][:6]
+            raise AssertionError((k, int(bad[rows].sum()), float(np.abs(a - b)[rows].max()), float(np.abs(b).max()),
+                                  [(int(i), a[i].tolist(), b[i].tolist(), int(radii_c[i]) if len(b) == len(radii_c) else -1)
+                                   for i in r_]))
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("cfg", ["tiny", "tiny_strands"])
-def test_gpu_render_replays_the_reference_render_golden(gold, cfg, fused):
+@pytest.mark.parametrize("cfg,camname", mk.RENDER_CASES)
+def test_gpu_render_replays_the_reference_render_golden(gold, cfg, camname, fused):
     dev = torch.device("cuda:0")
-    ref = _sub(gold, "render/%s/" % cfg)
+    ref = _sub(gold, mk.render_tag(cfg, camname), arbiter=True)
     spec = syn.CONFIGS[cfg]
-    model, cam = syn.make_model(spec, dev), syn.make_view(spec, dev)
+    model, cam = syn.make_model(spec, dev), syn.make_view(spec, dev, camname)
     pipe = SimpleNamespace(debug=False, fused_projection=fused)
     pkg = render(cam, model, pipe, syn.background(dev))
     assert set(pkg.keys()) == set(KEYS)
@@ -129,11 +142,12 @@ def test_gpu_render_replays_the_reference_render_golden(gold, cfg, fused):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fused", [False, True])
-def test_gpu_render_hair_replays_the_reference_render_hair_golden(gold, fused):
+@pytest.mark.parametrize("camname", mk.HAIR_CAMS)
+def test_gpu_render_hair_replays_the_reference_render_hair_golden(gold, camname, fused):
     from tests.test_api_cpu import _hair_scene
     dev = torch.device("cuda:0")
-    ref = _sub(gold, "render_hair/")
-    spec, head, hair, cam = _hair_scene(dev)
+    ref = _sub(gold, mk.hair_tag(camname))
+    spec, head, hair, cam = _hair_scene(dev, camname)
     hair.initialize_gaussians_hair()
     pipe = SimpleNamespace(debug=False, fused_projection=fused)
     pkg = render_hair(cam, head, hair, pipe, syn.background(dev))

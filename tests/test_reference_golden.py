@@ -24,13 +24,27 @@ def close(a, b, rtol=2e-5, atol=1e-6):
     assert (err <= 0).all(), "max violation %g at %s" % (err.max(), np.unravel_index(err.argmax(), err.shape))
 
 
-@pytest.mark.parametrize("cfg", ["tiny", "tiny_strands"])
-def test_projection_helpers_match_reference(cfg):
+# cameras: scene/cameras.py:parity_camera -- the rotated / rolled ring views have all nine entries of W non-trivial (with the
+# front camera's W = I a transposed view rotation in T = W J, the 2D direction or the SH view direction would be invisible)
+@pytest.mark.parametrize("cfg,camname", [("tiny", "front"), ("tiny_strands", "front"), ("tiny", "ring13roll"),
+                                         ("tiny_strands", "ring5")])
+def test_projection_helpers_match_reference(cfg, camname):
     spec = syn.CONFIGS[cfg]
     m = syn.make_model(spec)
-    cam = syn.make_view(spec)
+    cam = syn.make_view(spec, cam=camname)
+    cfg = cfg if camname == "front" else cfg + "@" + camname
     close(cam.world_view_transform.numpy(), G[cfg + "/view"])
     close(cam.full_proj_transform.numpy(), G[cfg + "/proj"])
+    # ... and the camera itself against the reference's own construction (src/scene/cameras.py:72-80) from (R, T, FoV)
+    from gaussianhaircut_amd.scene.cameras import Camera
+    fx, fy = G[cfg + "/cam_fov"]
+    c2 = Camera(G[cfg + "/cam_R"], G[cfg + "/cam_T"], fx, fy, spec.W, spec.H)
+    close(c2.world_view_transform.numpy(), G[cfg + "/ref_view"], rtol=1e-6, atol=1e-7)
+    close(c2.full_proj_transform.numpy(), G[cfg + "/ref_proj"], rtol=2e-6, atol=1e-6)
+    close(c2.camera_center.numpy(), G[cfg + "/ref_center"], rtol=1e-5, atol=2e-6)
+    if camname != "front":
+        Rv = G[cfg + "/ref_view"][:3, :3]
+        assert np.abs(Rv - np.eye(3)).max() > 0.3 and np.abs(Rv - Rv.T).max() > 0.1
     with torch.no_grad():
         conic = m.get_conic(cam)
         close(m.get_scaling.numpy(), G[cfg + "/scaling"])
@@ -81,12 +95,14 @@ def test_losses_match_reference():
     close(float(lu.or_loss(a1, a2)), G["loss/or_noconf"])
 
 
-def test_strand_model_matches_reference_strands_module():
+@pytest.mark.parametrize("camname", ["front", "ring13roll"])
+def test_strand_model_matches_reference_strands_module(camname):
     """GaussianModelStrands vs the reference's src/scene/gaussian_model_strands.py (initialize_gaussians_hair,
     get_conic with eps 1e-7, get_direction_2d = normalize(dir) @ T, filter_points, unit opacity / label)."""
     from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
     spec = syn.CONFIGS["tiny_strands"]
-    cam = syn.make_view(spec)
+    cam = syn.make_view(spec, cam=camname)
+    V = "strands/" if camname == "front" else "strands@" + camname + "/"
     m = GaussianModelStrands(3).create_from_strands(torch.from_numpy(G["strands/origins"]),
                                                     torch.from_numpy(G["strands/dirs"]),
                                                     torch.from_numpy(G["strands/features"]))
@@ -95,16 +111,16 @@ def test_strand_model_matches_reference_strands_module():
         close(m._rotation.numpy(), G["strands/rotation"], rtol=1e-5, atol=1e-6)
         close(m.get_scaling.numpy(), G["strands/scaling"])
         conic = m.get_conic(cam)
-        close(m.cov.numpy(), G["strands/cov3D"], rtol=5e-5, atol=1e-9)
-        ref2d = G["strands/cov2d"]
+        close(m.cov.numpy(), G[V + "cov3D"], rtol=5e-5, atol=1e-9)
+        ref2d = G[V + "cov2d"]
         assert np.abs(m.cov2d.numpy() - ref2d).max() <= 2e-4 * np.abs(ref2d).max() + 1e-4
-        refc = G["strands/conic"]
+        refc = G[V + "conic"]
         rel = np.abs(conic.numpy() - refc) / (np.abs(refc).max(axis=1, keepdims=True) + 1e-6)
         assert rel.max() < 1e-5, rel.max()   # every row (same torch ops as the reference's Python: 0 on the golden's machine)
-        close(m.get_mean_2d(cam).numpy(), G["strands/mean2d"], rtol=2e-5, atol=2e-6)
-        close(m.get_depths(cam).numpy(), G["strands/depths"])
-        close(m.get_direction_2d(cam).numpy(), G["strands/dir2d"], rtol=1e-4, atol=1e-4)
-        assert (m.filter_points(cam).numpy() == G["strands/mask"]).all()
+        close(m.get_mean_2d(cam).numpy(), G[V + "mean2d"], rtol=2e-5, atol=2e-6)
+        close(m.get_depths(cam).numpy(), G[V + "depths"])
+        close(m.get_direction_2d(cam).numpy(), G[V + "dir2d"], rtol=1e-4, atol=1e-4)
+        assert (m.filter_points(cam).numpy() == G[V + "mask"]).all()
         close(m.get_opacity.numpy(), G["strands/opacity"])
         close(m.get_label.numpy(), G["strands/label"])
         close(m.get_orient_conf.numpy(), G["strands/orient_conf"])

@@ -1,11 +1,23 @@
 #!/bin/bash
-# Kernel-experiment build: tools/build_variant.sh <name> [-DFLAG ...] -> build/variants/libghr_<name>.so
-# (select with GHR_LIB_PATH; *.so is git-ignored but travels to the GPU box)
+# Kernel-experiment build:  tools/build_variant.sh <name> [-p <patch> ...] [-DFLAG ...] -> build/variants/libghr_<name>.so
+# (select with GHR_LIB_PATH; *.so is git-ignored but travels to the GPU box).
+# Rejected kernel forms and their ablation knobs do not live in the product headers: they are patches under
+# tools/experiments/ (e.g. r03_experiment_knobs_of_the_render_loss_adam_kernels.patch brings back -DGHR_B3_NOARITH,
+# -DGHR_B3_NOATOM, -DGHR_K7_HALVES, ...).  -p applies a patch to a scratch copy of csrc/ + include/ before compiling.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
-mkdir -p $R/build/variants
+S=$R/build/variants/src_$name
+rm -rf $S; mkdir -p $S/gaussianhaircut_amd $R/build/variants
+cp -r $R/gaussianhaircut_amd/csrc $S/gaussianhaircut_amd/csrc
+cp -r $R/include $S/include
+rm -f $S/gaussianhaircut_amd/csrc/*.so
+flags=()
+while [ $# -gt 0 ]; do
+  if [ "$1" = "-p" ]; then (cd $S && patch -s -p1 < "$(cd $R && realpath "$2")"); shift 2; else flags+=("$1"); shift; fi
+done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared \
-  -I$R/include -I$R/gaussianhaircut_amd/csrc "$@" $R/gaussianhaircut_amd/csrc/ghr_capi.hip \
-  -o $R/build/variants/libghr_$name.so
+  -I$S/include -I$S/gaussianhaircut_amd/csrc "${flags[@]}" $S/gaussianhaircut_amd/csrc/ghr_capi.hip \
+  -o $R/build/variants/libghr_$name.so 2>&1 | grep -E "error|spill" || true
+rm -rf $S
 echo built $R/build/variants/libghr_$name.so

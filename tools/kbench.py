@@ -75,6 +75,10 @@ def main():
               " waves=%d cycles_per_wave mean %.0f p50 %.0f p99 %.0f max %.0f  count7=%d p4_cycles_per_count=%.0f" %
               (used.sum(), v[used, 6].mean(), np.percentile(v[used, 6], 50), np.percentile(v[used, 6], 99),
                v[used, 6].max(), int(tot[7]), tot[4] / max(tot[7], 1)))
+        if hasattr(L, "ghr_debug_timeline") and os.environ.get("GHR_TIMELINE"):
+            tl = np.zeros((n_slots, 2), np.uint64)
+            L.ghr_debug_timeline(ctypes.c_void_p(tl.ctypes.data), n_slots)
+            np.savez_compressed(os.environ["GHR_TIMELINE"], prof=buf, tl=tl)
         wg = v[: (v.shape[0] // 4) * 4, 6].reshape(-1, 4)
         wg = wg[wg.max(axis=1) > 0]
         print("PROF workgroups: %d working; slot-cycles of a workgroup = 4 x its slowest wave: %.3g against %.3g summed over "
