@@ -289,9 +289,32 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
 
+        # (the timing lambdas run ~40 optimizer passes over zero gradients -- moments decay, the step counter advances: the
+        # optimizer is put back afterwards so that what follows sees the state the timed steps left)
+        o.sync_moments()
+        snap = [t.detach().clone() for t in (o.flat_param, o.exp_avg, o.exp_avg_sq, o.state_dev)]
         ar_ms = timed(lambda: o.all_reduce())                                      # the gradient message alone
         adam_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=False))  # the local update alone
-        both_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=True))   # as in the step: chunks overlapped
+        both_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=True, shard=False))  # replicated update
+        zero_ms = timed(lambda: o.step_chunked(chunks=4, zero_grad=True, reduce=True, shard=True))   # ZeRO-1, as in the step
+        from gaussianhaircut_amd.optim import FusedAdam as _FA
+        Gw, rk = (dist.get_world_size(), dist.get_rank()) if dist.is_initialized() else (1, 0)
+        shards = [(a, b) for a, b, how in _FA._shard_plan(o._reduce_plan(4), Gw) if how == "shard"]
+
+        def rs():
+            for a, b in shards:
+                L = (b - a) // Gw
+                dist.reduce_scatter_tensor(o.flat_grad[a + rk * L: a + (rk + 1) * L], o.flat_grad[a:b])
+
+        def ag():
+            for a, b in shards:
+                L = (b - a) // Gw
+                dist.all_gather_into_tensor(o.flat_param[a:b], o.flat_param[a + rk * L: a + (rk + 1) * L])
+        rs_ms, ag_ms = (timed(rs), timed(ag)) if dist.is_initialized() else (None, None)
+        o.sync_moments()
+        for dst, src in zip((o.flat_param, o.exp_avg, o.exp_avg_sq, o.state_dev), snap):
+            dst.copy_(src)
+        o.zero()
         G = max(world, 1)
         shard = out.get("config4_shard")
         out["scaling_breakdown"] = {
@@ -303,6 +326,10 @@ def main():
             "config4_shard_ms_per_step": shard["ms_per_step"] if shard else None,
             "headline_ms_per_step": round(ms_per_step, 4),
             "all_reduce_ms": round(ar_ms, 4), "adam_ms": round(adam_ms, 4), "all_reduce_plus_adam_chunked_ms": round(both_ms, 4),
+            "reduce_scatter_ms": round(rs_ms, 4) if rs_ms is not None else None,
+            "all_gather_ms": round(ag_ms, 4) if ag_ms is not None else None,
+            "reduce_scatter_adam_slice_all_gather_chunked_ms": round(zero_ms, 4),
+            "optimizer": "ZeRO-1 (FusedAdam.step_chunked(shard=True)): each rank updates 1 / N of every reduced range",
             "message_bytes": int(4 * msg), "bytes_on_wire_per_gpu_ring": int(2 * (G - 1) / G * 4 * msg),
             "bus_bandwidth_GBps": round(2 * (G - 1) / G * 4 * msg / (ar_ms * 1e-3) / 1e9, 2) if ar_ms > 0 and G > 1 else None,
             "backend": dist.get_backend() if dist.is_initialized() else None, "replicas_identical": replicas_identical,
@@ -338,23 +365,30 @@ def op_only_bench(dev, cfg="cfg2", iters=50, warm=10):  # 10 warm-u
     # One event triple per iteration, read back after the loop: the host is not stalled between iterations (a training
     # loop is not either), so the Python work of call i+1 -- argument structs, workspace tensors -- is done while the GPU
     # is still busy with the backward of call i.  The forward's own blocking read of num_rendered stays where it is.
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(iters + warm)]
-    for i in range(iters + warm):
-        for t in leaves.values():
-            t.grad = None
-        e = ev[i]
-        e[0].record()
-        color, radii = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], shs=None,
-                            colors_precomp=leaves["colors"], opacities=leaves["opacities"], cov3D_precomp=ri["cov3D"],
-                            conic_precomp=leaves["conic"])
-        e[1].record()
-        torch.autograd.backward(color, grad_tensors=dL)
-        e[2].record()
-    torch.cuda.synchronize()
-    tf = [e[0].elapsed_time(e[1]) for e in ev[warm:]]
-    tb = [e[1].elapsed_time(e[2]) for e in ev[warm:]]
-    tf.sort(), tb.sort()
+    def run(n_it, sync_each):
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(n_it + warm)]
+        for i in range(n_it + warm):
+            for t in leaves.values():
+                t.grad = None
+            e = ev[i]
+            e[0].record()
+            color, radii = rast(means3D=leaves["means3D"], means2D=leaves["means2D"], shs=None,
+                                colors_precomp=leaves["colors"], opacities=leaves["opacities"], cov3D_precomp=ri["cov3D"],
+                                conic_precomp=leaves["conic"])
+            e[1].record()
+            torch.autograd.backward(color, grad_tensors=dL)
+            e[2].record()
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        f = sorted(e[0].elapsed_time(e[1]) for e in ev[warm:])
+        b = sorted(e[1].elapsed_time(e[2]) for e in ev[warm:])
+        return f, b
+    tf, tb = run(iters, False)
     mf, mb = tf[len(tf) // 2], tb[len(tb) // 2]
+    # ... and with the host waiting for the GPU after every iteration (how rounds 1-2 and a cold single call measure: the
+    # Python work of a call is then NOT hidden behind the previous backward)
+    sf, sb = run(max(iters // 2, 10), True)
     pct = lambda v, q: round(v[min(len(v) - 1, int(q * len(v)))], 4)
     R = dgr.LAST_STATS["num_rendered"]
     P, N, T = ri["P"], spec.W * spec.H, ((spec.W + 15) // 16) * ((spec.H + 15) // 16)
@@ -365,6 +399,7 @@ def op_only_bench(dev, cfg="cfg2", iters=50, warm=10):  # 10 warm-u
             "whole_backward_hbm_frac": round(b_bwd / (mb * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             "algorithmic_bytes": {"B_fwd = 92 P + 112 R + 48 N + 16 T": b_fwd, "B_bwd = 140 P + 132 R + 48 N + 8 T": b_bwd},
             "fwd_ms_p10_p90": [pct(tf, 0.1), pct(tf, 0.9)], "bwd_ms_p10_p90": [pct(tb, 0.1), pct(tb, 0.9)],
+            "fwd_ms_host_sync_every_iter": round(sf[len(sf) // 2], 4), "bwd_ms_host_sync_every_iter": round(sb[len(sb) // 2], 4),
             "iters": iters, "warmup": warm,
             "note": "GaussianRasterizer op (autograd, workspace allocation and the num_rendered read included); HIP events per "
                     "iteration, no host synchronisation between iterations"}

@@ -455,8 +455,8 @@ __global__ void __launch_bounds__(256) k_loss_bwd(LossBwdArgs a)
 //     row) and keeps the last ten for the next one, where a 32 x 16 tile filters 26 rows for 16 (1.6x the arithmetic, on 208
 //     of 256 threads) and loads a 2.1x window;
 //   * the vertical pass gives a lane four rows of one column from 14 LDS rows (3.5 reads per output and plane, not 6);
-//   * the input window is the ALIGNED superset of the strip's 26 columns: bx-8 .. bx+23, 8 float4 per row -- two 16-B loads
-//     per lane and plane and pass, from a 32-bit byte offset against a scalar base, never under a branch (clamped address,
+//   * the input window is the ALIGNED superset of the strip's 42 columns (32 + the 5-column halo on either side):
+//     bx-8 .. bx+39, GHR_LM_WQ = 12 float4 per row -- 16-B loads from a 32-bit byte offset against a scalar base, never under a branch (clamped address,
 //     then a select), and issued one pass ahead (the registers are carried around the loop); the tile kernels issue 15
 //     one-float loads per thread, each under its own branch with its own 64-bit address (their forward runs 348 float
 //     instructions among 365 other VALU and 306 scalar ones);
@@ -516,12 +516,13 @@ __device__ __forceinline__ float wave_sum(float v)
 // operations in order; this keeps the compiler from moving them across, and is no instruction
 __device__ __forceinline__ void wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
-// Float4 i of a batch of input rows starting at image row r0 (columns bx-8 .. bx+23): its row in the batch, its float4 in
+// Float4 i of a batch of input rows starting at image row r0 (columns bx-8 .. bx+39): its row in the batch, its float4 in
 // the row, and the byte offset of its pixels inside a plane (0 when outside the image or the batch)
 struct WinPos { int row, q; bool in; uint32_t off; };
 __device__ __forceinline__ WinPos win_pos(int i, int nvec, int bx, int r0, int W, int H)
 {
     WinPos w;
+    static_assert(GHR_LM_WQ == 12, "win_pos divides by GHR_LM_WQ with the multiply-shift below: 43691 / 2^19 = 1 / 12");
     w.row = (int)(((uint32_t)i * 43691u) >> 19);  // i / 12 for i < 2^13
     w.q = i - GHR_LM_WQ * w.row;
     const int gx = bx - 8 + 4 * w.q, gy = r0 + w.row;

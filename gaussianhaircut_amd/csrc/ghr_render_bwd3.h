@@ -84,6 +84,8 @@ __device__ __forceinline__ uint32_t lds_addr(T* p)
 // atomicAdd(lds word, 1) by lane 0 only, result broadcast.  Written in asm: in front of the C++ atomic the compiler puts
 // s_waitcnt vmcnt(0) (it cannot tell the LDS-DMA gathers in flight from the word), which drained the wave's outstanding
 // line atomics and gathers at every cell draw.
+// Only for WAVE-UNIFORM control flow with lane 0 active (the cell loop of b3_tile: whole waves): the atomic is issued by
+// lane 0 under a hand-set EXEC and its result is read back from lane 0.
 __device__ __forceinline__ uint32_t lds_draw(uint32_t addr)
 {
     // (the address arrives in a scalar register and the result register doubles as the address operand: nothing of the

@@ -673,6 +673,20 @@ def test_deferred_gradient_zeroing_is_invisible_or_loud():
             model.optimizer.step()
         model.optimizer.zero_grad()                         # the documented way out
         model.optimizer.step()
+        # (d') READERS: between two fused steps p.grad still holds the gradients of the step just taken (the
+        # reference's are None at that point) -- finite, usable for gradient-norm logging -- while the bucket accessor
+        # `optimizer.flat`, whose contract is "what the next accumulation starts from", zero-fills first
+        model = syn.make_model(spec, dev)
+        model.training_setup(opt)
+        training_step(model, cams[:2], bg, opt, 1)
+        o = model.optimizer
+        assert o._deferred is not None
+        g = model._xyz.grad
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+        assert float(o.flat.abs().sum()) == 0.0 and o._deferred is None and float(model._xyz.grad.abs().sum()) == 0.0
+        with pytest.raises(ValueError):
+            o.step(zero_grad="true")                        # a typo must not silently mean "defer"
+        training_step(model, cams[:2], bg, opt, 2)          # ... and the next step runs on as if nothing had happened
         # (e)
         model = syn.make_model(spec, dev)
         model.training_setup(opt)
