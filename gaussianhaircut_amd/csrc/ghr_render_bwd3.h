@@ -167,22 +167,23 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
         // e = 0..15 (ascending e = back to front); the ones past the front of the list repeat the chunk's last entry and
         // are masked.  Lane L gathers quarter L >> 4 of entry L & 15, so that a buffer holds the 16 first quarters, then the 16
         // second ones, ...: the chunk's reads below (16 entries side by side) are free of bank conflicts.
-        auto issue = [&](uint32_t t) {
+        // (`buf` = t % GHR_B3_NBUF, carried by the callers: a running counter instead of a division per use)
+        auto issue = [&](uint32_t t, uint32_t buf) {
             const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
             const uint32_t e = min((uint32_t)lane & 15u, cnt - 1u);
             const uint32_t pos = 64u * w_lo + list[hi - 1u - e];
             const uint32_t id = SMALL ? sh.id[pos] : ld32(point_list, 4u * (beg + pos));
             const uint32_t slot = min(beg + pos, cap - 1u);  // the gradient lines lie in list order
-            gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][t % GHR_B3_NBUF][0]);
-            if (lane < 16) sh.cslot[wave][t % GHR_B3_NBUF][lane] = slot;
+            gather16_to_lds(rec, 64u * id + 16u * ((uint32_t)lane >> 4), &sh.rec[wave][buf][0]);
+            if (lane < 16) sh.cslot[wave][buf][lane] = slot;
         };
         build();
         while (n_c == 0 && w_hi >= GHR_B3_SEG_WORDS) { w_hi -= GHR_B3_SEG_WORDS; build(); }
         GHR_PROF(2);
         if (n_c == 0) continue;  // nothing of the cell's list reaches its pixels (wave-uniform)
         if (SMALL) {
-            issue(0);
-            if (n_c > 16u) issue(1);
+            issue(0, 0);
+            if (n_c > 16u) issue(1, 1);
         }
 
         // ---- the cell's pixels: lane (k, m) evaluates the pixels (x = 4g + k, y = 4 band + q), q = 0..3.  Their loads go
@@ -248,7 +249,8 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
 
         for (;;) {  // segments
             const uint32_t nch = (n_c + 15u) >> 4;
-            for (uint32_t t = 0; t < nch; t++) {
+            uint32_t bt = 0;  // t % GHR_B3_NBUF
+            for (uint32_t t = 0; t < nch; t++, bt = bt == GHR_B3_NBUF - 1 ? 0u : bt + 1u) {
                 const uint32_t hi = n_c - 16u * t, cnt = min(hi, 16u);
                 if (SMALL) {
                     // memory operations issued after the gather of chunk t: [t >= 2: the four atomics of chunk t-2]
@@ -259,7 +261,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                     else if (t == 1) { if (more) GHR_VMCNT(5); else GHR_VMCNT(4); }
                     else { if (more) GHR_VMCNT(1); else GHR_VMCNT(0); }
                 } else {
-                    issue(t);
+                    issue(t, bt);
                     GHR_VMCNT(0);
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -270,7 +272,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 const uint32_t j = min((uint32_t)m, cnt - 1u);  // lanes past the end recompute the last entry, masked
                 const int f0 = 6 + k, f1 = 10 + k, f2 = 6 + kc2;            // colours k, 4 + k, 8 + k
                 // field f of entry j sits at float (f >> 2) * 64 + 4 j + (f & 3): quarter-major, see the gather
-                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][t % GHR_B3_NBUF][0]) + 4u * j;
+                const float* R = reinterpret_cast<const float*>(&sh.rec[wave][bt][0]) + 4u * j;
                 const f4 r0 = *reinterpret_cast<const f4*>(R);              // x y a b
                 const f2b r1 = *reinterpret_cast<const f2b*>(R + 64);       // c o
                 const float col0 = R[(f0 >> 2) * 64 + (f0 & 3)], col1 = R[(f1 >> 2) * 64 + (f1 & 3)],
@@ -341,7 +343,7 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 da = mfma16(wB.y, phiW[3], da);
                 const f4 d = da + db;
                 // the gather of chunk t+2 goes out before this chunk's atomics (see GHR_VMCNT above)
-                if (SMALL && t + 2 < nch) issue(t + 2);
+                if (SMALL && t + 2 < nch) issue(t + 2, bt == 0 ? GHR_B3_NBUF - 1 : bt - 1u);  // (t + 2) % 3 == (t - 1) % 3
                 // a DPP row adds one whole 64-B line per register: resolved in this XCD's L2 (only this workgroup ever
                 // touches the instance's line).  Always four atomic INSTRUCTIONS (the vmcnt arithmetic above): the rows
                 // without an entry are masked out of EXEC by hand -- under an `if` the compiler would branch around the
@@ -350,24 +352,34 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
                 // (lane (k, c) adds to the entries 4k + r: their lines from one 16-B read -- the gather fills all sixteen
                 // slots of a chunk, the ones past the end with the last entry's; which rows have an entry is wave-uniform
                 // arithmetic on cnt: the rows k < ceil((cnt - r) / 4))
-                const uint32_t* cs4 = &sh.cslot[wave][t % GHR_B3_NBUF][4 * k];
+                const uint32_t* cs4 = &sh.cslot[wave][bt][4 * k];
                 const uint32_t sl[4] = {cs4[0], cs4[1], cs4[2], cs4[3]};
+                if (cnt == 16u) {  // (wave-uniform) a full chunk -- three of five: every lane has an entry, nothing to mask
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t rows = cnt > (uint32_t)r ? (cnt - (uint32_t)r + 3u) >> 2 : 0u;   // 0..4, wave-uniform
-                    const unsigned long long has = rows >= 4u ? ~0ull : ((1ull << (16u * rows)) - 1ull);
-                    float val = r == 0 ? d.x : (r == 1 ? d.y : (r == 2 ? d.z : d.w));
-                    val = ((has >> lane) & 1ull) ? val : 0.f;  // (only lane 0 can be active without an entry)
-                    const unsigned long long on = has | 1ull;
-                    const uint32_t off = 64u * sl[r] + 4u * (uint32_t)m;
-                    unsigned long long saved;
-                    asm volatile("s_mov_b64 %0, exec\n\t"
-                                 "s_and_b64 exec, exec, %1\n\t"
-                                 "global_atomic_add_f32 %2, %3, %4\n\t"
-                                 "s_mov_b64 exec, %0"
-                                 : "=&s"(saved)
-                                 : "s"(on), "v"(off), "v"(val), "s"(ginst)
-                                 : "memory");
+                    for (int r = 0; r < 4; r++) {
+                        const float val = r == 0 ? d.x : (r == 1 ? d.y : (r == 2 ? d.z : d.w));
+                        const uint32_t off = 64u * sl[r] + 4u * (uint32_t)m;
+                        asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(off), "v"(val), "s"(ginst) : "memory");
+                    }
+                } else {
+                    const uint32_t k4 = 4u * (uint32_t)k;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        // lane (k, c) has an entry in register r when 4 k + r < cnt: one vector compare gives the lane mask
+                        const unsigned long long has = __builtin_amdgcn_ballot_w64(k4 + (uint32_t)r < cnt);
+                        float val = r == 0 ? d.x : (r == 1 ? d.y : (r == 2 ? d.z : d.w));
+                        val = (k4 + (uint32_t)r < cnt) ? val : 0.f;  // (only lane 0 can be active without an entry)
+                        const unsigned long long on = has | 1ull;
+                        const uint32_t off = 64u * sl[r] + 4u * (uint32_t)m;
+                        unsigned long long saved;
+                        asm volatile("s_mov_b64 %0, exec\n\t"
+                                     "s_and_b64 exec, exec, %1\n\t"
+                                     "global_atomic_add_f32 %2, %3, %4\n\t"
+                                     "s_mov_b64 exec, %0"
+                                     : "=&s"(saved)
+                                     : "s"(on), "v"(off), "v"(val), "s"(ginst)
+                                     : "memory");
+                    }
                 }
                 GHR_PROF(4);
             }
@@ -379,8 +391,8 @@ __device__ __forceinline__ void b3_tile(B3Shared& sh, int W, int H, int tx, int 
             } while (n_c == 0);
             if (w_hi < 0) break;
             if (SMALL) {
-                issue(0);
-                if (n_c > 16u) issue(1);
+                issue(0, 0);
+                if (n_c > 16u) issue(1, 1);
             }
         }
     }
