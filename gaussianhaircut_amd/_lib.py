@@ -23,7 +23,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 NUM_CHANNELS = 10
 GRAD_STRIDE = 16
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 14  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 15  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -116,7 +116,7 @@ class WsView(ctypes.Structure):
 
 # Every symbol include/ghr.h declares (the CPU test suite checks the library exports all of them).
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
-           "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_model_forward_stage1",
+           "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
            "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range"]
@@ -152,6 +152,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_set_profile_events.argtypes = [vp, vp, vp, vp]
     L.ghr_set_deterministic.argtypes = [i32]
     L.ghr_selftest_wave.argtypes = [vp, vp, vp]
+    L.ghr_selftest_math.argtypes = [vp, i32, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
     L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]
     L.ghr_loss_gt_stats.argtypes = [vp, ctypes.POINTER(LossArgs), vp]

@@ -710,6 +710,14 @@ int ghr_selftest_wave(void* stream, const float* in, float* out)
     return finish((hipStream_t)stream, 1);
 }
 
+int ghr_selftest_math(void* stream, int32_t n, const float* in, float* out)
+{
+    if (n < 0 || (n > 0 && (!in || !out))) return fail(GHR_E_INVALID, "ghr_selftest_math: bad arguments");
+    if (n == 0) return GHR_OK;
+    hipLaunchKernelGGL(ghr::k_math_selftest, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, in, out);
+    return finish((hipStream_t)stream, 1);
+}
+
 int ghr_set_deterministic(int32_t on)
 {
     const int prev = g_deterministic;

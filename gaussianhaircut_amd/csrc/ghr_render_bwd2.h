@@ -101,6 +101,17 @@ typedef float f2b __attribute__((ext_vector_type(2)));  // pairs of pixel rows: 
 
 
 // ---- self test of the wave primitives (tests/test_gpu_wave_primitives.py): in[8][64] -> out[12][64] ---------------------
+// ghr_selftest_math (include/ghr.h): the device twins of the transcendentals of ghr_device.h on caller data
+__global__ void __launch_bounds__(256) k_math_selftest(int n, const float* __restrict__ in, float* __restrict__ out)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const f4 v = reinterpret_cast<const f4*>(in)[i];
+    reinterpret_cast<f4*>(out)[i] = f4{fast_exp(v.x), fast_rcp(v.y), fast_sqrt(v.z), fast_log(v.w)};
+#endif
+}
+
 __global__ void k_wave_selftest(const float* __restrict__ in, float* __restrict__ out)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 14
+#define GHR_ABI_VERSION 15
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -292,6 +292,14 @@ int ghr_set_deterministic(int32_t on);
  * row broadcast, v_mfma_f32_16x16x4_f32 operand / result layout): in[8][64] floats -> out[12][64] floats (device
  * pointers); tests/test_gpu_wave_primitives.py states the expected values. */
 int ghr_selftest_wave(void* stream, const float* in, float* out);
+
+/* ABI 15.  Self test of the hardware transcendentals the kernels use where the reference calls libm (exp in the alpha of
+ * forward.cu:366 / backward.cu:504, 1 / (1 - alpha) in backward.cu:507, sqrt / log / rcp in the conservative culls): the
+ * DEVICE twins of csrc/ghr_device.h -- v_exp_f32(x * log2 e), v_rcp_f32, v_sqrt_f32, v_log_f32 * ln 2 -- which the CPU
+ * host-sim tests cannot see (they compile the host twins: expf, 1 / x, sqrtf, logf).  in[n][4] -> out[n][4] (device pointers):
+ * out = (fast_exp(in.x), fast_rcp(in.y), fast_sqrt(in.z), fast_log(in.w)); tests/test_gpu_wave_primitives.py bounds their
+ * error in ulp -- the margin of 2e-5 the parity tests give a discrete decision (tests/helpers.py) rests on those bounds. */
+int ghr_selftest_math(void* stream, int32_t n, const float* in, float* out);
 
 /* Introspection for tests (device pointers into the workspaces; layout is otherwise private). */
 typedef struct ghr_ws_view {
