@@ -204,11 +204,12 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
-                "note": "gradient walk bound by the misses a CU keeps in flight, not by bandwidth (profiles/r03i, r03m: VALU "
-                        "issue 57 %% of the SIMD cycles at 5 waves per SIMD, TA busy 60 %%, L1 stalled on pending misses 55 %% "
-                        "of the kernel: removing the chunk arithmetic saves 17 %%, the atomics 7 %%; every L2 atomic is written "
-                        "through to HBM, hence traffic > algorithmic bytes; the zero-fill of the gradient lines runs under "
-                        "the forward pass's tile sort); algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T "
+                "note": "gradient walk NOT bound by HBM bandwidth: it issues one 64-B line atomic per (cell, splat) hit and the L2 "
+                        "retires ~17 G of them per second (profiles/r04k: 2.96 M hits = 0.174 ms on this workload; four more "
+                        "per chunk cost 2.7x), with the wave's issue chain (~0.17 ms) and the chunk arithmetic (0.117 ms of "
+                        "VALU) right behind; every L2 atomic is written through to HBM, hence traffic > algorithmic bytes; "
+                        "the zero-fill of the gradient lines runs under the forward pass's tile sort; DESIGN.md 10 / 11); "
+                        "algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T "
                         "of the measured view; kernel duration from HIP events the library records around the kernel on its "
                         "launch stream, %d solo passes" % n_ev}
 
