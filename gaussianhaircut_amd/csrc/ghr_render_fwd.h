@@ -135,9 +135,16 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                     (128u * (uint32_t)(mask_word0(beg, tile) + ((base + sub) >> 6)) + 8u * (uint32_t)(4 * wave + grp))) = todo;
             if (((alive >> (16 * grp)) & 0xffffull) == 0) todo = 0;  // this cell is finished
             while (todo) {  // divergent per GROUP (all 16 lanes of a DPP row share `todo`)
-                const uint32_t j = sub + (uint32_t)__builtin_ctzll(todo);
+                // (the entry's LDS byte offset straight from the bit index -- (ctz << 4) + 16 sub is ONE v_lshl_add -- and its
+                // list position from the scalar base + sub + 1: the kernel is VALU-bound, +8 VALU per step = +17 %)
+                const uint32_t bit = (uint32_t)__builtin_ctzll(todo);
                 todo &= todo - 1;
-                done |= fwd_step(st, !done, pxf, pyf, s_r0[j], s_r1[j], s_r2[j], s_r3[j], base + j + 1);
+                uint32_t off;  // (written out: the compiler turns (bit << 4) + 16 sub back into an OR and a shift)
+                asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(off) : "v"(bit), "s"(16u * sub));
+                done |= fwd_step(st, !done, pxf, pyf, *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(s_r0) + off),
+                                 *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(s_r1) + off),
+                                 *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(s_r2) + off),
+                                 *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(s_r3) + off), (base + sub + 1u) + bit);
             }
             GHR_PROF(4);
         }
