@@ -128,9 +128,9 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
         for (int i = 0; i < 4; i++) sb[i] = (i < per_b && tid * per_b + i < nblk) ? slot_blk[tid * per_b + i] : 0u;
     // ---- tile counts -> tile_start, rounds of 8192 tiles (one at 1080p)
     uint32_t carry = 0u;
+    uint32_t c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (kept past the loop: the order below takes a single round's counts from here)
     for (uint32_t base = 0; base < (uint32_t)T; base += 8u * GHR_SCAN_BLOCK) {
         const uint32_t t0 = base + 8u * (uint32_t)tid;
-        uint32_t c[8];
         if (t0 + 8u <= (uint32_t)T) {  // (tile_count / tile_start are 256-B aligned sub-allocations: 32-B accesses)
             const uint4 a = *reinterpret_cast<const uint4*>(tile_count + t0), b = *reinterpret_cast<const uint4*>(tile_count + t0 + 4);
             c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
@@ -204,9 +204,20 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
             for (uint32_t k = total_x + (uint32_t)lane; k < grid / 8u; k += 64u) tile_order[8u * k + (uint32_t)x] = 0xffffffffu;
         }
         __syncthreads();
-        for (uint32_t t = tid; t < (uint32_t)T; t += GHR_SCAN_BLOCK) {
-            const uint32_t x = (t / GHR_XCD_RUN) & 7u;
-            tile_order[8u * atomicAdd(&s_hist[x][63u - min((tile_start[t + 1] - tile_start[t]) >> 4, 63u)], 1u) + x] = t;
+        if ((uint32_t)T <= 8u * GHR_SCAN_BLOCK) {  // one round (1080p: 8160 tiles): the counts are still in registers
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t t = 8u * (uint32_t)tid + (uint32_t)i;
+                if (t < (uint32_t)T) {
+                    const uint32_t x = (t / GHR_XCD_RUN) & 7u;
+                    tile_order[8u * atomicAdd(&s_hist[x][63u - min(c[i] >> 4, 63u)], 1u) + x] = t;
+                }
+            }
+        } else {
+            for (uint32_t t = tid; t < (uint32_t)T; t += GHR_SCAN_BLOCK) {
+                const uint32_t x = (t / GHR_XCD_RUN) & 7u;
+                tile_order[8u * atomicAdd(&s_hist[x][63u - min((tile_start[t + 1] - tile_start[t]) >> 4, 63u)], 1u) + x] = t;
+            }
         }
     }
 #endif
@@ -226,27 +237,42 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
     const int lane = threadIdx.x & 63, q = lane >> 4;
     const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 16) + (lane & 15);
     rect4 r = rect4{0u, 0u, 0u, 0u};
-    if (idx < P) {
+    uint32_t sb = 0u;
+    float dep = 0.f;
+    if (idx < P) {  // (the three loads together: one round trip, not three -- the depth used to sit under its own branch)
         r = rects[idx];
-        if (q == 0) rects[idx].w = slot_blk[idx >> 8];  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
+        sb = slot_blk[idx >> 8];
+        dep = depths[idx];
     }
+    if (idx < P && q == 0) rects[idx].w = sb;  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
     const int w = x1 - x0, full = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
     const bool big = full > GHR_BIG_RECT;  // walked by the whole wave below
     const int area = big ? 0 : full;
-    const uint64_t key = full ? (((uint64_t)__float_as_uint(depths[idx]) << 32) | (uint32_t)idx) : 0ull;
+    const uint64_t key = full ? (((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx) : 0ull;
     int max_area = area;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));  // same in all 4 rows
     // first ordinal q -> (kx, ky); afterwards advance by 4 without a division per step (w >= 1 when area > 0)
     int ky = area ? q / w : 0, kx = area ? q - ky * w : 0;
-    for (int k = q; k - q < max_area; k += 4) {
-        const bool on = k < area;
-        const int t = (y0 + ky) * gx + x0 + kx;
-        const uint32_t pos = wave_inc(tile_cursor, (uint32_t)t, on);
-        if (on && tile_start[t] + pos < cap) keys[tile_start[t] + pos] = key;  // cap: see ghr_forward_stage2
+    // Two ordinals per trip (all there are below GHR_BIG_RECT = 8 tiles): both returning atomics and both tile_start loads
+    // are in flight together -- the kernel was this chain of dependent round trips, one per ordinal (round 5)
+    for (int k = q; k - q < max_area; k += 8) {
+        const bool on0 = k < area;
+        const int t0 = (y0 + ky) * gx + x0 + kx;
         kx += 4;
-        while (on && kx >= w) { kx -= w; ky++; }
+        while (on0 && kx >= w) { kx -= w; ky++; }
+        const bool on1 = k + 4 < area;
+        const int t1 = (y0 + ky) * gx + x0 + kx;
+        kx += 4;
+        while (on1 && kx >= w) { kx -= w; ky++; }
+        int lead0, lead1;
+        const uint32_t b0 = wave_inc_issue(tile_cursor, (uint32_t)t0, on0, lead0);
+        const uint32_t b1 = wave_inc_issue(tile_cursor, (uint32_t)t1, on1, lead1);
+        const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
+        const uint32_t p0 = s0 + wave_inc_result(b0, lead0), p1 = s1 + wave_inc_result(b1, lead1);
+        if (on0 && p0 < cap) keys[p0] = key;  // cap: see ghr_forward_stage2
+        if (on1 && p1 < cap) keys[p1] = key;
     }
     // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- take it from row 0
     unsigned long long todo = __builtin_amdgcn_ballot_w64(big) & 0xffffull;

@@ -279,6 +279,29 @@ __device__ __forceinline__ uint32_t wave_inc(uint32_t* counter, uint32_t t, bool
     base = (uint32_t)__shfl((int)base, lead);
     return base + (uint32_t)(lane - lead);
 }
+// wave_inc in two halves, so that SEVERAL returning atomics of a lane are in flight together (k_scatter: a lane's chain of
+// dependent round trips was the kernel): _issue sends the run leaders' atomics and returns the raw result (valid in the
+// leader lanes only, not yet waited for) with the lane's leader in `lead`; _result broadcasts it inside the run.
+__device__ __forceinline__ uint32_t wave_inc_issue(uint32_t* counter, uint32_t t, bool active, int& lead)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t key = active ? t : 0xffffffffu;
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    const bool leader = lane == 0 || prev != key;
+    const unsigned long long lm = __builtin_amdgcn_ballot_w64(leader);
+    const unsigned long long upto = (2ull << lane) - 1ull;
+    lead = 63 - __builtin_clzll(lm & upto);
+    const unsigned long long after = lm & ~((2ull << lead) - 1ull);
+    const int end = after ? __builtin_ctzll(after) : 64;
+    uint32_t base = 0;
+    if (leader && active) base = atomicAdd(&counter[t], (uint32_t)(end - lead));
+    return base;
+}
+__device__ __forceinline__ uint32_t wave_inc_result(uint32_t base, int lead)
+{
+    const int lane = threadIdx.x & 63;
+    return (uint32_t)__shfl((int)base, lead) + (uint32_t)(lane - lead);
+}
 #endif
 
 // ---- chip mapping ----------------------------------------------------------------------------------------------------

@@ -249,12 +249,20 @@ GHR_HD float sh_coeff(const ModelArgs& a, int idx, const float* rest, int k, int
     return k < a.sh_coeffs ? rest[(k - 1) * 3 + ch] : 0.f;
 }
 
-// Forward for one Gaussian.  Returns false when culled.
-GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1)
+// What the forward leaves per Gaussian (k_project stores it itself: the record through an LDS transpose)
+struct ProjOut {
+    f4 rec[4];      // packed render record (zero when culled)
+    float depth;    // view z (culled: not stored)
+    int radius;     // 0 when culled
+    float ndc[3];   // get_mean_2d values, written for every row
+};
+
+// Forward for one Gaussian, nothing stored.  Returns false when culled.
+GHR_HD bool project_core(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1, ProjOut& o)
 {
-    const size_t row = (size_t)a.row0 + idx;
-    a.radii[row] = 0;
-    a.rects[row] = rect4{0u, 0u, 0u, 0u};
+    o.radius = 0;
+    o.depth = 0.f;
+    o.rec[0] = o.rec[1] = o.rec[2] = o.rec[3] = f4{0.f, 0.f, 0.f, 0.f};
     ProjCtx c;
     proj_setup(a, idx, c);
     const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
@@ -267,11 +275,7 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
     const float hw = mx * pm[3] + my * pm[7] + mz * pm[11] + pm[15];
     const float p_w = 1.0f / (hw + 0.0000001f);
     const float ndcx = hx * p_w, ndcy = hy * p_w;
-    if (a.means2D) {
-        a.means2D[3 * row] = ndcx;
-        a.means2D[3 * row + 1] = ndcy;
-        a.means2D[3 * row + 2] = hz * p_w;
-    }
+    o.ndc[0] = ndcx; o.ndc[1] = ndcy; o.ndc[2] = hz * p_w;
 
     // filter_points (gaussian_model.py:166-172) == K1's cull (auxiliary.h:154)
     if (!(c.t[2] > 0.2f)) return false;
@@ -325,15 +329,30 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
         }
     }
 
-    f4* r = a.rec + 4 * row;
-    r[0] = f4{pixx, pixy, cx, cy};
-    r[1] = f4{cz, opac, rgb[0], rgb[1]};
-    r[2] = f4{rgb[2], label, 1.0f, d2x};
-    r[3] = f4{d2y, 0.0f, conf, c.t[2]};
-    a.depths[row] = c.t[2];
-    a.radii[row] = (int)my_radius;
-    a.rects[row] = make_rect4(x0, y0, x1, y1, 0u);  // the caller fills in the gradient-slot base
+    o.rec[0] = f4{pixx, pixy, cx, cy};
+    o.rec[1] = f4{cz, opac, rgb[0], rgb[1]};
+    o.rec[2] = f4{rgb[2], label, 1.0f, d2x};
+    o.rec[3] = f4{d2y, 0.0f, conf, c.t[2]};
+    o.depth = c.t[2];
+    o.radius = (int)my_radius;
     return true;
+}
+
+// project_core + the stores of one Gaussian (tests/hostsim; k_project stores for itself).  Returns false when culled.
+GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1)
+{
+    const size_t row = (size_t)a.row0 + idx;
+    ProjOut o;
+    const bool ok = project_core(a, idx, rest, x0, y0, x1, y1, o);
+    if (a.means2D) { a.means2D[3 * row] = o.ndc[0]; a.means2D[3 * row + 1] = o.ndc[1]; a.means2D[3 * row + 2] = o.ndc[2]; }
+    a.radii[row] = o.radius;
+    a.rects[row] = ok ? make_rect4(x0, y0, x1, y1, 0u) : rect4{0u, 0u, 0u, 0u};  // the caller fills in the gradient-slot base
+    if (ok) {
+        f4* r = a.rec + 4 * row;
+        r[0] = o.rec[0]; r[1] = o.rec[1]; r[2] = o.rec[2]; r[3] = o.rec[3];
+        a.depths[row] = o.depth;
+    }
+    return ok;
 }
 
 // Backward for one Gaussian: packed rasterizer gradients `ga[16]` (already summed over the Gaussian's tile instances)
@@ -625,12 +644,38 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     __syncthreads();
     const int idx = base + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    const bool ok = idx < a.P && project_one(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1);
+    ProjOut o;
+    const bool ok = idx < a.P && project_core(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1, o);
     __shared__ uint32_t s_scan[4];
     uint32_t blk_total;
     const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
-    if (ok) a.rects[(size_t)a.row0 + idx].z = slot0;
+    // (the scan's barrier is also the one behind which nobody reads the coefficient slab any more)
+    // The record is 64 B per Gaussian: stored by its own thread it is four 16-B pieces at a 64-B stride per instruction (2.47 M
+    // partial write requests at 500k Gaussians, profiles/r02a).  Through LDS instead: thread t stores the 16-B pieces
+    // t, t + 256, ... of the workgroup's 16 KB of records -- 1 KB contiguous per wave and instruction.  Culled rows get zeros.
+    f4* s_rec = reinterpret_cast<f4*>(s_rest);
+    if (idx < a.P) {
+        const size_t rowi = (size_t)a.row0 + idx;
+#pragma unroll
+        for (int q = 0; q < 4; q++) s_rec[4 * threadIdx.x + q] = o.rec[q];
+        if (a.means2D) { a.means2D[3 * rowi] = o.ndc[0]; a.means2D[3 * rowi + 1] = o.ndc[1]; a.means2D[3 * rowi + 2] = o.ndc[2]; }
+        a.radii[rowi] = o.radius;
+        // (one 16-B store with the gradient-slot base inside the workgroup already in place; .w comes from k_scatter)
+        rect4 r = rect4{0u, 0u, 0u, 0u};
+        if (ok) { r = make_rect4(x0, y0, x1, y1, 0u); r.z = slot0; }
+        a.rects[rowi] = r;
+        if (ok) a.depths[rowi] = o.depth;
+    }
     if (threadIdx.x == 0) a.slot_blk[blockIdx.x + (a.row0 >> 8)] = blk_total;
+    __syncthreads();
+    {
+        f4* dst = a.rec + 4 * ((size_t)a.row0 + base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int j = threadIdx.x + GHR_BLOCK * k;
+            if (j < 4 * nb) dst[j] = s_rec[j];
+        }
+    }
     count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
 #endif
 }
