@@ -9,7 +9,6 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <initializer_list>
 
 #include "ghr_binning.h"
 #include "ghr_device.h"
@@ -575,16 +574,12 @@ static dim3 loss_march_grid(const ghr_loss_args* l, int seg)
 {
     return dim3(8 * (((l->W + GHR_LM_TW - 1) / GHR_LM_TW + 7) / 8), (l->H + seg - 1) / seg, 3);
 }
-// (every plane the marching kernels touch is accessed 16 B at a time since round 5 -- the epilogue's per-pixel planes too)
-static bool loss_vec_ok(const ghr_loss_args* l, std::initializer_list<const void*> more = {})
+static bool loss_vec_ok(const ghr_loss_args* l, const void* p0 = nullptr, const void* p1 = nullptr)
 {
     const bool off = std::getenv("GHR_LOSS_SCALAR") != nullptr;  // test / measurement knob (read per call): the tile kernels
     if (off || (l->W & 3) || (size_t)l->W * (size_t)l->H >= ((size_t)1 << 30)) return false;
-    const void* ps[] = {l->image, l->mask, l->dir2d, l->orient_conf, l->gt_image, l->gt_mask, l->gt_orient_angle,
-                        l->gt_orient_conf, l->gt_stats};
+    const void* ps[] = {l->image, l->gt_image, l->gt_mask, l->gt_stats, p0, p1};
     for (const void* p : ps)
-        if (((uintptr_t)p & 15u) != 0) return false;
-    for (const void* p : more)
         if (((uintptr_t)p & 15u) != 0) return false;
     return true;
 }
@@ -602,7 +597,7 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
                     l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums, l->gt_stats, nullptr,
                     loss_march_seg(l, false)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    const bool vec = loss_vec_ok(l, {maps});
+    const bool vec = loss_vec_ok(l, maps);
     const dim3 grid_v = loss_march_grid(l, a.seg);
     if (l->gt_stats) {
         if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_cached_v, grid_v, dim3(64), 0, s, a);
@@ -625,7 +620,7 @@ int ghr_loss_gt_stats(void* stream, const ghr_loss_args* l, float* stats_out)
     ghr::LossArgs a{l->W, l->H, l->gt_image, nullptr, nullptr, nullptr, l->gt_image, l->gt_mask, nullptr, nullptr,
                     l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out, loss_march_seg(l, false)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    if (loss_vec_ok(l, {stats_out})) hipLaunchKernelGGL(ghr::k_loss_gt_stats_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
+    if (loss_vec_ok(l, stats_out)) hipLaunchKernelGGL(ghr::k_loss_gt_stats_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(ghr::k_loss_gt_stats, grid, dim3(256), 0, s, a);
     return finish(s, 0);
 }
@@ -647,7 +642,7 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
                        grad_loss, l->w_l1, l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, d_image, d_mask, d_dir2d,
                        d_orient_conf, zero_plane_a, zero_plane_b, loss_march_seg(l, true)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
-    if (loss_vec_ok(l, {maps, d_image, d_mask, d_dir2d, d_orient_conf, zero_plane_a, zero_plane_b})) hipLaunchKernelGGL(ghr::k_loss_bwd_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
+    if (loss_vec_ok(l, maps)) hipLaunchKernelGGL(ghr::k_loss_bwd_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(ghr::k_loss_bwd, grid, dim3(256), 0, s, a);
     return finish(s, 0);
 }

@@ -567,31 +567,6 @@ __device__ __forceinline__ void vpass4(const float (*s_h)[GHR_LM_HR][GHR_LM_HS],
             }
     }
 }
-// Vertical 11-tap pass for the FOUR COLUMNS 4 cg .. 4 cg + 3 of output row r, from rows r .. r + 10 of the filtered planes as
-// 16-B reads (taps in ascending order for every output, like vpass4 and the tile kernels: the same bits).  This is the
-// mapping of the marching kernels' epilogue since round 5: a lane owns four ADJACENT pixels of one row, so everything the
-// epilogue loads and stores per pixel is one 16-B access per plane instead of four 4-B ones a row apart -- the kernels are
-// bound by the L1's address path (profiles/r03h: TA busy 60 %), which works per instruction and quad, not per byte.
-template <int NM>
-__device__ __forceinline__ void vpass_row4(const float (*s_h)[GHR_LM_HR][GHR_LM_HS], int r, int cg, float (*acc)[NM])
-{
-#pragma unroll
-    for (int o = 0; o < 4; o++)
-#pragma unroll
-        for (int k = 0; k < NM; k++) acc[o][k] = 0.f;
-#pragma unroll
-    for (int t = 0; t < 11; t++) {
-        const float w = c_ssim_w[t];
-#pragma unroll
-        for (int k = 0; k < NM; k++) {
-            const f4 v = *reinterpret_cast<const f4*>(&s_h[k][r + t][4 * cg]);
-            fmac_s(acc[0][k], w, v.x);
-            fmac_s(acc[1][k], w, v.y);
-            fmac_s(acc[2][k], w, v.z);
-            fmac_s(acc[3][k], w, v.w);
-        }
-    }
-}
 // rows 8..17 of the filtered planes become rows 0..9 of the next pass: 10 rows x 8 float4 per plane.  The two ranges overlap:
 // every read is issued before the first write (one wave: its LDS operations execute in program order)
 template <int NM>
@@ -722,8 +697,8 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
         }
     };
 
-    const int er = lane & 7, ecg = lane >> 3;  // epilogue: output row er of the pass, columns 4 ecg .. 4 ecg + 3 of the strip
-    const int gx = bx + 4 * ecg;             // (W % 4 == 0: the four columns are inside or outside the image together)
+    const int tx = lane & 31, rg = lane >> 5;
+    const int gx = bx + tx;
     const bool orient = MODE != 2 && CH2 && a.dir2d != nullptr;  // uniform
     // The loop is rotated so that a batch is committed at the END of the pass before it, in straight-line code behind the
     // pass's stores: the wait for its loads then is an exact count (vmcnt = the stores issued since) instead of a drain of
@@ -747,69 +722,74 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
         // store round trip per pass (measured: 112 us per kernel, SIMDs 25 % busy).
         const bool more = yb + GHR_LM_ROWS < y1;  // uniform
         fetch(yb + GHR_LM_ROWS + GHR_SSIM_R, more ? GHR_LM_ROWS * GHR_LM_WQ : 0);
-        const int gy = yb + er;
-        const bool ok = gx < W && gy < y1;
-        const uint32_t p4 = ok ? 4u * ((uint32_t)gy * (uint32_t)W + (uint32_t)gx) : 0u;  // byte offset of the lane's four pixels
-        const f4 z4 = {0.f, 0.f, 0.f, 0.f};
-        f4 l_mu2 = z4, l_e22 = z4, l_mk = z4, l_gmk = z4;
-        if (MODE != 2) {
-            if (MODE == 1) {
-                l_mu2 = ldb<f4>(a.gt_stats + (size_t)(0 * 3 + ch) * N, p4);
-                l_e22 = ldb<f4>(a.gt_stats + (size_t)(1 * 3 + ch) * N, p4);
-            }
-            if (!CH2) {
-                l_mk = ldb<f4>(a.mask + (size_t)ch * N, p4);
-                l_gmk = ldb<f4>(a.gt_mask + (size_t)ch * N, p4);
-            }
+        bool ok[4];
+        uint32_t p4[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int gy = yb + 4 * rg + o;
+            ok[o] = gx < W && gy < y1;
+            p4[o] = ok[o] ? 4u * ((uint32_t)gy * (uint32_t)W + (uint32_t)gx) : 0u;
         }
-        // (CH2: the orientation term's six planes too -- requested here, used behind the vertical pass)
-        f4 ow = z4, od0 = z4, od1 = z4, oc = z4, oa = z4, om = z4;
-        if (CH2 && orient) {
-            ow = ldb<f4>(a.gt_oconf, p4); od0 = ldb<f4>(a.dir2d, p4); od1 = ldb<f4>(a.dir2d + N, p4);
-            oc = ldb<f4>(a.oconf, p4); oa = ldb<f4>(a.gt_angle, p4); om = ldb<f4>(a.gt_mask, p4);
+        float l_mu2[4], l_e22[4], l_mk[4], l_gmk[4];
+        if (MODE != 2) {
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (MODE == 1) {
+                    l_mu2[o] = ldb<float>(a.gt_stats + (size_t)(0 * 3 + ch) * N, p4[o]);
+                    l_e22[o] = ldb<float>(a.gt_stats + (size_t)(1 * 3 + ch) * N, p4[o]);
+                }
+                if (!CH2) {
+                    l_mk[o] = ldb<float>(a.mask + (size_t)ch * N, p4[o]);
+                    l_gmk[o] = ldb<float>(a.gt_mask + (size_t)ch * N, p4[o]);
+                }
+            }
         }
         wave_lds_fence();
         float acc[4][NM];
-        vpass_row4<NM>(s_h, er, ecg, acc);
+        vpass4<NM>(s_h, rg, tx, acc);
         if (MODE == 2) {
-            f4 oy = {acc[0][PY], acc[1][PY], acc[2][PY], acc[3][PY]}, oyy = {acc[0][PYY], acc[1][PYY], acc[2][PYY], acc[3][PYY]};
-            touch4(oy); touch4(oyy);
-            if (ok) {
-                stb<f4>(a.stats_out + (size_t)(0 * 3 + ch) * N, p4, oy);
-                stb<f4>(a.stats_out + (size_t)(1 * 3 + ch) * N, p4, oyy);
-            }
+#pragma unroll
+            for (int o = 0; o < 4; o++) { touch(acc[o][PY]); touch(acc[o][PYY]); }
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+                if (ok[o]) {
+                    stb<float>(a.stats_out + (size_t)(0 * 3 + ch) * N, p4[o], acc[o][PY]);
+                    stb<float>(a.stats_out + (size_t)(1 * 3 + ch) * N, p4[o], acc[o][PYY]);
+                }
         } else {
             float d0[4], d1[4], d2[4];
-            const float mu2v[4] = {l_mu2.x, l_mu2.y, l_mu2.z, l_mu2.w}, e22v[4] = {l_e22.x, l_e22.y, l_e22.z, l_e22.w};
-            const float mkv[4] = {l_mk.x, l_mk.y, l_mk.z, l_mk.w}, gmkv[4] = {l_gmk.x, l_gmk.y, l_gmk.z, l_gmk.w};
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                const float mu2 = MODE == 1 ? mu2v[o] : acc[o][PY];
-                const float e22 = MODE == 1 ? e22v[o] : acc[o][PYY];
+                const float mu2 = MODE == 1 ? l_mu2[o] : acc[o][PY];
+                const float e22 = MODE == 1 ? l_e22[o] : acc[o][PYY];
                 const float sv = ssim_point(acc[o][PX], mu2, acc[o][PXX], e22, acc[o][PXY], d0[o], d1[o], d2[o]);
-                sums[1] += ok ? sv : 0.f;
-                if (!CH2) sums[2] += ok ? fabsf(mkv[o] - gmkv[o]) : 0.f;
+                sums[1] += ok[o] ? sv : 0.f;
+                if (!CH2) sums[2] += ok[o] ? fabsf(l_mk[o] - l_gmk[o]) : 0.f;
             }
-            if (CH2 && orient) {  // the waves of the third colour channel also carry the orientation term
-                const float wv[4] = {ow.x, ow.y, ow.z, ow.w}, d0v[4] = {od0.x, od0.y, od0.z, od0.w},
-                            d1v[4] = {od1.x, od1.y, od1.z, od1.w}, cv[4] = {oc.x, oc.y, oc.z, oc.w},
-                            av[4] = {oa.x, oa.y, oa.z, oa.w}, mv[4] = {om.x, om.y, om.z, om.w};
+            if (CH2 && orient) {  // the waves of the third colour channel also carry the orientation term (before the stores:
+                                  // waiting for its loads then does not wait for them)
 #pragma unroll
                 for (int o = 0; o < 4; o++) {
-                    const OrientPix op = orient_pixel(d0v[o], d1v[o], cv[o], av[o], mv[o]);
-                    sums[3] += ok ? op.l * wv[o] : 0.f;
-                    sums[4] += ok ? wv[o] : 0.f;
+                    const float w = ldb<float>(a.gt_oconf, p4[o]);
+                    const OrientPix op = orient_pixel(ldb<float>(a.dir2d, p4[o]), ldb<float>(a.dir2d + N, p4[o]),
+                                                      ldb<float>(a.oconf, p4[o]), ldb<float>(a.gt_angle, p4[o]),
+                                                      ldb<float>(a.gt_mask, p4[o]));
+                    sums[3] += ok[o] ? op.l * w : 0.f;
+                    sums[4] += ok[o] ? w : 0.f;
                 }
             }
-            // (ALL the values first, then nothing but the stores under the lane mask)
-            f4 m0 = {d0[0], d0[1], d0[2], d0[3]}, m1 = {d1[0], d1[1], d1[2], d1[3]}, m2 = {d2[0], d2[1], d2[2], d2[3]};
-            touch4(m0); touch4(m1); touch4(m2);
+            // (ALL the values first, then nothing but the stores under the lane masks)
+#pragma unroll
+            for (int o = 0; o < 4; o++) { touch(d0[o]); touch(d1[o]); touch(d2[o]); }
 #pragma unroll
             for (int k = 0; k < 5; k++) touch(sums[k]);
-            if (ok) {
-                stb<f4>(a.maps + (size_t)(0 * 3 + ch) * N, p4, m0);
-                stb<f4>(a.maps + (size_t)(1 * 3 + ch) * N, p4, m1);
-                stb<f4>(a.maps + (size_t)(2 * 3 + ch) * N, p4, m2);
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                if (ok[o]) {
+                    stb<float>(a.maps + (size_t)(0 * 3 + ch) * N, p4[o], d0[o]);
+                    stb<float>(a.maps + (size_t)(1 * 3 + ch) * N, p4[o], d1[o]);
+                    stb<float>(a.maps + (size_t)(2 * 3 + ch) * N, p4[o], d2[o]);
+                }
             }
         }
         wave_lds_fence();  // every read of the vertical pass and of the last horizontal pass is done
@@ -903,8 +883,8 @@ __device__ __forceinline__ void loss_bwd_march(const LossBwdArgs& a, float (*s_m
         }
     };
 
-    const int er = lane & 7, ecg = lane >> 3;  // epilogue: output row er of the pass, columns 4 ecg .. 4 ecg + 3 (see vpass_row4)
-    const int gx = bx + 4 * ecg;
+    const int tx = lane & 31, rg = lane >> 5;
+    const int gx = bx + tx;
     const bool masked = a.mask_colours != 0;
     const bool orient_out = CH2 && a.d_dir2d != nullptr;                                       // uniform
     const bool orient_on = orient_out && a.dir2d != nullptr && a.w_orient != 0.f;              // uniform
@@ -936,34 +916,33 @@ __device__ __forceinline__ void loss_bwd_march(const LossBwdArgs& a, float (*s_m
         // the next batch BEFORE the epilogue's loads (see loss_fwd_march)
         const bool more = yb + GHR_LM_ROWS < y1;  // uniform
         fetch(yb + GHR_LM_ROWS + GHR_SSIM_R, more ? GHR_LM_ROWS * GHR_LM_WQ : 0);
-        const int gy = yb + er;
-        const bool ok = gx < W && gy < y1;
-        const uint32_t p4 = ok ? 4u * ((uint32_t)gy * (uint32_t)W + (uint32_t)gx) : 0u;  // byte offset of the lane's four pixels
-        const f4 one4 = {1.f, 1.f, 1.f, 1.f}, z4 = {0.f, 0.f, 0.f, 0.f};
-        const f4 l_im = ldb<f4>(a.image + (size_t)ch * N, p4);
-        const f4 l_g = ldb<f4>(a.gt_image + (size_t)ch * N, p4);
-        const f4 l_m = masked ? ldb<f4>(a.gt_mask + N, p4) : one4;
-        f4 l_mk = z4, l_gmk = z4;
-        if (!CH2) {
-            l_mk = ldb<f4>(a.mask + (size_t)ch * N, p4);
-            l_gmk = ldb<f4>(a.gt_mask + (size_t)ch * N, p4);
+        bool ok[4];
+        uint32_t p4[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            const int gy = yb + 4 * rg + o;
+            ok[o] = gx < W && gy < y1;
+            p4[o] = ok[o] ? 4u * ((uint32_t)gy * (uint32_t)W + (uint32_t)gx) : 0u;
         }
-        f4 ow = z4, od0 = z4, od1 = z4, oc = z4, oa = z4, om = z4;  // (CH2: the orientation term's six planes, used behind the vertical pass)
-        if (CH2 && orient_live) {
-            ow = ldb<f4>(a.gt_oconf, p4); od0 = ldb<f4>(a.dir2d, p4); od1 = ldb<f4>(a.dir2d + N, p4);
-            oc = ldb<f4>(a.oconf, p4); oa = ldb<f4>(a.gt_angle, p4); om = ldb<f4>(a.gt_mask, p4);
+        float l_im[4], l_g[4], l_m[4], l_mk[4], l_gmk[4];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            l_im[o] = ldb<float>(a.image + (size_t)ch * N, p4[o]);
+            l_g[o] = ldb<float>(a.gt_image + (size_t)ch * N, p4[o]);
+            l_m[o] = masked ? ldb<float>(a.gt_mask + N, p4[o]) : 1.0f;
+            if (!CH2) {
+                l_mk[o] = ldb<float>(a.mask + (size_t)ch * N, p4[o]);
+                l_gmk[o] = ldb<float>(a.gt_mask + (size_t)ch * N, p4[o]);
+            }
         }
         wave_lds_fence();
         float c[4][3];
-        vpass_row4<3>(s_h, er, ecg, c);
-        const float imv[4] = {l_im.x, l_im.y, l_im.z, l_im.w}, gv[4] = {l_g.x, l_g.y, l_g.z, l_g.w},
-                    mv[4] = {l_m.x, l_m.y, l_m.z, l_m.w}, mkv[4] = {l_mk.x, l_mk.y, l_mk.z, l_mk.w},
-                    gmkv[4] = {l_gmk.x, l_gmk.y, l_gmk.z, l_gmk.w};
+        vpass4<3>(s_h, rg, tx, c);
         float di[4], dmk[4], zval[4];
 #pragma unroll
         for (int o = 0; o < 4; o++) {
-            const float mm = mv[o];
-            const float im = imv[o], g = gv[o];
+            const float mm = l_m[o];
+            const float im = l_im[o], g = l_g[o];
             const float x = im * mm, y = g * mm;
             // d(mean ssim)/dx(p), then Lssim = 1 - mean  and x = image * m
             const float dssim_dx = (c[o][0] + 2.f * x * c[o][1] + y * c[o][2]) * inv3N;
@@ -972,39 +951,42 @@ __device__ __forceinline__ void loss_bwd_march(const LossBwdArgs& a, float (*s_m
             di[o] = up * (a.w_l1 * sgn * mm * inv3N - a.w_ssim * dssim_dx * mm);
             dmk[o] = 0.f;
             if (!CH2) {
-                const float dm = mkv[o] - gmkv[o];
+                const float dm = l_mk[o] - l_gmk[o];
                 const float sm = dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f);
                 dmk[o] = up * a.w_mask * sm * inv2N;
             }
             zval[o] = zfill ? 0.f : dmk[o];
         }
         float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, gc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (CH2 && orient_live) {
-            const float wv[4] = {ow.x, ow.y, ow.z, ow.w}, d0v[4] = {od0.x, od0.y, od0.z, od0.w},
-                        d1v[4] = {od1.x, od1.y, od1.z, od1.w}, cv[4] = {oc.x, oc.y, oc.z, oc.w},
-                        av[4] = {oa.x, oa.y, oa.z, oa.w}, omv[4] = {om.x, om.y, om.z, om.w};
+        if (CH2 && orient_live) {  // (before the stores: waiting for its loads then does not wait for them)
 #pragma unroll
             for (int o = 0; o < 4; o++) {
-                const OrientPix op = orient_pixel(d0v[o], d1v[o], cv[o], av[o], omv[o]);
-                const float sc = up * a.w_orient * wv[o] * inv_wsum;
+                const OrientPix op = orient_pixel(ldb<float>(a.dir2d, p4[o]), ldb<float>(a.dir2d + N, p4[o]),
+                                                  ldb<float>(a.oconf, p4[o]), ldb<float>(a.gt_angle, p4[o]),
+                                                  ldb<float>(a.gt_mask, p4[o]));
+                const float sc = up * a.w_orient * ldb<float>(a.gt_oconf, p4[o]) * inv_wsum;
                 g0[o] = sc * op.dl_dd0; g1[o] = sc * op.dl_dd1; gc[o] = sc * op.dl_dconf;
             }
         }
-        // (ALL the values first, then nothing but the stores under the lane mask)
-        f4 o_di = {di[0], di[1], di[2], di[3]}, o_a, o_b, o_c = z4;
-        if (!CH2) { o_a = f4{dmk[0], dmk[1], dmk[2], dmk[3]}; o_b = f4{zval[0], zval[1], zval[2], zval[3]}; }
-        else { o_a = f4{g0[0], g0[1], g0[2], g0[3]}; o_b = f4{g1[0], g1[1], g1[2], g1[3]}; o_c = f4{gc[0], gc[1], gc[2], gc[3]}; }
-        touch4(o_di); touch4(o_a); touch4(o_b);
-        if (CH2) touch4(o_c);
-        if (ok) {
-            stb<f4>(a.d_image + (size_t)ch * N, p4, o_di);
-            if (!CH2) {
-                stb<f4>(d_mask_ch, p4, o_a);
-                stb<f4>(zdst, p4, o_b);
-            } else if (orient_out) {
-                stb<f4>(a.d_dir2d, p4, o_a);
-                stb<f4>(a.d_dir2d + N, p4, o_b);
-                stb<f4>(a.d_oconf, p4, o_c);
+        // (ALL the values first, then nothing but the stores under the lane masks)
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            touch(di[o]);
+            if (!CH2) { touch(dmk[o]); touch(zval[o]); }
+            else { touch(g0[o]); touch(g1[o]); touch(gc[o]); }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            if (ok[o]) {
+                stb<float>(a.d_image + (size_t)ch * N, p4[o], di[o]);
+                if (!CH2) {
+                    stb<float>(d_mask_ch, p4[o], dmk[o]);
+                    stb<float>(zdst, p4[o], zval[o]);
+                } else if (orient_out) {
+                    stb<float>(a.d_dir2d, p4[o], g0[o]);
+                    stb<float>(a.d_dir2d + N, p4[o], g1[o]);
+                    stb<float>(a.d_oconf, p4[o], gc[o]);
+                }
             }
         }
         wave_lds_fence();

@@ -27,9 +27,17 @@ def _zero_grad_mode(zero_grad):
     return bool(zero_grad), False
 
 
-# Optimizer sharding over the ranks (ZeRO-1): reduce-scatter the gradients, update 1 / G of the
-# parameters per rank, all-gather the parameters -- the wire bytes of the all-reduce, 1 / G of the Adam pass.
+# Optimizer-COMPUTE sharding over the ranks (the communication pattern of ZeRO-1: reduce-scatter the gradients, update 1 / G
+# of the parameters per rank, all-gather the parameters -- the wire bytes of the all-reduce, 1 / G of the Adam pass).  It is
+# NOT ZeRO-1's memory saving: both moment buffers stay allocated in full on every rank (488 B per Gaussian against 288 GB of
+# HBM; densification re-lays them as whole tensors), only the slices a rank does not own go stale there -- see sync_moments().
 SHARD_ADAM = True
+
+
+class StaleMomentsError(RuntimeError):
+    """The Adam moments of this rank are current only on the slices it owns (sharded update, step_chunked(shard=True)):
+    reading them all needs sync_moments(), a COLLECTIVE every rank must enter.  Raised instead of starting that
+    collective from a call that is usually made by one rank alone (``if rank == 0: torch.save(gaussians.capture())``)."""
 
 
 def collectives_on() -> bool:
@@ -361,7 +369,13 @@ class FusedAdam:
         self._acc_event = None
         skip, self._skip_next = self._skip_next, 0
         comm = reduce and collectives_on()
-        shard = comm and (SHARD_ADAM if shard is None else bool(shard))
+        if shard and not (zero_grad or defer):
+            # the in-place reduce-scatter leaves a rank's OWN slice holding the global sum and the other slices local
+            # gradients / send-buffer remains: a caller that keeps the gradients (zero_grad=False) would read a mix
+            raise ValueError("FusedAdam.step_chunked: shard=True needs zero_grad=True or 'defer' (the sharded update does "
+                             "not leave the summed gradient on every rank); use shard=False to keep the gradients")
+        # (default: shard only when the gradients are not kept -- the same on every rank, it only depends on the arguments)
+        shard = comm and (SHARD_ADAM and (zero_grad or defer) if shard is None else bool(shard))
         G, r = (dist.get_world_size(), dist.get_rank()) if comm else (1, 0)
         plan = self._reduce_plan(chunks) if comm else [(a, b, "local") for a, b in self._chunk_ranges(chunks)]
         if shard:
@@ -437,10 +451,18 @@ class FusedAdam:
                 out.append((a + main, b, "sum"))
         return out
 
+    def moments_stale(self) -> bool:
+        """True when this rank's moments are current only on the slices it owns (after a sharded step on more than one
+        rank): state_dict() / capture() then need sync_moments() -- on every rank -- first."""
+        return self._moment_shards is not None and collectives_on()
+
     def sync_moments(self):
         """All-gather the Adam moments of the sharded ranges so that every rank holds all of them again (no-op when the
-        optimizer is not sharded or already in sync).  COLLECTIVE: every rank must call it at the same point -- which
-        holds for its callers (checkpointing, densification and the plan change all happen on every rank alike)."""
+        optimizer is not sharded or already in sync).  COLLECTIVE: every rank must call it at the same point.  That holds
+        for the callers inside this class that do so implicitly -- optimizer surgery (prune / extend / replace:
+        densification runs on every rank alike or the replicas diverge anyway), a change of the shard plan, a replicated
+        ``step()`` -- but NOT for checkpointing, which is usually rank 0's business alone: ``state_dict()`` therefore
+        never starts it on its own (StaleMomentsError; pass ``collective=True`` from every rank, or call this first)."""
         key, self._moment_shards = self._moment_shards, None
         if key is None or not collectives_on():
             return
@@ -462,12 +484,25 @@ class FusedAdam:
                 yield gi, off, off + p.numel(), p
                 off += p.numel()
 
-    def state_dict(self):
+    def state_dict(self, collective: bool = False):
         """``torch.optim.Adam.state_dict()`` layout (what the reference's ``GaussianModel.capture`` stores,
         src/scene/gaussian_model.py:84-99): ``state[i] = {step, exp_avg, exp_avg_sq}`` per parameter index and
         ``param_groups`` with ``params`` as indices -- a checkpoint written here restores into torch.optim.Adam and the
-        other way round.  ``step`` of a parameter is the optimizer's step count less the steps its group sat out."""
-        self.sync_moments()
+        other way round.  ``step`` of a parameter is the optimizer's step count less the steps its group sat out.
+
+        After a sharded step on more than one rank the moments are stale outside this rank's slices.  Bringing them in is a
+        collective, so it only happens on request: ``collective=True`` -- EVERY rank must then make this call -- or an
+        explicit ``sync_moments()`` on every rank beforehand.  Otherwise StaleMomentsError: the common
+        ``if rank == 0: torch.save(gaussians.capture())`` fails loudly instead of hanging in an all-gather nobody else joins."""
+        if self.moments_stale():
+            if not collective:
+                raise StaleMomentsError(
+                    "FusedAdam.state_dict(): the Adam moments are sharded over %d ranks (step_chunked(shard=True)) and stale "
+                    "on this one outside its own slices.  Call optimizer.sync_moments() on EVERY rank first (it is a "
+                    "collective), or state_dict(collective=True) / GaussianModel.capture(collective=True) from every rank; "
+                    "FusedAdam.SHARD off (optim.SHARD_ADAM = False) keeps every rank's moments complete."
+                    % dist.get_world_size())
+            self.sync_moments()
         st = self.state_dev.cpu()
         state = {}
         for i, (gi, a, b, p) in enumerate(self._param_ranges()):

@@ -80,11 +80,19 @@ class GaussianModel(DensificationMixin, PlyMixin):
         self.max_radii2D = torch.zeros(P, device=dev)
         return self
 
-    def capture(self):
+    def capture(self, collective: bool = False):
+        """The reference's checkpoint tuple (src/scene/gaussian_model.py:84-99).  Under data parallelism with the sharded
+        FusedAdam update the optimizer state is only complete after a collective: ``collective=True`` (every rank makes
+        the call) or ``optimizer.sync_moments()`` on every rank first -- a lone ``capture()`` raises StaleMomentsError
+        instead of hanging (optim.FusedAdam.state_dict)."""
+        opt = None
+        if self.optimizer:
+            from ..optim import FusedAdam
+            opt = self.optimizer.state_dict(collective=collective) if isinstance(self.optimizer, FusedAdam) \
+                else self.optimizer.state_dict()
         return (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling,
                 self._rotation, self._opacity, self._orient_conf, self._label, self.max_radii2D,
-                self.xyz_gradient_accum, self.denom, self.optimizer.state_dict() if self.optimizer else None,
-                self.spatial_lr_scale)
+                self.xyz_gradient_accum, self.denom, opt, self.spatial_lr_scale)
 
     def restore(self, model_args, training_args=None):
         (self.active_sh_degree, self._xyz, self._features_dc, self._features_rest, self._scaling, self._rotation,

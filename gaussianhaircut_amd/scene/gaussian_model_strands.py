@@ -92,3 +92,4 @@ class GaussianModelStrands(GaussianModel):
 # what differs is where the strand polylines come from (a latent texture decoded by an un-vendored strand prior: out of
 # scope).  For the hot path the two classes are the same object.
 GaussianModelLatentStrands = GaussianModelStrands
+GaussianModelCurves = GaussianModelStrands  # the reference's class name in this module (src/scene/gaussian_model_strands.py:31)

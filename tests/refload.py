@@ -27,8 +27,9 @@ def load_reference_renderer():
     scene = types.ModuleType("scene")
     gm = types.ModuleType("scene.gaussian_model")
     gm.GaussianModel = GaussianModel
-    ls = types.ModuleType("scene.gaussian_model_latent_strands")
-    ls.GaussianModelHair = object
+    # the module the reference's line 17 (`from scene.gaussian_model_latent_strands import GaussianModelHair`) resolves to
+    # is this package's own compat module, not a stub: the name it asks for must exist there
+    import gaussianhaircut_amd.scene.gaussian_model_latent_strands as ls
     sys.modules["scene"], sys.modules["scene.gaussian_model"] = scene, gm
     sys.modules["scene.gaussian_model_latent_strands"] = ls
     for m in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:

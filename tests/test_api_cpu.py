@@ -306,3 +306,15 @@ def test_camera_that_requires_grad_never_takes_the_fused_projection():
     pose = c.world_view_transform.clone().requires_grad_(True)
     c.full_proj_transform = pose @ c.projection_matrix
     assert camera_requires_grad(c)
+
+
+def test_strand_model_modules_export_the_reference_class_names():
+    """R:src/scene/__init__.py:17-19 / gaussian_renderer/__init__.py:17 / train_strands.py:21 / train_latent_strands.py:21
+    import GaussianModelCurves from scene.gaussian_model_strands and GaussianModelHair from
+    scene.gaussian_model_latent_strands (and both from `scene`): the drop-in package answers to the same names."""
+    from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelCurves, GaussianModelStrands
+    from gaussianhaircut_amd.scene.gaussian_model_latent_strands import GaussianModelHair
+    from gaussianhaircut_amd import scene
+    assert GaussianModelCurves is GaussianModelStrands and issubclass(GaussianModelHair, GaussianModelStrands)
+    assert scene.GaussianModelCurves is GaussianModelCurves and scene.GaussianModelHair is GaussianModelHair
+    assert scene.GaussianModel.__name__ == "GaussianModel"

@@ -97,6 +97,13 @@ def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None):
     if shard is not None:
         o = model.optimizer
         out["stale"] = o._moment_shards is not None
+        if o.moments_stale():  # a lone checkpoint call must fail loudly, not start the collective (optim.StaleMomentsError)
+            from gaussianhaircut_amd.optim import StaleMomentsError
+            try:
+                o.state_dict()
+                out["lone_state_dict"] = "returned"
+            except StaleMomentsError:
+                out["lone_state_dict"] = "raised"
         o.sync_moments()
         out.update(params=o.flat_param.cpu().numpy(), m=o.exp_avg.cpu().numpy(), v=o.exp_avg_sq.cpu().numpy(),
                    n_calls=len(calls), state=model.optimizer.state_dict()["state"][0]["exp_avg"].cpu().numpy())
@@ -176,6 +183,8 @@ def test_sharded_adam_equals_the_replicated_update_bit_for_bit_on_two_ranks():
         for k in ("params", "m", "v", "state"):
             np.testing.assert_array_equal(res[0][k], res[1][k], err_msg=k)
         assert res[0]["stale"] == shard   # sharded: the other rank's slices of the moments were stale until synced
+        if shard:
+            assert res[0]["lone_state_dict"] == "raised" and res[1]["lone_state_dict"] == "raised"
         runs[shard] = res[0]
     for k in ("params", "m", "v", "state"):
         np.testing.assert_array_equal(runs[True][k], runs[False][k], err_msg="sharded vs replicated: " + k)
