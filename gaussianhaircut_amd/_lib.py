@@ -23,7 +23,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 NUM_CHANNELS = 10
 GRAD_STRIDE = 16
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 15  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 16  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -93,7 +93,8 @@ class ModelArgs(ctypes.Structure):
                [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "conic_eps")] + \
                [("debug", ctypes.c_int32), ("mode", ctypes.c_int32), ("row0", ctypes.c_int32),
                 ("dir3d", ctypes.c_void_p)] + \
-               [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")]
+               [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")] + \
+               [("img_ws_recycled", ctypes.c_int32)]
 
 
 class LossArgs(ctypes.Structure):
@@ -105,7 +106,11 @@ class LossArgs(ctypes.Structure):
                [("unmasked_colours", ctypes.c_int32), ("gt_stats", ctypes.c_void_p)]
 
 
-LOSS_SUMS = 1288  # GHR_LOSS_SUMS
+
+
+def loss_sums_floats(W: int, H: int) -> int:
+    """floats of the loss kernels' ``sums`` scratch for a W x H image (``ghr_loss_sums_floats``)."""
+    return int(lib().ghr_loss_sums_floats(int(W), int(H)))
 
 
 class WsView(ctypes.Structure):
@@ -118,7 +123,7 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
+           "ghr_model_backward_segment", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range"]
 
 _lib = None
@@ -154,6 +159,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_selftest_wave.argtypes = [vp, vp, vp]
     L.ghr_selftest_math.argtypes = [vp, i32, vp, vp]
     L.ghr_model_forward_stage1.argtypes = [vp, ctypes.POINTER(ModelArgs), vp, vp, vp, vp, vp]
+    L.ghr_loss_sums_floats.argtypes = [i32, i32]
+    L.ghr_loss_sums_floats.restype = ctypes.c_size_t
     L.ghr_loss_forward.argtypes = [vp, ctypes.POINTER(LossArgs), vp, vp, vp]
     L.ghr_loss_gt_stats.argtypes = [vp, ctypes.POINTER(LossArgs), vp]
     L.ghr_loss_backward.argtypes = [vp, ctypes.POINTER(LossArgs)] + [vp] * 9

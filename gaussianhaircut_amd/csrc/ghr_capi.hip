@@ -408,7 +408,8 @@ int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t row
     Geom g; Img im;
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
-    if (first) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    // (a recycled workspace -- ghr_model_args.img_ws_recycled -- has its counters at zero already: k_tile_sort left them there)
+    if (first && !m->img_ws_recycled) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
     // rows between the end of this segment and the next multiple of 256 are padding: culled, no gradient slots
     const int end = a.row0 + a.P;
     const int pad_end = (int)std::min<long long>((long long)n_blocks(end) * GHR_BLOCK, rows_total);
@@ -532,16 +533,23 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
 }
 
 namespace ghr {
-__global__ void k_loss_finalize(const float* sums, float w_l1, float w_ssim, float w_mask, float w_orient, float n_pix,
-                                float* aux, float* out)
+// One 256-thread workgroup folds the n_slots x 5 partial sums the forward kernel's workgroups stored (ghr_loss.h): thread t
+// takes the slots t, t + 256, ... in double, then a butterfly inside each wave and the four wave totals in order -- a fixed
+// order, so the loss value does not depend on how the forward kernel was scheduled.
+__global__ void __launch_bounds__(256) k_loss_finalize(const float* slots, uint32_t n_slots, float w_l1, float w_ssim,
+                                                       float w_mask, float w_orient, float n_pix, float* aux, float* out)
 {
-    // one wave: lane l folds slots l, l+64, ... in double, then a butterfly over the 64 lanes
+    __shared__ double s_part[4][GHR_LOSS_TERMS];
     double s[GHR_LOSS_TERMS] = {0, 0, 0, 0, 0};
-    for (int i = threadIdx.x; i < GHR_LOSS_SLOTS; i += 64)
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += sums[GHR_LOSS_TERMS * i + k];
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 256)
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += slots[GHR_LOSS_TERMS * (size_t)i + k];
     for (int off = 32; off >= 1; off >>= 1)
         for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += __shfl_xor(s[k], off);
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) s_part[threadIdx.x >> 6][k] = s[k];
+    __syncthreads();
     if (threadIdx.x == 0) {
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
         float lo = 0.f, bad = 0.f;
         if (w_orient != 0.f) {
             lo = (float)(s[3] / s[4]);
@@ -584,6 +592,14 @@ static bool loss_vec_ok(const ghr_loss_args* l, const void* p0 = nullptr, const 
     return true;
 }
 
+size_t ghr_loss_sums_floats(int32_t W, int32_t H)
+{
+    if (W <= 0 || H <= 0) return 0;
+    // the larger of the two kernel forms' slot counts (marching form at its shortest segment, GHR_LM_ROWS rows)
+    const size_t n = std::max(ghr::loss_slots_tile(W, H), ghr::loss_slots_march(W, H, GHR_LM_ROWS));
+    return GHR_LOSS_AUX + GHR_LOSS_TERMS * n;
+}
+
 int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* sums, float* loss_out)
 {
     if (!l || l->W <= 0 || l->H <= 0 || !l->image || !l->mask || !l->gt_image || !l->gt_mask || !maps || !sums || !loss_out)
@@ -592,10 +608,10 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
     if (orient && (!l->dir2d || !l->orient_conf || !l->gt_orient_angle || !l->gt_orient_conf))
         return fail(GHR_E_INVALID, "ghr_loss_forward: w_orient != 0 needs dir2d / orient_conf / gt_orient_angle / gt_orient_conf");
     hipStream_t s = (hipStream_t)stream;
-    GHR_HIP(hipMemsetAsync(sums, 0, GHR_LOSS_SUMS * sizeof(float), s));
+    // sums = {aux[GHR_LOSS_AUX] | one slot of five partial sums per workgroup of the forward kernel}: nothing to zero
     ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
-                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums, l->gt_stats, nullptr,
-                    loss_march_seg(l, false)};
+                    l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums + GHR_LOSS_AUX, l->gt_stats,
+                    nullptr, loss_march_seg(l, false)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
     const bool vec = loss_vec_ok(l, maps);
     const dim3 grid_v = loss_march_grid(l, a.seg);
@@ -606,9 +622,9 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
         if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_v, grid_v, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
     }
-    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(64), 0, s, sums, l->w_l1, l->w_ssim, l->w_mask,
-                       orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
-                       loss_out);
+    const size_t n_slots = vec ? ghr::loss_slots_march(l->W, l->H, a.seg) : ghr::loss_slots_tile(l->W, l->H);
+    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(256), 0, s, sums + GHR_LOSS_AUX, (uint32_t)n_slots, l->w_l1,
+                       l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums, loss_out);
     return finish(s, 0);
 }
 
@@ -638,7 +654,7 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
     hipStream_t s = (hipStream_t)stream;
     ghr::LossBwdArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image,
                        l->gt_mask, l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps,
-                       sums + GHR_LOSS_TERMS * GHR_LOSS_SLOTS,
+                       sums,  // aux: {sum of the orientation weights, NaN flag} (k_loss_finalize)
                        grad_loss, l->w_l1, l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, d_image, d_mask, d_dir2d,
                        d_orient_conf, zero_plane_a, zero_plane_b, loss_march_seg(l, true)};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
@@ -736,6 +752,7 @@ int ghr_set_profile_events(void* fwd_start, void* fwd_stop, void* bwd_start, voi
 // kernel-experiment builds only (not declared in include/ghr.h): per-wave phase cycles of the instrumented K8
 int ghr_debug_prof(unsigned long long* out, int n_slots, int reset)
 {
+    if (n_slots < 0 || n_slots > GHR_PROF_SLOTS) return GHR_E_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return GHR_E_HIP;
     if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(ghr::g_k8_prof), 64 * (size_t)n_slots) != hipSuccess) return GHR_E_HIP;
     if (reset) {
@@ -747,6 +764,7 @@ int ghr_debug_prof(unsigned long long* out, int n_slots, int reset)
 }
 int ghr_debug_timeline(unsigned long long* out, int n_slots)
 {
+    if (!out || n_slots < 0 || n_slots > GHR_PROF_SLOTS) return GHR_E_INVALID;
     if (hipDeviceSynchronize() != hipSuccess) return GHR_E_HIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ghr::g_k8_tl), 16 * (size_t)n_slots) != hipSuccess) return GHR_E_HIP;
     return GHR_OK;

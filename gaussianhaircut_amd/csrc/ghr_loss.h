@@ -25,8 +25,14 @@ namespace ghr {
 #define GHR_SSIM_R 5
 #define GHR_SSIM_T 16
 #define GHR_SSIM_E (GHR_SSIM_T + 2 * GHR_SSIM_R)  // 26
-#define GHR_LOSS_SLOTS 256
 #define GHR_LOSS_TERMS 5  // partial sums per slot: |image-gt|*m, ssim_map, |mask-gt_mask|, orient num, orient den
+#define GHR_LOSS_AUX 8    // floats in front of the slots: {sum of the orientation weights, orientation-term-is-NaN flag, pad}
+// Every workgroup of a forward kernel (tile form: a 32 x 16 tile of one channel; marching form: one wave = a strip segment of
+// one channel) owns ONE slot of five partial sums and stores it (round 5; until then the workgroups added into 256 shared
+// slots with atomics, which needed a zero-fill launch in front of every forward pass): nothing to initialise, and the fold
+// in k_loss_finalize has a fixed order -- the loss value is the same bits run after run.
+GHR_HD size_t loss_slots_tile(int W, int H) { return (size_t)3 * ((W + 31) / 32) * ((H + 15) / 16); }
+GHR_HD size_t loss_slots_march(int W, int H, int seg) { return (size_t)3 * ((W + 31) / 32) * ((H + seg - 1) / seg); }
 
 __device__ __constant__ float c_ssim_w[11] = {1.028380124e-03f, 7.598758209e-03f, 3.600077331e-02f, 1.093606874e-01f,
                                              2.130055279e-01f, 2.660117149e-01f, 2.130055279e-01f, 1.093606874e-01f,
@@ -63,8 +69,7 @@ struct LossArgs {
     const float* gt_oconf;  // [1,H,W] per-pixel weight of the orientation term
     int mask_colours;       // 0: colour terms on the whole image (strand stage)
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
-    float* sums;            // [GHR_LOSS_SLOTS][GHR_LOSS_TERMS] partial sums, zeroed by the caller; block b adds into
-                            // slot b % SLOTS (one hot address would serialise ~73k atomics)
+    float* sums;            // [n workgroups][GHR_LOSS_TERMS] partial sums, one slot per workgroup (plain stores)
     const float* gt_stats;  // [2][3][H*W] window moments of the masked ground truth (mu2, E[y^2]) or NULL
     float* stats_out;       // k_loss_gt_stats: where those moments go
     int seg;                // marching kernels: rows of a strip per wave (a multiple of GHR_LM_ROWS)
@@ -296,15 +301,10 @@ __device__ __forceinline__ void loss_fwd_body(const LossArgs& a)
         }
     }
     block_sum_n<5>(sums, s_red);
-    if (tid == 0) {
-        const unsigned slot = (blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 97u) % GHR_LOSS_SLOTS;
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 0], sums[0]);
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 1], sums[1]);
-        if (ch < 2) atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 2], sums[2]);
-        if (orient) {
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 3], sums[3]);
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 4], sums[4]);
-        }
+    if (tid == 0) {  // (sums[2] is 0 in the third channel's blocks, sums[3], sums[4] without the orientation term)
+        float* dst = a.sums + GHR_LOSS_TERMS * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z));
+#pragma unroll
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[k] = sums[k];
     }
 #endif
 }
@@ -799,15 +799,10 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
     if (MODE == 2) return;
 #pragma unroll
     for (int k = 0; k < 5; k++) sums[k] = wave_sum(sums[k]);
-    if (lane == 0) {
-        const unsigned slot = ((unsigned)sx + blockIdx.y * gridDim.x + (unsigned)ch * 97u) % GHR_LOSS_SLOTS;
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 0], sums[0]);
-        atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 1], sums[1]);
-        if (!CH2) atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 2], sums[2]);
-        if (orient) {
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 3], sums[3]);
-            atomicAdd(&a.sums[GHR_LOSS_TERMS * slot + 4], sums[4]);
-        }
+    if (lane == 0) {  // this wave's slot: strip sx (< nst: the grid's padding strips have returned), segment, channel
+        float* dst = a.sums + GHR_LOSS_TERMS * ((size_t)sx + (size_t)nst * (blockIdx.y + (size_t)gridDim.y * (unsigned)ch));
+#pragma unroll
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[k] = sums[k];
     }
 #endif
 }

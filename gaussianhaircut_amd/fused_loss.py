@@ -66,7 +66,7 @@ class _Stage1LossPacked(torch.autograd.Function):
         dev = renders.device
         with torch.cuda.device(dev):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
-            sums = torch.empty(_lib.LOSS_SUMS, dtype=torch.float32, device=dev)
+            sums = torch.empty(_lib.loss_sums_floats(W, H), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             if gt_stats is not None:
                 assert gt_stats.shape == (2, 3, H, W) and gt_stats.is_contiguous() and gt_stats.dtype == torch.float32
@@ -107,7 +107,7 @@ class _PhotometricLoss(torch.autograd.Function):
         dev = image.device
         with torch.cuda.device(dev):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
-            sums = torch.empty(_lib.LOSS_SUMS, dtype=torch.float32, device=dev)
+            sums = torch.empty(_lib.loss_sums_floats(W, H), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
             a = _args(W, H, _ptr(image_c), _ptr(mask_c), None, None, gt_image_c, gt_mask_c, None, None,
                       (w_l1, w_ssim, w_mask, 0.0))

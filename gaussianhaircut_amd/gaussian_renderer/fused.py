@@ -16,6 +16,40 @@ from .. import _lib
 from . import _tan_half
 from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
 
+RECYCLE_IMG_WS = os.environ.get("GHR_RECYCLE_IMG_WS", "1") != "0"  # see _ImgLease
+
+
+class _ImgLease:
+    """The image workspace of one fused forward pass, recycled between passes of the same size on the same stream.
+
+    Stage 1 counts instances per tile into the workspace's counters and needs them at zero: for a fresh buffer that is a
+    ~5-us zero-fill launch in front of every view.  A workspace that has been through a whole forward pass has its counters
+    back at zero (``k_tile_scan`` turns the counts into append cursors starting at 0, stage 2's tile sort resets them), so a
+    pass that gets such a buffer says so (``ghr_model_args.img_ws_recycled``) and the launch is dropped.  The lease lives
+    in the autograd node: the buffer goes back to the pool when the graph is freed (after backward, or when the outputs
+    go out of scope; a retained graph keeps it), and only if stage 2 was launched.  Pools are per (device, size, stream):
+    the next pass on the same stream is ordered behind everything that still reads the buffer."""
+    _pools = {}
+    MAX_POOLED = 4
+
+    def __init__(self, dev, nbytes):
+        self.key = (dev.index, int(nbytes), torch.cuda.current_stream(dev).cuda_stream)
+        pool = _ImgLease._pools.get(self.key)
+        if pool:
+            self.buf, self.recycled = pool.pop(), True
+        else:
+            self.buf, self.recycled = torch.empty((nbytes,), dtype=torch.uint8, device=dev), False
+        self.complete = False  # set once stage 2 has been launched on this buffer
+
+    def __del__(self):
+        try:
+            if self.complete and self.buf is not None:
+                pool = _ImgLease._pools.setdefault(self.key, [])
+                if len(pool) < _ImgLease.MAX_POOLED:
+                    pool.append(self.buf)
+        except Exception:  # interpreter shutdown
+            pass
+
 
 def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug):
     m = _lib.ModelArgs()
@@ -47,9 +81,11 @@ class _RenderModelFused(torch.autograd.Function):
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             gbytes, ibytes = _lib.forward_sizes(P, W, H, False)
             geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
-            img = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
+            lease = _ImgLease(dev, ibytes) if RECYCLE_IMG_WS else None
+            img = lease.buf if lease is not None else torch.empty((ibytes,), dtype=torch.uint8, device=dev)
             m = _model_args(P, W, H, cfg["sh_degree"], K, params, view, proj, campos, bg, cfg["scale_modifier"],
                             cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+            m.img_ws_recycled = int(lease is not None and lease.recycled)
             pinned = _pinned(dev)
             _lib.check(L.ghr_model_forward_stage1(_stream(), ctypes.byref(m), _ptr(geom), _ptr(img), _ptr(radii),
                                                   _ptr(screenspace_points.detach()), ctypes.c_void_p(pinned.data_ptr())))
@@ -72,6 +108,9 @@ class _RenderModelFused(torch.autograd.Function):
 
             # speculative (see diff_gaussian_rasterization.run_stage2); with cfg["defer_count"] R is a PendingCount
             R, cap, (binb, ctx.scratch) = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
+            if lease is not None:
+                lease.complete = True  # stage 2 has been launched: the counters end up at zero again
+                ctx.img_lease = lease  # (lives as long as the graph: the backward pass reads the workspace)
         cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
         ctx.scratch_clean = ctx.scratch is not None  # zeroed under stage 2's tile sort, untouched since

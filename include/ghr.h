@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 15
+#define GHR_ABI_VERSION 16
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -166,6 +166,11 @@ typedef struct ghr_model_args {
     int32_t row0;
     const float* dir3d;           /* [P,3] or NULL */
     float const_opacity, const_label, const_conf;
+    /* ABI 16.  != 0: img_ws is the image workspace of an EARLIER forward pass of the same W x H whose stage 1 AND stage 2 were
+     * both launched, ordered before this call on the stream (or through events), and which nobody has written since.  Its
+     * per-tile counters are then back at zero -- k_tile_scan turns the counts into append cursors starting at 0 and stage 2's
+     * tile sort resets every cursor -- so stage 1 does not launch its zero-fill (one ~5-us launch per view).  0: any buffer. */
+    int32_t img_ws_recycled;
 } ghr_model_args;
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
@@ -234,9 +239,11 @@ typedef struct ghr_loss_args {
                                      ghr_loss_gt_stats -- constants of a training view; with them ghr_loss_forward
                                      convolves three moments instead of five, with bit-identical results */
 } ghr_loss_args;
-/* maps: 9*H*W floats of scratch kept for backward.  sums: GHR_LOSS_SUMS device floats of scratch kept for backward.
- * loss_out: device scalar. */
-#define GHR_LOSS_SUMS 1288 /* 256 slots x 5 partial sums + {sum of orientation weights, NaN flag} + pad */
+/* maps: 9*H*W floats of scratch kept for backward.  sums: ghr_loss_sums_floats(W, H) device floats of scratch kept for
+ * backward -- {sum of orientation weights, NaN flag, pad} + one slot of five partial sums per workgroup of the forward kernel;
+ * needs no initialisation (ABI 16: the 256 shared slots of earlier versions were zero-filled by a launch of their own in front
+ * of every forward pass; with a slot per workgroup the fold also has a fixed order).  loss_out: device scalar. */
+size_t ghr_loss_sums_floats(int32_t W, int32_t H);
 int ghr_loss_forward(void* stream, const ghr_loss_args* a, float* maps, float* sums, float* loss_out);
 /* stats_out [2,3,H,W] = {w * y, w * y^2} per colour channel, y = gt_image (* gt_mask[1] unless unmasked_colours), w the
  * 11x11 window of loss_utils.py:91-121.  Reads only W, H, gt_image, gt_mask, unmasked_colours of `a`. */

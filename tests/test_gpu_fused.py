@@ -707,3 +707,46 @@ def test_deferred_gradient_zeroing_is_invisible_or_loud():
     finally:
         tr.DEFER_GRAD_ZEROING = True
         _lib.lib().ghr_set_deterministic(0)
+
+
+def test_recycled_image_workspace_skips_the_zero_fill_and_changes_nothing():
+    """Round 5: a fused forward pass that gets the image workspace of an earlier, completed pass back from the pool
+    (gaussian_renderer/fused.py _ImgLease) tells stage 1 so (ghr_model_args.img_ws_recycled) and the per-tile counters'
+    zero-fill launch is dropped -- k_tile_scan / the tile sort left them at zero.  Images, radii and instance counts of
+    three passes in a row (different cameras, so different counts per tile) must equal the fresh-buffer path's bit for
+    bit, and the second and third pass must really have run on a recycled buffer."""
+    from gaussianhaircut_amd.gaussian_renderer import fused
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    cams = ring_cameras(3, spec.W, spec.H, device=dev)
+    outs = {}
+    for recycle in (False, True):
+        fused.RECYCLE_IMG_WS = recycle
+        fused._ImgLease._pools.clear()
+        model = _model(spec, dev, 2)
+        got = []
+        seen = []
+        orig = fused._ImgLease.__init__
+
+        def spy(self, d, n, _orig=orig, _seen=seen):
+            _orig(self, d, n)
+            _seen.append(self.recycled)
+        fused._ImgLease.__init__ = spy
+        try:
+            for cam in cams:
+                pkg = render(cam, model, FUSED, syn.background(dev))
+                (pkg["render"].sum() + pkg["mask"].sum()).backward()
+                got.append((pkg["render"].detach().clone(), pkg["radii"].clone(), model._xyz.grad.detach().clone()))
+                del pkg  # the graph is gone: the lease returns its buffer
+        finally:
+            fused._ImgLease.__init__ = orig
+        outs[recycle] = got
+        if recycle:
+            assert seen == [False, True, True], seen
+        torch.cuda.synchronize()
+    fused.RECYCLE_IMG_WS = True
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        # (the gradient walk's atomics are unordered: same sums, last-bit differences between any two runs)
+        assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7 * float(a[2].abs().max()))

@@ -4,7 +4,7 @@
 # Rejected kernel forms and their ablation knobs do not live in the product headers: they are patches under
 # tools/experiments/ (e.g. r03_experiment_knobs_of_the_render_loss_adam_kernels.patch brings back -DGHR_B3_NOARITH,
 # -DGHR_B3_NOATOM, -DGHR_K7_HALVES, ...).  -p applies a patch to a scratch copy of csrc/ + include/ before compiling.
-set -e
+set -e -o pipefail
 R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 S=$R/build/variants/src_$name
@@ -16,8 +16,12 @@ flags=()
 while [ $# -gt 0 ]; do
   if [ "$1" = "-p" ]; then (cd $S && patch -s -p1 < "$(cd $R && realpath "$2")"); shift 2; else flags+=("$1"); shift; fi
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared \
-  -I$S/include -I$S/gaussianhaircut_amd/csrc "${flags[@]}" $S/gaussianhaircut_amd/csrc/ghr_capi.hip \
-  -o $R/build/variants/libghr_$name.so 2>&1 | grep -E "error|spill" || true
+# (a failed compile must not leave a stale libghr_<name>.so behind to be measured as if it were the new variant)
+out=$R/build/variants/libghr_$name.so
+rm -f $out
+log=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -munsafe-fp-atomics -fPIC -shared \
+  -I$S/include -I$S/gaussianhaircut_amd/csrc "${flags[@]}" $S/gaussianhaircut_amd/csrc/ghr_capi.hip -o $out 2>&1) || rc=$?
+echo "$log" | grep -E "error|spill" || true
 rm -rf $S
-echo built $R/build/variants/libghr_$name.so
+if [ -n "${rc:-}" ] || [ ! -s $out ]; then echo "build_variant: hipcc FAILED for $name (rc=${rc:-0})" >&2; exit 1; fi
+echo built $out
