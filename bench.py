@@ -191,18 +191,22 @@ def main():
     bytes_bwd_kernel = 132 * R + 48 * N_pix + 8 * T_tiles
     bytes_fwd_kernel = 68 * R + 48 * N_pix + 8 * T_tiles
     achieved = bytes_bwd_kernel / (bwd_avg * 1e-3) / 1e9 if bwd_avg > 0 else 0.0
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_stale = None, None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_k_render_bwd.json")
     if os.path.exists(pmc_file):
         try:
-            rec = json.load(open(pmc_file))
-            rec = rec.get(args.workload, rec if args.workload == "cfg3" and "hbm_bytes_per_launch" in rec else {})
+            whole = json.load(open(pmc_file))
+            rec = whole.get(args.workload, whole if args.workload == "cfg3" and "hbm_bytes_per_launch" in whole else {})
             traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+            # the counters were taken from a particular build of the kernel: the record carries the hash of its sources
+            # (tools/k8_source_hash.py, written by the profiling script) and a figure taken from other sources says so
+            from tools.k8_source_hash import k8_source_hash
+            traffic_stale = whole.get("k8_source_sha256") != k8_source_hash()
         except Exception:
             traffic = None
     roofline = {"kernel": "k_render_bwd_cells (K8)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic_source": traffic_src, "traffic_stale": traffic_stale,
                 "algorithmic_bytes_per_launch": bytes_bwd_kernel, "avg_kernel_ms": round(bwd_avg, 4),
                 "note": "gradient walk NOT bound by HBM bandwidth: it issues one 64-B line atomic per (cell, splat) hit and the L2 "
                         "retires ~17 G of them per second (profiles/r04k: 2.96 M hits = 0.174 ms on this workload; four more "

@@ -33,7 +33,14 @@ SO_STRICT = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref_strict.so")
 
 def _load(path):
     if not os.path.exists(path):
-        pytest.skip("%s is not built (needs /root/reference at build time)" % os.path.relpath(path, hp.ROOT))
+        msg = "%s is not built (needs /root/reference at build time)" % os.path.relpath(path, hp.ROOT)
+        # In THIS repository the library is always there on a GPU box: build() makes it in the build container (which has
+        # /root/reference) and the built file travels with the tree.  Its absence would silently drop the whole live matrix
+        # with the run still green -- so where the recipe exists it is a FAILURE.  A third party that runs the suite without
+        # the reference sources sets GHR_ALLOW_MISSING_REF=1.
+        if os.path.exists(os.path.join(hp.ROOT, "oracle", "Makefile.ref")) and not os.environ.get("GHR_ALLOW_MISSING_REF"):
+            pytest.fail(msg + "; run __graft_entry__.build() where /root/reference exists, or set GHR_ALLOW_MISSING_REF=1")
+        pytest.skip(msg)
     import gaussianhaircut_amd._lib as _lib
     _lib.lib()  # torch's HIP runtime and the product first: every HIP-linked library shares one runtime
     L = ctypes.CDLL(path)
@@ -182,13 +189,14 @@ def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
     # ---- K7.  The pixel means of the two builds differ by up to 2 ulp (2.4e-4 px), alpha of a splat therefore by up to
     # ~1e-3 relative -- beyond the 2e-5 margin of the oracle's `fragile` flag (which covers exp rounding only): on a few pixels
     # one splat passes alpha >= 1/255 in one build and not in the other, or the stop test falls one entry later.  Those
-    # pixels are COUNTED (<= 2 % of the frame: measured 1.3 % for cfg3's one-pixel-wide strands, whose conics are the
+    # pixels are COUNTED (<= 1.6 % of the frame: measured 1.3 % for cfg3's one-pixel-wide strands, whose conics are the
     # steepest, 0.01 % for cfg2's blobs), their error BOUNDED by two such splats (alpha <= 1.02/255 each, times the
     # largest feature / background value), and they leave the gradient comparison on both sides.
     nc, nc_ref = ins["n_contrib"][ok], ref["st_n_contrib"].view(np.uint32)[ok]
     a, b = run.out.cpu().numpy().reshape(10, -1)[:, ok], ref["out_color"].reshape(10, -1)[:, ok]
     off = (nc != nc_ref) | ~hp.image_close(ins["final_T"][ok], ref["st_final_T"][ok]) | ~hp.image_close(a, b).all(axis=0)
-    assert off.mean() <= 2e-2, "%d of %d unmasked pixels decide a splat differently" % (off.sum(), off.size)
+    # (bound = the largest measured value, 1.3 % on cfg3, plus a margin: a regression must show -- VERDICT r4 next #6)
+    assert off.mean() <= 1.6e-2, "%d of %d unmasked pixels decide a splat differently" % (off.sum(), off.size)
     vmax = max(float(ri["colors"].abs().max()), float(ri["bg"].abs().max()))
     same_walk = off & (nc == nc_ref)
     if same_walk.any():
@@ -202,7 +210,7 @@ def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
     # Gradients: the two sides' INPUTS to K8 differ in the last bits (pixel means), and T <- T / (1 - alpha) amplifies a
     # relative difference in alpha by alpha / (1 - alpha) (x 99 at the clamp): a handful of rows sit a few 1e-4 of the row
     # apart although both are right (the strict build, same inputs, agrees to the bar on EVERY element); dL/dmean2D of a
-    # one-pixel-wide strand moves by ~dx / sigma^2 = 8e-4 relative for a 2-ulp dx.  Counted and bounded: at most 1 % of a
+    # one-pixel-wide strand moves by ~dx / sigma^2 = 8e-4 relative for a 2-ulp dx.  Counted and bounded: at most 0.5 % of a
     # tensor's elements beyond the bar of tests/helpers.py (measured: 5 of 2.9e5 for cfg2's blobs, 0.35 % of dL/dmean2D for
     # cfg3's strands), none beyond 100 x the bar.
     keep = ~flipped
@@ -213,7 +221,7 @@ def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
         ok_el = hp.grad_close(a, b)
         n_bad = int((~ok_el).sum())
         worst[k] = n_bad
-        assert n_bad <= max(2, int(1e-2 * ok_el.size)), (k, n_bad, ok_el.size)
+        assert n_bad <= max(2, int(5e-3 * ok_el.size)), (k, n_bad, ok_el.size)  # measured <= 0.35 % (dL/dmean2D, cfg3)
         assert hp.grad_close(a, b, tol=100 * hp.TOL, floor=100 * hp.GRAD_FLOOR).all(), k
     print("live, default build: gradient elements beyond the bar:", worst, flush=True)
     print("live, default build: %d K1 flips, %.1f %% of the depth keys one ulp apart, %d swapped list positions in %d tiles, "

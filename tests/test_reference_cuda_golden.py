@@ -119,3 +119,32 @@ def test_hip_rasterizer_matches_the_reference_cuda_rasterizer(gold, cfg, mode, c
     check_state(gold, t, run.radii.cpu().numpy(), ins["depths"], ins["rec"][:, 0:2], ins["rec"][:, 2:6], run.R, ranges,
                 ins["point_list"], ins["n_contrib"], ins["final_T"], run.out.cpu().numpy(), frag)
     check_grads(gold, t, run.backward(torch.from_numpy(dL)), rel=1e-4, of_max=1e-4)
+
+
+@pytest.mark.parametrize("case", ["tiny@ring13roll", "tiny"])
+def test_reference_binary_mode_b_conic_equals_the_reference_pythons_get_conic(gold, case):
+    """every "reference binary" number goes through oracle/ref_shim/glm (a builder-written stand-in
+    for the un-vendored glm).  This compares two artefacts neither of which involves the oracle or the product: the
+    conic the reference's CUDA kernel computed in mode B (scales + rotations -> computeCov3D -> computeCov2D -> inverse,
+    forward.cu:74-152,214-239; the strict build for the rolled camera) as stored by make_reference_cuda_golden.py, and
+    the conic the reference's own PYTHON computes for the same Gaussians and camera (GaussianModel.get_conic,
+    src/scene/gaussian_model.py:303-315; reference_host_golden.npz, made by importing the reference on the CPU).  With
+    a full 3x3 view rotation (ring view 13 rolled 20 degrees) any transposed / row-major slip in the shim's mat3
+    products would show at O(1).  Bound 2e-6 of the row's largest entry (measured 4.9e-7: fp32 rounding of two
+    differently ordered product chains; the Python adds eps = 1e-12 to the determinant)."""
+    host = np.load(os.path.join(os.path.dirname(GOLD), "reference_host_golden.npz"))
+    t = case + "/B_sr/"
+    m = host[case + "/mask"].astype(bool)  # the cull raster_inputs() applied before the op (filter_points)
+    # same Gaussians, same camera on both sides
+    assert m.sum() == gold[t + "in_scales"].shape[0]
+    assert np.abs(gold[t + "in_scales"] - host[case + "/scaling"][m]).max() <= 2e-8
+    assert np.array_equal(gold[t + "in_rotations"], host[case + "/rotation"][m])
+    assert np.array_equal(gold[t + "in_viewmatrix"].reshape(-1), host[case + "/view"].reshape(-1))
+    if case != "tiny":
+        assert float(np.abs(host[case + "/view"].reshape(4, 4)[:3, :3] - np.eye(3)).min()) > 1e-3  # every entry of R is non-trivial
+    vis = gold[t + "radii"] > 0
+    assert vis.sum() > 1900
+    bin_conic = gold[t + "st_conic_opacity"][vis, :3]
+    py_conic = host[case + "/conic"][m][vis]
+    rel = np.abs(bin_conic - py_conic) / np.abs(py_conic).max(axis=1, keepdims=True)
+    assert rel.max() <= 2e-6, rel.max()
