@@ -27,7 +27,8 @@ from tests import helpers as hp
 
 pytestmark = pytest.mark.gpu
 
-# default build through rotated cameras: share of a gradient tensor's elements that may sit beyond the bar (see _compare_default)
+# default build through rotated cameras: share of a gradient tensor's elements that may sit beyond the bar (see _compare_default).
+# Measured (round 5, cfg3 @ ring13roll, the worst case): dL/dopacity 0.80 %, dL/dmean2D 0.35 %, dL/dconic 0.13 %; cfg2: <= 9 elements.
 GRAD_OFF_BOUND = 1e-2
 SO = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref.so")
 SO_STRICT = os.path.join(hp.ROOT, "oracle", "_ref", "libghr_ref_strict.so")
