@@ -266,28 +266,36 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         const int t1 = (y0 + ky) * gx + x0 + kx;
         kx += 4;
         while (on1 && kx >= w) { kx -= w; ky++; }
+#ifdef GHR_PROBE_SCATTER_NOATOM  // timing probe (WRONG RESULTS): positions without atomics -- the kernel's streaming floor
+        const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
+        const uint32_t p0 = min(s0 + (uint32_t)(idx & 7), cap - 1u), p1 = min(s1 + (uint32_t)(idx & 7), cap - 1u);
+#else
         int lead0, lead1;
         const uint32_t b0 = wave_inc_issue(tile_cursor, (uint32_t)t0, on0, lead0);
         const uint32_t b1 = wave_inc_issue(tile_cursor, (uint32_t)t1, on1, lead1);
         const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
         const uint32_t p0 = s0 + wave_inc_result(b0, lead0), p1 = s1 + wave_inc_result(b1, lead1);
+#endif
         if (on0 && p0 < cap) keys[p0] = key;  // cap: see ghr_forward_stage2
         if (on1 && p1 < cap) keys[p1] = key;
     }
-    // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- take it from row 0
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(big) & 0xffffull;
-    while (todo) {  // wave-uniform
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bw = __shfl(w, src), bn = __shfl(full, src);
-        const uint32_t klo = (uint32_t)__shfl((int)(uint32_t)key, src), khi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
-        const uint64_t bkey = ((uint64_t)khi << 32) | klo;
-        for (int k = lane; k < bn; k += 64) {
-            const int by = k / bw;
-            const int t = (by0 + by) * gx + bx0 + (k - by * bw);
-            const uint32_t pos = tile_start[t] + atomicAdd(&tile_cursor[t], 1u);
-            if (pos < cap) keys[pos] = bkey;
-        }
+    // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- row 0 speaks for it; the workgroup's big
+    // rects are expanded together, load-balanced (BigRects), two instances per thread and trip so that their returning
+    // atomics are in flight together
+    __shared__ BigRects s_big;
+    const uint32_t total = big_rects_setup(s_big, (big && q == 0) ? (uint32_t)full : 0u, x0, y0, w, (uint32_t)key,
+                                           (uint32_t)(key >> 32));
+    for (uint32_t j = threadIdx.x; j < total; j += 2 * GHR_BLOCK) {
+        const uint32_t j1 = j + GHR_BLOCK;
+        const bool on1 = j1 < total;
+        uint32_t o0, o1;
+        const uint32_t t0 = big_rect_instance(s_big, j, gx, o0), t1 = big_rect_instance(s_big, on1 ? j1 : j, gx, o1);
+        const uint32_t c0 = atomicAdd(&tile_cursor[t0], 1u);
+        uint32_t c1 = 0u;
+        if (on1) c1 = atomicAdd(&tile_cursor[t1], 1u);
+        const uint32_t p0 = tile_start[t0] + c0, p1 = tile_start[t1] + c1;
+        if (p0 < cap) keys[p0] = ((uint64_t)s_big.khi[o0] << 32) | s_big.klo[o0];
+        if (on1 && p1 < cap) keys[p1] = ((uint64_t)s_big.khi[o1] << 32) | s_big.klo[o1];
     }
 #endif
 }

@@ -258,6 +258,55 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t n, uint32_t* s_
     return before + incl - n;
 }
 
+// Big rects (more than GHR_BIG_RECT tiles) of a 256-thread workgroup, LOAD-BALANCED (round 5): the workgroup scans their
+// areas and every thread takes the instances j = tid, tid + 256, ... of the concatenation -- owner by binary search over the
+// scanned offsets, tile from the ordinal inside the owner's rect -- so a workgroup with a handful of 20 x 20-tile splats
+// spends total / 256 steps per thread, all of them independent, instead of walking the rects one after the other with one
+// wave each (cfg2, 100k blobs of 10.6 tiles on average: k_preprocess 40 us for 380 workgroups; the per-wave walk had
+// replaced a per-LANE walk that was 3x slower still).  Shared by the tile counting (K1) and the scatter.
+struct BigRects {
+    uint32_t off[GHR_BLOCK + 1];  // exclusive prefix of the big rects' areas in thread order; off[256] = total
+    uint32_t xy[GHR_BLOCK];       // x0 | y0 << 16
+    uint32_t w[GHR_BLOCK];        // rect width in tiles
+    uint32_t klo[GHR_BLOCK], khi[GHR_BLOCK];  // (scatter) the owner's 64-bit key
+    uint32_t tmp[4];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t n, uint32_t* s_tmp, uint32_t* total);
+// Every thread of the workgroup calls it with its own rect (area 0: not a big rect).  Returns the total number of instances;
+// afterwards (total > 0) thread-independent lookups big_rect_instance(j) are valid until the next barrier-separated reuse.
+__device__ __forceinline__ uint32_t big_rects_setup(BigRects& s, uint32_t area, int x0, int y0, int w, uint32_t klo = 0u,
+                                                   uint32_t khi = 0u)
+{
+    uint32_t total;
+    const uint32_t off = block_excl_scan_256(area, s.tmp, &total);
+    if (total == 0u) return 0u;  // (workgroup-uniform)
+    const int tid = threadIdx.x;
+    s.off[tid] = off;
+    s.xy[tid] = (uint32_t)x0 | ((uint32_t)y0 << 16);
+    s.w[tid] = (uint32_t)w;
+    s.klo[tid] = klo;
+    s.khi[tid] = khi;
+    if (tid == 0) s.off[GHR_BLOCK] = total;
+    __syncthreads();
+    return total;
+}
+// instance j of the concatenation: its owner thread (the last one whose offset is <= j: it has a non-empty rect) and tile
+__device__ __forceinline__ uint32_t big_rect_instance(const BigRects& s, uint32_t j, int gx, uint32_t& owner)
+{
+    uint32_t lo = 0u, hi = GHR_BLOCK;  // off[lo] <= j < off[hi]
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s.off[mid] <= j) lo = mid; else hi = mid;
+    }
+    owner = lo;
+    const uint32_t ord = j - s.off[lo], w = s.w[lo], xy = s.xy[lo];
+    const uint32_t ky = ord / w, kx = ord - ky * w;
+    return ((xy >> 16) + ky) * (uint32_t)gx + (xy & 0xffffu) + kx;
+}
+#endif
+
 // Run-aggregated atomicAdd(&counter[t], 1) for every lane with `active`: a run of ADJACENT lanes that target the same
 // counter issues ONE atomic (strand Gaussians that are neighbours in memory are neighbours on screen: a wave's 64
 // increments collapse to a handful; incoherent inputs degrade to one atomic per lane plus ~15 VALU).  Returns the value

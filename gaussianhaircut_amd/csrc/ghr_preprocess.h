@@ -161,9 +161,11 @@ GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1,
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// tile_count[t] += 1 for every tile of every lane's rect (empty rect: x1 == x0), run-aggregated (wave_inc).  Lanes walk
-// their k-th tile in lockstep, so neighbouring Gaussians with equal rects merge perfectly.  All lanes of the wave call it.
-__device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1)
+// tile_count[t] += 1 for every tile of every thread's rect (empty rect: x1 == x0).  Rects of up to GHR_BIG_RECT tiles:
+// run-aggregated (wave_inc) -- lanes walk their k-th tile in lockstep, so neighbouring Gaussians with equal rects merge
+// perfectly.  Larger ones: load-balanced over the workgroup (BigRects).  EVERY thread of the 256-thread workgroup calls it;
+// `s` is workgroup scratch nobody else touches between the barrier in front of the call and the end of the kernel.
+__device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1, BigRects& s)
 {
     const int w = x1 - x0, full = w * (y1 - y0);
     const bool big = full > GHR_BIG_RECT;
@@ -172,21 +174,32 @@ __device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
     int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
+#ifdef GHR_PROBE_K1_RETURNING  // timing probe: the counting atomics RETURN (all of a lane's up to 8 in flight, then collected)
+    uint32_t pb[GHR_BIG_RECT];
+    int pl[GHR_BIG_RECT];
+#pragma unroll
+    for (int k = 0; k < GHR_BIG_RECT; k++) {
+        pb[k] = 0u; pl[k] = 0;
+        if (k < max_area) {  // wave-uniform
+            pb[k] = wave_inc_issue(tile_count, (uint32_t)t, k < area, pl[k]);
+            if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+        }
+    }
+    uint32_t acc_ = 0u;
+#pragma unroll
+    for (int k = 0; k < GHR_BIG_RECT; k++)
+        if (k < max_area) acc_ += wave_inc_result(pb[k], pl[k]);
+    if (acc_ == 0xdeadbeefu) tile_count[0] = acc_;  // keep the results alive
+#else
     for (int k = 0; k < max_area; k++) {
         wave_inc(tile_count, (uint32_t)t, k < area, false);
         if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
     }
-    // big rects (GHR_BIG_RECT): one at a time, 64 distinct tiles per step
-    const int lane = threadIdx.x & 63;
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(big);
-    while (todo) {  // wave-uniform
-        const int src = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const int bx0 = __shfl(x0, src), by0 = __shfl(y0, src), bw = __shfl(w, src), bn = __shfl(full, src);
-        for (int k = lane; k < bn; k += 64) {
-            const int ky = k / bw;
-            atomicAdd(&tile_count[(by0 + ky) * gx + bx0 + (k - ky * bw)], 1u);
-        }
+#endif
+    const uint32_t total = big_rects_setup(s, big ? (uint32_t)full : 0u, x0, y0, w);
+    for (uint32_t j = threadIdx.x; j < total; j += GHR_BLOCK) {
+        uint32_t owner;
+        atomicAdd(&tile_count[big_rect_instance(s, j, gx, owner)], 1u);
     }
 }
 #endif
@@ -197,6 +210,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
     const int idx = blockIdx.x * GHR_BLOCK + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     __shared__ uint32_t s_scan[4];
+    __shared__ BigRects s_big;
     const bool ok = idx < a.P && preprocess_one(a, idx, x0, y0, x1, y1);
     uint32_t blk_total;
     const uint32_t base = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
@@ -204,7 +218,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
     if (threadIdx.x == 0) a.slot_blk[blockIdx.x] = blk_total;
     // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
     // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
-    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
+    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1, s_big);
 #endif
 }
 

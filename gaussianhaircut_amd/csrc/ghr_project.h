@@ -676,7 +676,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
             if (j < 4 * nb) dst[j] = s_rec[j];
         }
     }
-    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1);
+    __syncthreads();  // the record stores have read the staging area: it now serves the big rects' expansion
+    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1, *reinterpret_cast<BigRects*>(s_rest));
 #endif
 }
 
