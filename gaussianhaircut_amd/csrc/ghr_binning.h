@@ -266,16 +266,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         const int t1 = (y0 + ky) * gx + x0 + kx;
         kx += 4;
         while (on1 && kx >= w) { kx -= w; ky++; }
-#ifdef GHR_PROBE_SCATTER_NOATOM  // timing probe (WRONG RESULTS): positions without atomics -- the kernel's streaming floor
-        const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
-        const uint32_t p0 = min(s0 + (uint32_t)(idx & 7), cap - 1u), p1 = min(s1 + (uint32_t)(idx & 7), cap - 1u);
-#else
         int lead0, lead1;
         const uint32_t b0 = wave_inc_issue(tile_cursor, (uint32_t)t0, on0, lead0);
         const uint32_t b1 = wave_inc_issue(tile_cursor, (uint32_t)t1, on1, lead1);
         const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
         const uint32_t p0 = s0 + wave_inc_result(b0, lead0), p1 = s1 + wave_inc_result(b1, lead1);
-#endif
         if (on0 && p0 < cap) keys[p0] = key;  // cap: see ghr_forward_stage2
         if (on1 && p1 < cap) keys[p1] = key;
     }

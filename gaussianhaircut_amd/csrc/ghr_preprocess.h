@@ -174,28 +174,10 @@ __device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
     int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
-#ifdef GHR_PROBE_K1_RETURNING  // timing probe: the counting atomics RETURN (all of a lane's up to 8 in flight, then collected)
-    uint32_t pb[GHR_BIG_RECT];
-    int pl[GHR_BIG_RECT];
-#pragma unroll
-    for (int k = 0; k < GHR_BIG_RECT; k++) {
-        pb[k] = 0u; pl[k] = 0;
-        if (k < max_area) {  // wave-uniform
-            pb[k] = wave_inc_issue(tile_count, (uint32_t)t, k < area, pl[k]);
-            if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
-        }
-    }
-    uint32_t acc_ = 0u;
-#pragma unroll
-    for (int k = 0; k < GHR_BIG_RECT; k++)
-        if (k < max_area) acc_ += wave_inc_result(pb[k], pl[k]);
-    if (acc_ == 0xdeadbeefu) tile_count[0] = acc_;  // keep the results alive
-#else
     for (int k = 0; k < max_area; k++) {
         wave_inc(tile_count, (uint32_t)t, k < area, false);
         if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
     }
-#endif
     const uint32_t total = big_rects_setup(s, big ? (uint32_t)full : 0u, x0, y0, w);
     for (uint32_t j = threadIdx.x; j < total; j += GHR_BLOCK) {
         uint32_t owner;
