@@ -68,9 +68,9 @@ __device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* ds
 }
 #endif
 
-// tile_count[T] -> tile_start[T+1] (exclusive scan; tile_count is reset to 0 so k_scatter can reuse it as the per-tile
-// append cursor; publishes R = tile_start[T]) and, in place, slot_blk[nblk] -> exclusive prefix of the gradient slots
-// used by the K1 workgroups.
+// tile_count[2][T] -> tile_start[T+1] (exclusive scan of small + big) and small_cnt[T] (the small rects' counts: their
+// instances already have their places, k_scatter appends the big rects' behind them); both planes are reset to 0 -- the second
+// one becomes k_scatter's append cursors; publishes R = tile_start[T]) and, in place, slot_blk[nblk] -> exclusive prefix of the gradient slots used by the K1 workgroups.
 // Also leaves tile_order[xcd_grid(T)] (round 3): the tile each workgroup of the tile sort and of K7 takes (K8 balances its
 // cells inside a tile and gains nothing: measured, MI355X, cfg3 / cfg5 / cfg2: K7 0.115 -> 0.100 / 0.320 -> 0.276 /
 // 0.131 -> 0.124 ms, K8 0.190 -> 0.189 / 0.499 -> 0.485 / 0.310 -> 0.313 ms; single-view step 0.930 -> 0.909 ms).
@@ -80,9 +80,9 @@ __device__ __forceinline__ uint32_t scan_1024(int n, uint32_t* src, uint32_t* ds
 // tools/cellstats/schedule_sim.py puts the launch at 1.16x (cfg3) / 1.10x (cfg2) of perfect packing, heaviest-first per
 // XCD at 1.09x / 1.04x.  The order inside a class comes from LDS atomics: it changes which workgroup takes a tile, never
 // a result.  Padding workgroups get 0xffffffff.
-__global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* tile_start,
-                                                              uint32_t* R_out, uint32_t* slot_blk, int nblk,
-                                                              uint32_t* R_mapped, uint32_t* tile_order)
+__global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* tile_count, uint32_t* small_cnt,
+                                                              uint32_t* tile_start, uint32_t* R_out, uint32_t* slot_blk,
+                                                              int nblk, uint32_t* R_mapped, uint32_t* tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     // One workgroup, latency-bound: everything a thread needs is requested in ONE round trip (8 consecutive counts as two
@@ -131,17 +131,34 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
     uint32_t c[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};  // (kept past the loop: the order below takes a single round's counts from here)
     for (uint32_t base = 0; base < (uint32_t)T; base += 8u * GHR_SCAN_BLOCK) {
         const uint32_t t0 = base + 8u * (uint32_t)tid;
-        if (t0 + 8u <= (uint32_t)T) {  // (tile_count / tile_start are 256-B aligned sub-allocations: 32-B accesses)
+        // two planes: [0] the small rects' instances (their positions are already handed out; the counts move to small_cnt:
+        // k_scatter appends the big rects' instances behind them), [1] the big rects'.  Both planes go back to 0: [1] serves
+        // as k_scatter's append cursors, and a workspace whose counters are at zero can be recycled without a zero-fill
+        uint32_t* big_count = tile_count + T;
+        if ((T & 3) == 0 && t0 + 8u <= (uint32_t)T) {  // (256-B aligned sub-allocations, T a multiple of 4: 16-B accesses)
             const uint4 a = *reinterpret_cast<const uint4*>(tile_count + t0), b = *reinterpret_cast<const uint4*>(tile_count + t0 + 4);
-            c[0] = a.x; c[1] = a.y; c[2] = a.z; c[3] = a.w; c[4] = b.x; c[5] = b.y; c[6] = b.z; c[7] = b.w;
-            const uint4 z = {0u, 0u, 0u, 0u};   // the counts become k_scatter's append cursors
+            const uint4 a2 = *reinterpret_cast<const uint4*>(big_count + t0), b2 = *reinterpret_cast<const uint4*>(big_count + t0 + 4);
+            c[0] = a.x + a2.x; c[1] = a.y + a2.y; c[2] = a.z + a2.z; c[3] = a.w + a2.w;
+            c[4] = b.x + b2.x; c[5] = b.y + b2.y; c[6] = b.z + b2.z; c[7] = b.w + b2.w;
+            const uint4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<uint4*>(small_cnt + t0) = a;
+            *reinterpret_cast<uint4*>(small_cnt + t0 + 4) = b;
             *reinterpret_cast<uint4*>(tile_count + t0) = z;
             *reinterpret_cast<uint4*>(tile_count + t0 + 4) = z;
+            *reinterpret_cast<uint4*>(big_count + t0) = z;
+            *reinterpret_cast<uint4*>(big_count + t0 + 4) = z;
         } else {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                c[i] = t0 + i < (uint32_t)T ? tile_count[t0 + i] : 0u;
-                if (t0 + i < (uint32_t)T) tile_count[t0 + i] = 0u;
+                if (t0 + i < (uint32_t)T) {
+                    const uint32_t cs = tile_count[t0 + i];
+                    c[i] = cs + big_count[t0 + i];
+                    small_cnt[t0 + i] = cs;
+                    tile_count[t0 + i] = 0u;
+                    big_count[t0 + i] = 0u;
+                } else {
+                    c[i] = 0u;
+                }
             }
         }
         uint32_t sum = 0u;
@@ -226,57 +243,49 @@ __global__ void __launch_bounds__(GHR_SCAN_BLOCK) k_tile_scan(int T, uint32_t* t
 __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rects,
                                                        const uint32_t* __restrict__ slot_blk,
                                                        const float* __restrict__ depths,
-                                                       const uint32_t* __restrict__ tile_start, uint32_t* tile_cursor,
-                                                       uint64_t* keys, uint32_t cap)
+                                                       const uint32_t* __restrict__ tile_start, uint32_t* tile_count,
+                                                       uint32_t T, const uint32_t* __restrict__ small_cnt,
+                                                       const uint32_t* __restrict__ pos, uint64_t* keys, uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // A wavefront serves 16 Gaussians: lane = 16*q + i handles the rect ordinals q, q+4, q+8, ... of Gaussian i
-    // (4x shorter chains of returning atomics and 4x more waves in flight than one thread per Gaussian), while lanes
-    // that are neighbours within a 16-lane row still hold neighbouring Gaussians at the SAME ordinal, so equal tiles
-    // of strand neighbours share one atomic (wave_inc).
+    // A wavefront serves 16 Gaussians: lane = 16*q + i handles the rect ordinals q, q+4 of Gaussian i.  Small rects (up to
+    // GHR_BIG_RECT = 8 tiles): the instance's place in its tile's list was handed out by K1's counting atomic (count_tiles:
+    // pos[i][ordinal]) -- one gather of tile_start, one 8-B store, no atomic (round 5).
     const int lane = threadIdx.x & 63, q = lane >> 4;
     const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 16) + (lane & 15);
     rect4 r = rect4{0u, 0u, 0u, 0u};
-    uint32_t sb = 0u;
+    uint32_t sb = 0u, pq0 = 0u, pq1 = 0u;
     float dep = 0.f;
-    if (idx < P) {  // (the three loads together: one round trip, not three -- the depth used to sit under its own branch)
+    if (idx < P) {  // (all the loads together: one round trip; the two positions of a culled / big rect are never used)
         r = rects[idx];
         sb = slot_blk[idx >> 8];
         dep = depths[idx];
+        pq0 = pos[(size_t)GHR_BIG_RECT * idx + q];
+        pq1 = pos[(size_t)GHR_BIG_RECT * idx + q + 4];
     }
     if (idx < P && q == 0) rects[idx].w = sb;  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
     const int w = x1 - x0, full = (x1 > x0 && y1 > y0) ? w * (y1 - y0) : 0;
-    const bool big = full > GHR_BIG_RECT;  // walked by the whole wave below
+    const bool big = full > GHR_BIG_RECT;  // expanded by the whole workgroup below
     const int area = big ? 0 : full;
     const uint64_t key = full ? (((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx) : 0ull;
-    int max_area = area;
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));  // same in all 4 rows
-    // first ordinal q -> (kx, ky); afterwards advance by 4 without a division per step (w >= 1 when area > 0)
-    int ky = area ? q / w : 0, kx = area ? q - ky * w : 0;
-    // Two ordinals per trip (all there are below GHR_BIG_RECT = 8 tiles): both returning atomics and both tile_start loads
-    // are in flight together -- the kernel was this chain of dependent round trips, one per ordinal (round 5)
-    for (int k = q; k - q < max_area; k += 8) {
-        const bool on0 = k < area;
-        const int t0 = (y0 + ky) * gx + x0 + kx;
-        kx += 4;
-        while (on0 && kx >= w) { kx -= w; ky++; }
-        const bool on1 = k + 4 < area;
-        const int t1 = (y0 + ky) * gx + x0 + kx;
-        kx += 4;
-        while (on1 && kx >= w) { kx -= w; ky++; }
-        int lead0, lead1;
-        const uint32_t b0 = wave_inc_issue(tile_cursor, (uint32_t)t0, on0, lead0);
-        const uint32_t b1 = wave_inc_issue(tile_cursor, (uint32_t)t1, on1, lead1);
+    static_assert(GHR_BIG_RECT == 8, "two ordinals per lane: q and q + 4");
+    {
+        // ordinal k -> tile (row-major inside the rect, as count_tiles walks it); w >= 1 when area > 0
+        const bool on0 = q < area, on1 = q + 4 < area;
+        const int ky0 = on0 ? q / w : 0, kx0 = q - ky0 * w;
+        const int ky1 = on1 ? (q + 4) / w : 0, kx1 = q + 4 - ky1 * w;
+        const int t0 = (y0 + ky0) * gx + x0 + kx0, t1 = (y0 + ky1) * gx + x0 + kx1;
         const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
-        const uint32_t p0 = s0 + wave_inc_result(b0, lead0), p1 = s1 + wave_inc_result(b1, lead1);
+        const uint32_t p0 = s0 + pq0, p1 = s1 + pq1;
         if (on0 && p0 < cap) keys[p0] = key;  // cap: see ghr_forward_stage2
         if (on1 && p1 < cap) keys[p1] = key;
     }
     // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- row 0 speaks for it; the workgroup's big
     // rects are expanded together, load-balanced (BigRects), two instances per thread and trip so that their returning
-    // atomics are in flight together
+    // atomics are in flight together.  They go BEHIND the tile's small-rect instances: small_cnt[t] of those, then the
+    // append cursor (the second plane of tile_count, at 0 on entry: k_tile_scan / the tile sort leave it there)
+    uint32_t* cursor = tile_count + T;
     __shared__ BigRects s_big;
     const uint32_t total = big_rects_setup(s_big, (big && q == 0) ? (uint32_t)full : 0u, x0, y0, w, (uint32_t)key,
                                            (uint32_t)(key >> 32));
@@ -285,10 +294,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         const bool on1 = j1 < total;
         uint32_t o0, o1;
         const uint32_t t0 = big_rect_instance(s_big, j, gx, o0), t1 = big_rect_instance(s_big, on1 ? j1 : j, gx, o1);
-        const uint32_t c0 = atomicAdd(&tile_cursor[t0], 1u);
+        const uint32_t c0 = atomicAdd(&cursor[t0], 1u);
         uint32_t c1 = 0u;
-        if (on1) c1 = atomicAdd(&tile_cursor[t1], 1u);
-        const uint32_t p0 = tile_start[t0] + c0, p1 = tile_start[t1] + c1;
+        if (on1) c1 = atomicAdd(&cursor[t1], 1u);
+        const uint32_t p0 = tile_start[t0] + small_cnt[t0] + c0, p1 = tile_start[t1] + small_cnt[t1] + c1;
         if (p0 < cap) keys[p0] = ((uint64_t)s_big.khi[o0] << 32) | s_big.klo[o0];
         if (on1 && p1 < cap) keys[p1] = ((uint64_t)s_big.khi[o1] << 32) | s_big.klo[o1];
     }
@@ -367,8 +376,9 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;
     const int tid = threadIdx.x;
-    // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may
-    // be replayed, e.g. after a too small speculative capacity)
+    // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may be
+    // replayed, e.g. after a too small speculative capacity) and a forward pass of its image workspace (a recycled one skips
+    // its zero-fill)
     // The tile's gradient lines are its n consecutive lines from s (they lie in list order): when the caller hands the
     // backward pass's scratch over, they are zeroed here, under the sort's LDS round trips where the memory pipe is idle
     // (the backward render kernel then starts accumulating at once: -10 % of its time inside the step).
@@ -377,9 +387,10 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
                              // (same call: K8 190.9 -> 189.4 us, loss forward 69.2 -> 66.2, step 0.857 -> 0.850 ms)
         for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
     }
-    const bool sorted_already = tile_cursor[tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
+    // (tile_cursor = tile_count[2][T]: [0] is back at 0 since k_tile_scan, [1] the big rects' append cursors / the DONE mark)
+    const bool sorted_already = tile_cursor[T + tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
     __syncthreads();
-    if (tid == 0) tile_cursor[tile] = 0u;
+    if (tid == 0) tile_cursor[T + tile] = 0u;
     if (n == 0 || sorted_already) return;
     uint64_t* g = keys + s;
     if (n <= GHR_SORT_CAP) {
@@ -489,7 +500,7 @@ __global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T
         __syncthreads();
         for (uint32_t i = tid; i < n; i += GHR_SORT_BIG_BLOCK)
             sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], (int)(tile % (uint32_t)gx), (int)(tile / (uint32_t)gx), cap);
-        if (tid == 0) tile_cursor[tile] = GHR_SORT_DONE;
+        if (tid == 0) tile_cursor[T + tile] = GHR_SORT_DONE;
     }
 #endif
 }

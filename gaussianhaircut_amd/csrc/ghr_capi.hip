@@ -113,13 +113,15 @@ struct Geom {
     float* depths;
     ghr::rect4* rects;
     uint32_t* slot_blk;  // [ceil(P/256)]
+    uint32_t* pos;       // [P][GHR_BIG_RECT]: place of each small-rect instance in its tile's list (count_tiles)
     float* cov3D;
 };
 struct Img {
     float* final_T;
     uint32_t* n_contrib;
-    uint32_t* tile_count;  // [T]: per-tile instance count, then append cursor
+    uint32_t* tile_count;  // [2][T]: per-tile instance counts of the small / the big rects; [1] then the big rects' append cursors
     uint32_t* tile_start;  // [T+1]
+    uint32_t* small_cnt;   // [T]: instances of small rects per tile (k_tile_scan; k_scatter appends the big rects' behind them)
     uint32_t* R_dev;
     uint32_t* cell_last;   // [16 T]: largest n_contrib of each 4x4-pixel cell
     uint32_t* tile_order;  // [xcd_grid(T)]: tile of each workgroup of the per-tile kernels (k_tile_scan: heaviest first)
@@ -139,8 +141,9 @@ size_t carve_geom(char* base, size_t P, bool mode_b, Geom* g)
     float* depths = (float*)take(P * 4);
     ghr::rect4* rects = (ghr::rect4*)take(P * 16);
     uint32_t* slot_blk = (uint32_t*)take(((P + GHR_BLOCK - 1) / GHR_BLOCK) * 4);
+    uint32_t* pos = (uint32_t*)take(P * 4 * GHR_BIG_RECT);
     float* cov3D = mode_b ? (float*)take(P * 24) : nullptr;
-    if (g) *g = Geom{rec, depths, rects, slot_blk, cov3D};
+    if (g) *g = Geom{rec, depths, rects, slot_blk, pos, cov3D};
     return off + ALIGN;
 }
 size_t carve_img(char* base, size_t N, size_t T, Img* im)
@@ -149,12 +152,13 @@ size_t carve_img(char* base, size_t N, size_t T, Img* im)
     auto take = [&](size_t bytes) { char* p = base ? base + off : nullptr; off += up(bytes); return p; };
     float* final_T = (float*)take(N * 4);
     uint32_t* n_contrib = (uint32_t*)take(N * 4);
-    uint32_t* tile_count = (uint32_t*)take(T * 4);
+    uint32_t* tile_count = (uint32_t*)take(2 * T * 4);
     uint32_t* tile_start = (uint32_t*)take((T + 1) * 4);
+    uint32_t* small_cnt = (uint32_t*)take(T * 4);
     uint32_t* R_dev = (uint32_t*)take(4);
     uint32_t* cell_last = (uint32_t*)take(T * 16 * 4);
     uint32_t* tile_order = (uint32_t*)take((size_t)ghr::xcd_grid((uint32_t)T) * 4);
-    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, R_dev, cell_last, tile_order};
+    if (im) *im = Img{final_T, n_contrib, tile_count, tile_start, small_cnt, R_dev, cell_last, tile_order};
     return off + ALIGN;
 }
 size_t carve_bin(char* base, size_t R, size_t T, Bin* b)
@@ -239,7 +243,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
 
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
     ghr::PreArgs pa;
     pa.P = a->P; pa.W = a->W; pa.H = a->H; pa.gx = gx; pa.gy = gy;
     pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;
@@ -250,10 +254,10 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     pa.focal_y = a->H / (2.0f * a->tan_fovy);  // rasterizer_impl.cu:224-225
     pa.focal_x = a->W / (2.0f * a->tan_fovx);
     pa.rec = g.rec; pa.depths = g.depths; pa.rects = g.rects; pa.cov3D = g.cov3D; pa.radii = radii;
-    pa.tile_count = im.tile_count; pa.slot_blk = g.slot_blk;
+    pa.tile_count = im.tile_count; pa.slot_blk = g.slot_blk; pa.pos = g.pos;
     hipLaunchKernelGGL(ghr::k_preprocess, dim3((a->P + GHR_BLOCK - 1) / GHR_BLOCK), dim3(GHR_BLOCK), 0, s, pa);
     uint32_t* R_mapped = mapped_word(R_host);
-    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.small_cnt, im.tile_start, im.R_dev,
                        g.slot_blk, (a->P + GHR_BLOCK - 1) / GHR_BLOCK, R_mapped, im.tile_order);
     if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, a->debug);
@@ -285,7 +289,7 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     if (R > 0) {
         // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
         hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
-                           g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, b.keys, R);
+                           g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, (uint32_t)T, im.small_cnt, g.pos, b.keys, R);
         // dense scenes (long lists on average) first get their dense tiles sorted in big LDS blocks; the regular kernel
         // then passes those by.  R is the capacity here, an upper bound of the count: a guess that is too high only
         // costs an idle 3-us launch.
@@ -389,7 +393,7 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     a->focal_x = m->W / (2.0f * m->tan_fovx);
     a->conic_eps = m->conic_eps;
     a->rec = nullptr; a->depths = nullptr; a->rects = nullptr; a->radii = nullptr; a->means2D = nullptr;
-    a->tile_count = nullptr; a->slot_blk = nullptr;
+    a->tile_count = nullptr; a->slot_blk = nullptr; a->pos = nullptr;
     return GHR_OK;
 }
 inline int n_blocks(int rows) { return (rows + GHR_BLOCK - 1) / GHR_BLOCK; }
@@ -409,7 +413,7 @@ int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t row
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
     // (a recycled workspace -- ghr_model_args.img_ws_recycled -- has its counters at zero already: k_tile_sort left them there)
-    if (first && !m->img_ws_recycled) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * (size_t)T, s));
+    if (first && !m->img_ws_recycled) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
     // rows between the end of this segment and the next multiple of 256 are padding: culled, no gradient slots
     const int end = a.row0 + a.P;
     const int pad_end = (int)std::min<long long>((long long)n_blocks(end) * GHR_BLOCK, rows_total);
@@ -419,7 +423,7 @@ int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t row
     }
     if (a.P == 0) return finish(s, m->debug);
     a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
-    a.tile_count = im.tile_count; a.slot_blk = g.slot_blk;
+    a.tile_count = im.tile_count; a.slot_blk = g.slot_blk; a.pos = g.pos;
     hipLaunchKernelGGL(ghr::k_project, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a);
     return finish(s, m->debug);
 }
@@ -437,7 +441,7 @@ int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     carve_img(align_base(img_ws), (size_t)W * H, (size_t)T, &im);
     uint32_t* R_mapped = mapped_word(R_host);
-    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.tile_start, im.R_dev,
+    hipLaunchKernelGGL(ghr::k_tile_scan, dim3(1), dim3(GHR_SCAN_BLOCK), 0, s, T, im.tile_count, im.small_cnt, im.tile_start, im.R_dev,
                        g.slot_blk, n_blocks(rows_total), R_mapped, im.tile_order);
     if (!R_mapped) GHR_HIP(hipMemcpyAsync(R_host, im.R_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     return finish(s, debug);

@@ -26,8 +26,9 @@ struct PreArgs {
     rect4* rects;
     float* cov3D;  // mode B only
     int* radii;
-    uint32_t* tile_count;  // [T] per-tile instance counts
+    uint32_t* tile_count;  // [2][T] per-tile instance counts: of the small rects (positions handed out), of the big ones
     uint32_t* slot_blk;    // [ceil(P/256)] gradient slots used by each K1 workgroup (scanned by k_tile_scan)
+    uint32_t* pos;         // [P][GHR_BIG_RECT] position of each small-rect instance inside its tile's list (see count_tiles)
 };
 
 // forward.cu:118-152.  The quaternion is used as given (normalisation is commented out at :127).
@@ -161,27 +162,57 @@ GHR_HD bool preprocess_one(const PreArgs& a, int idx, int& x0, int& y0, int& x1,
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// tile_count[t] += 1 for every tile of every thread's rect (empty rect: x1 == x0).  Rects of up to GHR_BIG_RECT tiles:
-// run-aggregated (wave_inc) -- lanes walk their k-th tile in lockstep, so neighbouring Gaussians with equal rects merge
-// perfectly.  Larger ones: load-balanced over the workgroup (BigRects).  EVERY thread of the 256-thread workgroup calls it;
-// `s` is workgroup scratch nobody else touches between the barrier in front of the call and the end of the kernel.
-__device__ __forceinline__ void count_tiles(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1, BigRects& s)
+// Counts every tile of every thread's rect (empty rect: x1 == x0) -- and, since round 5, HANDS OUT the instance's place in
+// its tile's list at the same time: the counting atomic of a small rect (up to GHR_BIG_RECT tiles) returns the count before
+// it, which IS a unique position among the tile's small-rect instances (the list is sorted afterwards: any unique
+// position will do), stored in pos_row[ordinal].  k_scatter then places those instances without an atomic of its own
+// (it used to repeat the 1.3 M atomics, returning ones, on the append cursors: throughput-bound, profiles/r05j).
+// Small rects: run-aggregated (wave_inc_issue / _result) -- lanes walk their k-th tile in lockstep, so neighbouring
+// Gaussians with equal rects share one atomic; all of a lane's up to 8 atomics are in flight before the first result is used.
+// Big rects: counted into the SECOND plane (tile_count + T), load-balanced over the workgroup (BigRects); k_scatter appends
+// them behind the small ones with cursors of their own.  EVERY thread of the 256-thread workgroup calls both halves; `s` is
+// workgroup scratch nobody else touches between the barrier in front of count_tiles_finish and the end of the kernel.
+// (in two halves, so that a kernel can do its stores between sending the atomics and needing their results)
+struct TileCountPending {
+    uint32_t pb[GHR_BIG_RECT];
+    int pl[GHR_BIG_RECT];
+    int max_area, area;
+};
+__device__ __forceinline__ void count_tiles_issue(uint32_t* tile_count, int gx, int x0, int y0, int x1, int y1, TileCountPending& c)
 {
     const int w = x1 - x0, full = w * (y1 - y0);
     const bool big = full > GHR_BIG_RECT;
-    const int area = big ? 0 : full;
-    int max_area = area;
+    c.area = big ? 0 : full;
+    int max_area = c.area;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) max_area = max(max_area, __shfl_xor(max_area, off));
+    c.max_area = max_area;
     int kx = 0, t = y0 * gx + x0;  // row-major walk over the rect without a division per step
-    for (int k = 0; k < max_area; k++) {
-        wave_inc(tile_count, (uint32_t)t, k < area, false);
-        if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+#pragma unroll
+    for (int k = 0; k < GHR_BIG_RECT; k++) {
+        c.pb[k] = 0u; c.pl[k] = 0;
+        if (k < max_area) {  // wave-uniform
+            c.pb[k] = wave_inc_issue(tile_count, (uint32_t)t, k < c.area, c.pl[k]);
+            if (++kx == w) { kx = 0; t += gx - w + 1; } else t++;
+        }
     }
-    const uint32_t total = big_rects_setup(s, big ? (uint32_t)full : 0u, x0, y0, w);
+}
+__device__ __forceinline__ void count_tiles_finish(uint32_t* tile_count, uint32_t T, int gx, int x0, int y0, int x1, int y1,
+                                                   BigRects& s, uint32_t* pos_row, const TileCountPending& c)
+{
+    uint32_t pv[GHR_BIG_RECT];
+#pragma unroll
+    for (int k = 0; k < GHR_BIG_RECT; k++) pv[k] = k < c.max_area ? wave_inc_result(c.pb[k], c.pl[k]) : 0u;
+    // (two 16-B stores per Gaussian -- the row is 32 B, 32-B aligned -- instead of one 4-B store per ordinal; the slots past
+    // the rect's area hold nothing anybody reads)
+    static_assert(GHR_BIG_RECT == 8, "pos rows are two uint4");
+    if (c.area > 0) reinterpret_cast<uint4*>(pos_row)[0] = uint4{pv[0], pv[1], pv[2], pv[3]};
+    if (c.area > 4) reinterpret_cast<uint4*>(pos_row)[1] = uint4{pv[4], pv[5], pv[6], pv[7]};
+    const int w = x1 - x0, full = w * (y1 - y0);
+    const uint32_t total = big_rects_setup(s, full > GHR_BIG_RECT ? (uint32_t)full : 0u, x0, y0, w);
     for (uint32_t j = threadIdx.x; j < total; j += GHR_BLOCK) {
         uint32_t owner;
-        atomicAdd(&tile_count[big_rect_instance(s, j, gx, owner)], 1u);
+        atomicAdd(&tile_count[T + big_rect_instance(s, j, gx, owner)], 1u);
     }
 }
 #endif
@@ -194,13 +225,16 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_preprocess(PreArgs a)
     __shared__ uint32_t s_scan[4];
     __shared__ BigRects s_big;
     const bool ok = idx < a.P && preprocess_one(a, idx, x0, y0, x1, y1);
+    // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
+    // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
+    TileCountPending tc;
+    count_tiles_issue(a.tile_count, a.gx, x0, y0, x1, y1, tc);
     uint32_t blk_total;
     const uint32_t base = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
     if (ok) a.rects[idx].z = base;
     if (threadIdx.x == 0) a.slot_blk[blockIdx.x] = blk_total;
-    // Per-tile instance counts (replaces the tiles_touched scan + duplicateWithKeys offsets,
-    // rasterizer_impl.cu:281,88): tile lists are laid out tile-major, so counts are all binning needs.
-    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1, s_big);
+    count_tiles_finish(a.tile_count, (uint32_t)(a.gx * a.gy), a.gx, x0, y0, x1, y1, s_big,
+                       a.pos + (size_t)GHR_BIG_RECT * (idx < a.P ? idx : 0), tc);
 #endif
 }
 

@@ -58,7 +58,8 @@ struct ModelArgs {
     rect4* rects;
     int* radii;
     float* means2D;  // [rows,3] NDC (viewspace_points values), may be null
-    uint32_t* tile_count;  // [T] counts
+    uint32_t* tile_count;  // [2][T] counts (small rects / big rects: count_tiles)
+    uint32_t* pos;         // [rows][GHR_BIG_RECT] list positions of the small-rect instances (count_tiles)
     uint32_t* slot_blk;    // [ceil(rows/256)] gradient slots per workgroup
 };  // rec / depths / rects / radii / means2D / slot_blk are indexed by WORKSPACE ROW (row0 + idx)
 
@@ -646,6 +647,10 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     ProjOut o;
     const bool ok = idx < a.P && project_core(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1, o);
+    // the counting atomics (they hand out the instances' list positions: count_tiles) go out now, their results are needed at
+    // the very end: the round trip runs under the stores below
+    TileCountPending tc;
+    count_tiles_issue(a.tile_count, a.gx, x0, y0, x1, y1, tc);
     __shared__ uint32_t s_scan[4];
     uint32_t blk_total;
     const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
@@ -677,7 +682,8 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
         }
     }
     __syncthreads();  // the record stores have read the staging area: it now serves the big rects' expansion
-    count_tiles(a.tile_count, a.gx, x0, y0, x1, y1, *reinterpret_cast<BigRects*>(s_rest));
+    count_tiles_finish(a.tile_count, (uint32_t)(a.gx * a.gy), a.gx, x0, y0, x1, y1, *reinterpret_cast<BigRects*>(s_rest),
+                       a.pos + (size_t)GHR_BIG_RECT * ((size_t)a.row0 + (idx < a.P ? idx : 0)), tc);
 #endif
 }
 
