@@ -5,7 +5,7 @@ import hashlib
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FILES = ("ghr_render_bwd3.h", "ghr_render_bwd2.h", "ghr_device.h")
+FILES = ("ghr_render_bwd3.h", "ghr_render_bwd2.h")  # the kernel and its wave primitives (ghr_device.h is shared by every kernel)
 
 
 def k8_source_hash() -> str:
