@@ -537,33 +537,57 @@ int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const 
 }
 
 namespace ghr {
-// One 256-thread workgroup folds the n_slots x 5 partial sums the forward kernel's workgroups stored (ghr_loss.h): thread t
-// takes the slots t, t + 256, ... in double, then a butterfly inside each wave and the four wave totals in order -- a fixed
-// order, so the loss value does not depend on how the forward kernel was scheduled.
-__global__ void __launch_bounds__(256) k_loss_finalize(const float* slots, uint32_t n_slots, float w_l1, float w_ssim,
-                                                       float w_mask, float w_orient, float n_pix, float* aux, float* out)
+// One 1024-thread workgroup folds the 5 x n_slots partial sums the forward kernel's workgroups stored (ghr_loss.h; laid out
+// [term][slot]): thread t takes the slots t, t + 1024, ... of every term (all of a round's loads in flight together), a DPP
+// sum inside each wave, and one thread per term adds the sixteen wave totals in double -- a fixed order, so the loss value
+// does not depend on how the forward kernel was scheduled.  (Built for latency: the kernel is a 5-us stop between the loss
+// forward and backward passes; a first form with double-precision butterflies took 12-17 us.)
+__global__ void __launch_bounds__(1024) k_loss_finalize(const float* slots, uint32_t n_slots, float w_l1, float w_ssim,
+                                                        float w_mask, float w_orient, float n_pix, float* aux, float* out)
 {
-    __shared__ double s_part[4][GHR_LOSS_TERMS];
-    double s[GHR_LOSS_TERMS] = {0, 0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < n_slots; i += 256)
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += slots[GHR_LOSS_TERMS * (size_t)i + k];
-    for (int off = 32; off >= 1; off >>= 1)
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] += __shfl_xor(s[k], off);
-    if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) s_part[threadIdx.x >> 6][k] = s[k];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ float s_part[GHR_LOSS_TERMS][16];
+    __shared__ double s_tot[GHR_LOSS_TERMS];
+    float s[GHR_LOSS_TERMS] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (uint32_t base = 0; base < n_slots; base += 8u * 1024u) {
+        float v[GHR_LOSS_TERMS][8];
+#pragma unroll
+        for (int k = 0; k < GHR_LOSS_TERMS; k++)
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = base + 1024u * u + threadIdx.x;
+                v[k][u] = i < n_slots ? slots[(size_t)k * n_slots + i] : 0.f;
+            }
+#pragma unroll
+        for (int k = 0; k < GHR_LOSS_TERMS; k++)
+            s[k] += ((v[k][0] + v[k][1]) + (v[k][2] + v[k][3])) + ((v[k][4] + v[k][5]) + (v[k][6] + v[k][7]));
+    }
+#pragma unroll
+    for (int k = 0; k < GHR_LOSS_TERMS; k++) {
+        const float w = wave_sum(s[k]);
+        if ((threadIdx.x & 63) == 0) s_part[k][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < GHR_LOSS_TERMS) {
+        double t = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) t += (double)s_part[threadIdx.x][w];
+        s_tot[threadIdx.x] = t;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) s[k] = ((s_part[0][k] + s_part[1][k]) + s_part[2][k]) + s_part[3][k];
+        const double s0 = s_tot[0], s1 = s_tot[1], s2 = s_tot[2], s3 = s_tot[3], s4 = s_tot[4];
         float lo = 0.f, bad = 0.f;
         if (w_orient != 0.f) {
-            lo = (float)(s[3] / s[4]);
+            lo = (float)(s3 / s4);
             if (lo != lo) { lo = 0.f; bad = 1.f; }  // train_gaussians.py:134: a NaN orientation loss is dropped
         }
-        aux[0] = (float)s[4];
+        aux[0] = (float)s4;
         aux[1] = bad;
-        out[0] = (float)(w_l1 * (s[0] / (3.0 * n_pix)) + w_ssim * (1.0 - s[1] / (3.0 * n_pix)) + w_mask * (s[2] / (2.0 * n_pix))) +
+        out[0] = (float)(w_l1 * (s0 / (3.0 * n_pix)) + w_ssim * (1.0 - s1 / (3.0 * n_pix)) + w_mask * (s2 / (2.0 * n_pix))) +
                  w_orient * lo;
     }
+#endif
 }
 }  // namespace ghr
 
@@ -615,10 +639,12 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
     // sums = {aux[GHR_LOSS_AUX] | one slot of five partial sums per workgroup of the forward kernel}: nothing to zero
     ghr::LossArgs a{l->W, l->H, l->image, l->mask, orient ? l->dir2d : nullptr, l->orient_conf, l->gt_image, l->gt_mask,
                     l->gt_orient_angle, l->gt_orient_conf, l->unmasked_colours ? 0 : 1, maps, sums + GHR_LOSS_AUX, l->gt_stats,
-                    nullptr, loss_march_seg(l, false)};
+                    nullptr, loss_march_seg(l, false), 0u};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
     const bool vec = loss_vec_ok(l, maps);
     const dim3 grid_v = loss_march_grid(l, a.seg);
+    const size_t n_slots = vec ? ghr::loss_slots_march(l->W, l->H, a.seg) : ghr::loss_slots_tile(l->W, l->H);
+    a.n_slots = (uint32_t)n_slots;
     if (l->gt_stats) {
         if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_cached_v, grid_v, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ghr::k_loss_fwd_cached, grid, dim3(256), 0, s, a);
@@ -626,8 +652,7 @@ int ghr_loss_forward(void* stream, const ghr_loss_args* l, float* maps, float* s
         if (vec) hipLaunchKernelGGL(ghr::k_loss_fwd_v, grid_v, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ghr::k_loss_fwd, grid, dim3(256), 0, s, a);
     }
-    const size_t n_slots = vec ? ghr::loss_slots_march(l->W, l->H, a.seg) : ghr::loss_slots_tile(l->W, l->H);
-    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(256), 0, s, sums + GHR_LOSS_AUX, (uint32_t)n_slots, l->w_l1,
+    hipLaunchKernelGGL(ghr::k_loss_finalize, dim3(1), dim3(1024), 0, s, sums + GHR_LOSS_AUX, (uint32_t)n_slots, l->w_l1,
                        l->w_ssim, l->w_mask, orient ? l->w_orient : 0.f, (float)l->W * (float)l->H, sums, loss_out);
     return finish(s, 0);
 }
@@ -638,7 +663,7 @@ int ghr_loss_gt_stats(void* stream, const ghr_loss_args* l, float* stats_out)
         return fail(GHR_E_INVALID, "ghr_loss_gt_stats: bad args");
     hipStream_t s = (hipStream_t)stream;
     ghr::LossArgs a{l->W, l->H, l->gt_image, nullptr, nullptr, nullptr, l->gt_image, l->gt_mask, nullptr, nullptr,
-                    l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out, loss_march_seg(l, false)};
+                    l->unmasked_colours ? 0 : 1, nullptr, nullptr, nullptr, stats_out, loss_march_seg(l, false), 0u};
     const dim3 grid((l->W + GHR_L_TW - 1) / GHR_L_TW, (l->H + GHR_L_TH - 1) / GHR_L_TH, 3);
     if (loss_vec_ok(l, stats_out)) hipLaunchKernelGGL(ghr::k_loss_gt_stats_v, loss_march_grid(l, a.seg), dim3(64), 0, s, a);
     else hipLaunchKernelGGL(ghr::k_loss_gt_stats, grid, dim3(256), 0, s, a);

@@ -69,10 +69,11 @@ struct LossArgs {
     const float* gt_oconf;  // [1,H,W] per-pixel weight of the orientation term
     int mask_colours;       // 0: colour terms on the whole image (strand stage)
     float* maps;            // [3 kinds][3 ch][H*W]: dm/dmu1, dm/dE[x^2], dm/dE[xy]
-    float* sums;            // [n workgroups][GHR_LOSS_TERMS] partial sums, one slot per workgroup (plain stores)
+    float* sums;            // [GHR_LOSS_TERMS][n_slots] partial sums, one slot per workgroup (plain stores)
     const float* gt_stats;  // [2][3][H*W] window moments of the masked ground truth (mu2, E[y^2]) or NULL
     float* stats_out;       // k_loss_gt_stats: where those moments go
     int seg;                // marching kernels: rows of a strip per wave (a multiple of GHR_LM_ROWS)
+    uint32_t n_slots;       // workgroups of the forward kernel = slots of `sums`, laid out [term][slot]
 };
 
 // Orientation term of ONE pixel (gaussian_renderer/__init__.py:100-105 + loss_utils.py:31-47), value and the partial
@@ -302,9 +303,9 @@ __device__ __forceinline__ void loss_fwd_body(const LossArgs& a)
     }
     block_sum_n<5>(sums, s_red);
     if (tid == 0) {  // (sums[2] is 0 in the third channel's blocks, sums[3], sums[4] without the orientation term)
-        float* dst = a.sums + GHR_LOSS_TERMS * ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z));
+        float* dst = a.sums + ((size_t)blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z));
 #pragma unroll
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[k] = sums[k];
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[(size_t)k * a.n_slots] = sums[k];
     }
 #endif
 }
@@ -800,9 +801,9 @@ __device__ __forceinline__ void loss_fwd_march(const LossArgs& a, float (*s_x)[G
 #pragma unroll
     for (int k = 0; k < 5; k++) sums[k] = wave_sum(sums[k]);
     if (lane == 0) {  // this wave's slot: strip sx (< nst: the grid's padding strips have returned), segment, channel
-        float* dst = a.sums + GHR_LOSS_TERMS * ((size_t)sx + (size_t)nst * (blockIdx.y + (size_t)gridDim.y * (unsigned)ch));
+        float* dst = a.sums + ((size_t)sx + (size_t)nst * (blockIdx.y + (size_t)gridDim.y * (unsigned)ch));
 #pragma unroll
-        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[k] = sums[k];
+        for (int k = 0; k < GHR_LOSS_TERMS; k++) dst[(size_t)k * a.n_slots] = sums[k];
     }
 #endif
 }
