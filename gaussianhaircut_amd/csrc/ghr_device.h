@@ -157,25 +157,29 @@ GHR_HD void gather_inst_grads(const float* ginst, const uint32_t* inst_line, con
     LineAcc A;
     line_acc_init(A);
     // four lines (16 independent 16-B loads) are requested per round trip: the loop is pure memory latency, and one
-    // line per trip cost cnt_max-of-the-wave serialized trips.  Lines past `cnt` are not read and add +0; the sum
-    // order (ascending ordinal) is unchanged.
+    // line per trip cost cnt_max-of-the-wave serialized trips.  Lines past `cnt` add +0; the sum order (ascending ordinal)
+    // is unchanged.  Positions past `cnt` READ the instance's last line again (a cache hit) and drop it: predicated loads
+    // (`in ? p[q] : z`) compiled to one EXEC-masked branch per load with a full vmcnt(0) drain in the middle of the batch --
+    // a third round trip per pass (round 5).
     const f4 z = {0.f, 0.f, 0.f, 0.f};
     uint32_t tx = 0, ty = 0;  // position of the instance's tile inside the rect
-    for (uint32_t k = 0; k < cnt; k += 4) {
+    for (uint32_t k = 0; k < cnt; k += 4) {  // (inside the loop cnt >= 1 and rows >= cnt: line 0 exists)
         uint32_t ln[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t v_ = k + j < cnt ? il[k + j] : 0u;
+            const uint32_t v_ = il[k + j < cnt ? k + j : cnt - 1u];
             ln[j] = v_ < rows ? v_ : 0u;  // (a stale entry after a too small capacity: memory-safe, the result is discarded)
         }
         f4 v[16];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const bool in = k + j < cnt;
             const f4* p = lines + 4 * (size_t)ln[j];
 #pragma unroll
-            for (int q = 0; q < 4; q++) v[4 * j + q] = in ? p[q] : z;
+            for (int q = 0; q < 4; q++) v[4 * j + q] = p[q];
         }
+#pragma unroll
+        for (int j = 1; j < 4; j++)
+            if (!(k + j < cnt)) v[4 * j] = v[4 * j + 1] = v[4 * j + 2] = v[4 * j + 3] = z;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             line_acc_add(A, v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3], r0.x, r0.y, x0 + tx, y0 + ty);

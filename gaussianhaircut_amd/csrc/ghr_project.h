@@ -161,6 +161,33 @@ GHR_HD void sh_basis_grad_dot(int deg, float x, float y, float z, const float* v
     ox = gx; oy = gy; oz = gz;
 }
 
+// One Gaussian's raw parameters (everything per-Gaussian but the higher SH coefficients, which the kernels stage through
+// LDS).  The kernels request them at the very top, next to the coefficient slab, so that the projection arithmetic finds
+// them in registers: loaded where they are used they were two to three more dependent HBM round trips inside a workgroup's
+// compute phase (round 5 phase profile: profiles/r05m).  NULL pointers of mode 1 read as their constants / zeros.
+struct RawIn {
+    float xyz[3], ls[3], q[4];
+    float op, lab, conf;  // opacity / label / orientation confidence as stored (logits and log in mode 0)
+    float dc[3];
+    float dir[3];         // mode 1 strand direction (zeros without one)
+};
+
+GHR_HD void load_raw(const ModelArgs& a, int idx, RawIn& in)
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        in.xyz[i] = a.xyz[3 * idx + i];
+        in.ls[i] = a.log_scales[3 * idx + i];
+        in.dc[i] = a.features_dc[3 * (size_t)idx + i];
+        in.dir[i] = a.dir3d ? a.dir3d[3 * idx + i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) in.q[i] = a.rotations[4 * idx + i];
+    in.op = a.opacity_logit ? a.opacity_logit[idx] : a.const_opacity;
+    in.lab = a.label_logit ? a.label_logit[idx] : a.const_label;
+    in.conf = a.orient_conf_log ? a.orient_conf_log[idx] : a.const_conf;
+}
+
 // Everything both passes need, recomputed from the raw parameters (cheaper than storing it: 61 floats in, ~300 flop).
 struct ProjCtx {
     float s[3], s0[3];    // scaling * modifier, scaling
@@ -180,16 +207,15 @@ struct ProjCtx {
 
 GHR_HD float sel3(const float* v, int j) { return j == 0 ? v[0] : (j == 1 ? v[1] : v[2]); }
 
-GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
+GHR_HD void proj_setup(const ModelArgs& a, const RawIn& in, ProjCtx& c)
 {
-    const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+    const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        c.s0[i] = a.mode == 0 ? expf(a.log_scales[3 * idx + i]) : a.log_scales[3 * idx + i];
+        c.s0[i] = a.mode == 0 ? expf(in.ls[i]) : in.ls[i];
         c.s[i] = c.s0[i] * a.scale_modifier;
     }
-    const float q0 = a.rotations[4 * idx], q1 = a.rotations[4 * idx + 1], q2 = a.rotations[4 * idx + 2],
-                q3 = a.rotations[4 * idx + 3];
+    const float q0 = in.q[0], q1 = in.q[1], q2 = in.q[2], q3 = in.q[3];
     c.qlen = sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
     const float il = 1.0f / c.qlen;
     const float w = q0 * il, x = q1 * il, y = q2 * il, z = q3 * il;
@@ -244,9 +270,9 @@ GHR_HD void proj_setup(const ModelArgs& a, int idx, ProjCtx& c)
 
 // SH coefficient k (0 = DC) of channel ch.  `rest` points at THIS Gaussian's (K-1) x 3 block of features_rest (staged
 // in LDS by the kernels, global memory in the host-sim); coefficients beyond K read as 0.
-GHR_HD float sh_coeff(const ModelArgs& a, int idx, const float* rest, int k, int ch)
+GHR_HD float sh_coeff(const ModelArgs& a, const RawIn& in, const float* rest, int k, int ch)
 {
-    if (k == 0) return a.features_dc[3 * (size_t)idx + ch];
+    if (k == 0) return in.dc[ch];
     return k < a.sh_coeffs ? rest[(k - 1) * 3 + ch] : 0.f;
 }
 
@@ -259,14 +285,15 @@ struct ProjOut {
 };
 
 // Forward for one Gaussian, nothing stored.  Returns false when culled.
-GHR_HD bool project_core(const ModelArgs& a, int idx, const float* rest, int& x0, int& y0, int& x1, int& y1, ProjOut& o)
+GHR_HD bool project_core(const ModelArgs& a, const RawIn& in, const float* rest, int& x0, int& y0, int& x1, int& y1,
+                         ProjOut& o)
 {
     o.radius = 0;
     o.depth = 0.f;
     o.rec[0] = o.rec[1] = o.rec[2] = o.rec[3] = f4{0.f, 0.f, 0.f, 0.f};
     ProjCtx c;
-    proj_setup(a, idx, c);
-    const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+    proj_setup(a, in, c);
+    const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
 
     // get_mean_2d (gaussian_model.py:332-335); proj is used row-vector style: hom = xyz @ P[:3,:] + P[3,:]
     const float* pm = a.proj;
@@ -305,25 +332,25 @@ GHR_HD bool project_core(const ModelArgs& a, int idx, const float* rest, int& x0
     for (int ch = 0; ch < 3; ch++) {
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, idx, rest, k, ch);
+        for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, in, rest, k, ch);
         rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
     }
     float label, conf, opac, d2x, d2y;
     if (a.mode == 0) {
-        label = sigmoidf_(a.label_logit[idx]);
-        conf = expf(a.orient_conf_log[idx]);
-        opac = sigmoidf_(a.opacity_logit[idx]);
+        label = sigmoidf_(in.lab);
+        conf = expf(in.conf);
+        opac = sigmoidf_(in.op);
         const float sj = sel3(c.s0, c.jmax);
         d2x = sj * sel3(c.p, c.jmax);
         d2y = sj * sel3(c.r, c.jmax);
     } else {
-        label = a.label_logit ? a.label_logit[idx] : a.const_label;
-        conf = a.orient_conf_log ? a.orient_conf_log[idx] : a.const_conf;
-        opac = a.opacity_logit ? a.opacity_logit[idx] : a.const_opacity;
+        label = in.lab;
+        conf = in.conf;
+        opac = in.op;
         d2x = 0.f;
         d2y = 0.f;
         if (a.dir3d) {  // normalize(dir) @ T (gaussian_model_strands.py:430-431; F.normalize eps = 1e-12)
-            const float dx_ = a.dir3d[3 * idx], dy_ = a.dir3d[3 * idx + 1], dz_ = a.dir3d[3 * idx + 2];
+            const float dx_ = in.dir[0], dy_ = in.dir[1], dz_ = in.dir[2];
             const float in_ = 1.0f / fmaxf(sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_), 1e-12f);
             d2x = (dx_ * c.u[0] + dy_ * c.u[1] + dz_ * c.u[2]) * in_;
             d2y = (dx_ * c.v[0] + dy_ * c.v[1] + dz_ * c.v[2]) * in_;
@@ -344,7 +371,9 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
 {
     const size_t row = (size_t)a.row0 + idx;
     ProjOut o;
-    const bool ok = project_core(a, idx, rest, x0, y0, x1, y1, o);
+    RawIn in;
+    load_raw(a, idx, in);
+    const bool ok = project_core(a, in, rest, x0, y0, x1, y1, o);
     if (a.means2D) { a.means2D[3 * row] = o.ndc[0]; a.means2D[3 * row + 1] = o.ndc[1]; a.means2D[3 * row + 2] = o.ndc[2]; }
     a.radii[row] = o.radius;
     a.rects[row] = ok ? make_rect4(x0, y0, x1, y1, 0u) : rect4{0u, 0u, 0u, 0u};  // the caller fills in the gradient-slot base
@@ -360,8 +389,9 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
 // -> raw-parameter gradients.  Writes (or accumulates into) every output element except d_rest, which is handed back in
 // the caller's staging block.  Returns whether any value stored was NaN.
 // `rest` / `d_rest`: this Gaussian's (K-1) x 3 blocks of features_rest and of its gradient (LDS in the kernel).
-GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
-                            float* d_rest)
+// `in` / `radius`: load_raw(a, idx) and radii[row0 + idx] (requested by the kernel long before they are needed).
+GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, const RawIn& in, int radius, const float* ga,
+                             const float* rest, float* d_rest)
 {
     bool bad = false;
     const int acc = g.accumulate;
@@ -376,21 +406,21 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
     g.d_means2D[3 * row + 1] = gmy;
     g.d_means2D[3 * row + 2] = 0.f;
 
-    if (a.radii[row] > 0) {
+    if (radius > 0) {
         ProjCtx c;
-        proj_setup(a, idx, c);
-        const float mx = a.xyz[3 * idx], my = a.xyz[3 * idx + 1], mz = a.xyz[3 * idx + 2];
+        proj_setup(a, in, c);
+        const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
         const float gA = ga[2], gB = 2.0f * ga[3], gC = ga[4];  // wrapper's [xx, 2*xy, yy] restack (__init__.py:149-153)
         const float gop = ga[5];
         const float* gc = ga + 6;  // colours: rgb 0-2, label 3, one 4, dir2D 5-7, conf 8, depth 9
 
         // ---- activations (mode 1: the inputs are the activated quantities)
         if (a.mode == 0) {
-            const float o = sigmoidf_(a.opacity_logit[idx]);
+            const float o = sigmoidf_(in.op);
             dlo = gop * o * (1.f - o);
-            const float l = sigmoidf_(a.label_logit[idx]);
+            const float l = sigmoidf_(in.lab);
             dll = gc[3] * l * (1.f - l);
-            dlc = gc[8] * expf(a.orient_conf_log[idx]);
+            dlc = gc[8] * expf(in.conf);
         } else {
             dlo = gop;
             dll = gc[3];
@@ -437,7 +467,7 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
 #pragma unroll
             for (int i = 0; i < 3; i++) dls[i] = dls[i] / c.s0[i];
             if (a.dir3d) {  // dir2D = normalize(dir) . (u, v): cotangents for u, v and for dir (through the normalisation)
-                const float dx_ = a.dir3d[3 * idx], dy_ = a.dir3d[3 * idx + 1], dz_ = a.dir3d[3 * idx + 2];
+                const float dx_ = in.dir[0], dy_ = in.dir[1], dz_ = in.dir[2];
                 const float len_ = sqrtf(dx_ * dx_ + dy_ * dy_ + dz_ * dz_);
                 const float in_ = 1.0f / fmaxf(len_, 1e-12f);
                 const float dh[3] = {dx_ * in_, dy_ * in_, dz_ * in_};
@@ -523,7 +553,7 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
                 float acc = 0.f;
 #pragma unroll
                 for (int k = 0; k < GHR_SH_MAX; k++) {
-                    cf[k] = sh_coeff(a, idx, rest, k, ch);
+                    cf[k] = sh_coeff(a, in, rest, k, ch);
                     acc += basis[k] * cf[k];
                 }
                 const float gch = (acc + 0.5f >= 0.0f) ? gc[ch] : 0.f;  // clamp_min backward: grad where x >= min
@@ -561,6 +591,15 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
     return bad;
 }
 
+// project_bwd_core with its inputs loaded on the spot (tests/hostsim)
+GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
+                            float* d_rest)
+{
+    RawIn in;
+    load_raw(a, idx, in);
+    return project_bwd_core(a, g, idx, in, a.radii[(size_t)a.row0 + idx], ga, rest, d_rest);
+}
+
 // features_rest is [P, K-1, 3]: one thread's 3(K-1) floats are contiguous but 180 B apart from its neighbour's, so
 // direct per-thread loads touch 64 cache lines per instruction.  A block's slab (256 x 3(K-1) floats) IS contiguous
 // and 16-B aligned: move it through LDS with coalesced b128 accesses; per-thread LDS reads at an odd stride (45) are
@@ -569,11 +608,32 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GHR_SLAB_IT ((GHR_BLOCK * GHR_REST_MAX / 4 + GHR_BLOCK - 1) / GHR_BLOCK)  // 12 b128 accesses per thread
-// Global -> registers: ALL of a thread's (up to 12) loads are issued back to back; a rolled `d4[i] = s4[i]` loop
-// compiles to load / s_waitcnt vmcnt(0) / ds_write per trip, i.e. 12 serialized HBM round trips per workgroup.
-__device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats, int tid)
+// Global -> LDS without a stop in registers (round 5): thread t's 16-B pieces t, t + 256, ... go straight to their place
+// (`global_load_lds_dwordx4`: 1 KB contiguous per wave and instruction on both sides), all (up to 12) in flight together
+// and counted in vmcnt.  The 48 VGPRs the pieces used to wait in are what lets the kernels hold a Gaussian's raw
+// parameters from the first instruction on (RawIn) at the same occupancy.  The caller waits (slab_wait) before the barrier
+// that publishes the slab.
+__device__ __forceinline__ void slab_dma(float* dst, const float* src, size_t n_floats, int tid)
 {
     // src starts 16-B aligned (256 * 3(K-1) * 4 bytes per block is a multiple of 16)
+    const uint32_t n4 = (uint32_t)(n_floats / 4);
+    const int wave0 = tid & ~63;
+#pragma unroll
+    for (int it = 0; it < GHR_SLAB_IT; it++) {
+        const uint32_t i = tid + GHR_BLOCK * it;
+        if (i < n4)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (size_t)i),
+                                             (__attribute__((address_space(3))) void*)(dst + 4 * (wave0 + GHR_BLOCK * it)),
+                                             16, 0, 2 /* nt: read once */);
+    }
+    // (the scalar tail of a partial last block)
+    for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
+}
+__device__ __forceinline__ void slab_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Global -> registers -> LDS (k_project): ALL of a thread's (up to 12) loads are issued back to back; a rolled
+// `d4[i] = s4[i]` loop compiles to load / s_waitcnt vmcnt(0) / ds_write per trip, i.e. 12 serialized HBM round trips.
+__device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats, int tid)
+{
     const uint32_t n4 = (uint32_t)(n_floats / 4);
     const f4* s4 = reinterpret_cast<const f4*>(src);
 #pragma unroll
@@ -582,7 +642,6 @@ __device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src
         if (i < n4) v[it] = __builtin_nontemporal_load(s4 + i);
     }
 }
-// registers -> LDS (+ the scalar tail of a partial last block straight from global)
 __device__ __forceinline__ void slab_to_lds(float* dst, const f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats,
                                             int tid)
 {
@@ -637,16 +696,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     const int row = 3 * (a.sh_coeffs - 1);
     const int base = blockIdx.x * GHR_BLOCK;
     const int nb = min(GHR_BLOCK, a.P - base);
+    const int idx = base + threadIdx.x;
+    RawIn in;
+    // (registers, not slab_dma: measured 50.5 us against 54.3 for this kernel, which has the registers to spare;
+    // the raw parameters requested here instead of where the projection uses them: 52.8 -> 50.5, profiles/r05o)
     if (row > 0) {
         f4 v[GHR_SLAB_IT];
         slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+        load_raw(a, min(idx, a.P - 1), in);  // requested behind the slab, in flight with it
         slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    } else {
+        load_raw(a, min(idx, a.P - 1), in);
     }
     __syncthreads();
-    const int idx = base + threadIdx.x;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     ProjOut o;
-    const bool ok = idx < a.P && project_core(a, idx, s_rest + threadIdx.x * row, x0, y0, x1, y1, o);
+    const bool ok = idx < a.P && project_core(a, in, s_rest + threadIdx.x * row, x0, y0, x1, y1, o);
     // the counting atomics (they hand out the instances' list positions: count_tiles) go out now, their results are needed at
     // the very end: the round trip runs under the stores below
     TileCountPending tc;
@@ -695,20 +760,28 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     const int base = blockIdx.x * GHR_BLOCK;
     const int nb = min(GHR_BLOCK, a.P - base);
     const int idx = base + threadIdx.x;
-    // request the rect, then the coefficient slab, and gather this Gaussian's gradient lines while the slab is in
-    // flight (vmcnt retires in order: the rect must be the OLDEST request or waiting for it drains the slab too)
-    rect4 r = make_rect4(0, 0, 0, 0, 0u);
-    if (idx < a.P) r = a.rects[(size_t)a.row0 + idx];
-    f4 v[GHR_SLAB_IT];
-    if (row > 0) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
-    f4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;  // pixel mean / conic / opacity of the record k_project wrote (culled rows: none)
-    if (idx < a.P && rect4_area(r) != 0u) { q0 = a.rec[4 * ((size_t)a.row0 + idx)]; q1 = a.rec[4 * ((size_t)a.row0 + idx) + 1]; }
+    // ONE first round trip for everything that does not depend on something loaded (round 5; the phase profile of round 4's
+    // form, profiles/r05m, showed seven dependent trips per workgroup: rect -> record -> line numbers -> lines, then inside the
+    // compute phase radius -> raw parameters -> activations): the rect, the record k_project wrote (zeros for culled rows, so
+    // no need to know the rect first), the raw parameters, the radius, and the coefficient slab straight into LDS.  Two more
+    // trips follow: the instances' line numbers and the lines.
+    const int idc = min(idx, a.P - 1);
+    const size_t rowc = (size_t)a.row0 + idc;
+    rect4 r = a.rects[rowc];
+    f4 q0 = a.rec[4 * rowc], q1 = a.rec[4 * rowc + 1];  // pixel mean / conic / opacity
+    RawIn in;
+    load_raw(a, idc, in);
+    const int radius = a.radii[rowc];
+    // (LDS-DMA, not registers: with the slab's 48 registers on top this kernel needs 180 VGPRs -- two waves per SIMD -- or
+    // spills at 168: 109 us against 89.6, profiles/r05o)
+    if (row > 0) slab_dma(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    if (idx >= a.P) r = make_rect4(0, 0, 0, 0, 0u);
     float ga[16];
     gather_inst_grads_wave(g.ginst, g.inst_line, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
-    if (row > 0) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    slab_wait();
     __syncthreads();
     bool bad = false;
-    if (idx < a.P) bad = project_bwd_one(a, g, idx, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+    if (idx < a.P) bad = project_bwd_core(a, g, idx, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
     __syncthreads();
     if (row > 0) bad |= slab_out(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
