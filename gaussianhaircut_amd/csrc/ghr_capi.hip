@@ -372,6 +372,9 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     if (m->sh_degree < 0 || m->sh_degree > 3 || m->sh_coeffs < (m->sh_degree + 1) * (m->sh_degree + 1) ||
         m->sh_coeffs > GHR_SH_MAX)
         return fail(GHR_E_INVALID, "bad sh_degree / sh_coeffs");
+    // K = (max_sh_degree + 1)^2 (include/ghr.h): the kernels' 16-B staging of features_rest counts on rows of >= 9 floats
+    if (m->sh_coeffs != 1 && m->sh_coeffs != 4 && m->sh_coeffs != 9 && m->sh_coeffs != 16)
+        return fail(GHR_E_INVALID, "ghr_model_args: sh_coeffs must be (max_sh_degree + 1)^2, i.e. 1, 4, 9 or 16");
     if (m->mode != 0 && m->mode != 1) return fail(GHR_E_INVALID, "ghr_model_args: mode must be 0 or 1");
     if (m->row0 < 0 || (m->row0 & (GHR_BLOCK - 1))) return fail(GHR_E_INVALID, "ghr_model_args: row0 must be a multiple of 256");
     const bool need_act = m->mode == 0;  // mode 1: opacity / label / confidence pointers are optional
@@ -424,7 +427,8 @@ int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t row
     if (a.P == 0) return finish(s, m->debug);
     a.rec = g.rec; a.depths = g.depths; a.rects = g.rects; a.radii = radii; a.means2D = means2D_out;
     a.tile_count = im.tile_count; a.slot_blk = g.slot_blk; a.pos = g.pos;
-    hipLaunchKernelGGL(ghr::k_project, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a);
+    if (a.sh_coeffs > 1) hipLaunchKernelGGL(ghr::k_project<true>, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a);
+    else hipLaunchKernelGGL(ghr::k_project<false>, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a);
     return finish(s, m->debug);
 }
 

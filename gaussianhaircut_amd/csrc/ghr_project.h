@@ -172,20 +172,29 @@ struct RawIn {
     float dir[3];         // mode 1 strand direction (zeros without one)
 };
 
+// No branches: an absent array reads xyz instead (always there, always long enough) and the value is dropped.  A load
+// behind a branch -- even a uniform one -- may or may not have been issued, and the compiler can then only wait for OLDER
+// loads with vmcnt(0): the kernels want to use these values while the loads they issue next are still in flight.
 GHR_HD void load_raw(const ModelArgs& a, int idx, RawIn& in)
 {
+    const float* dir = a.dir3d ? a.dir3d : a.xyz;
+    const float* op = a.opacity_logit ? a.opacity_logit : a.xyz;
+    const float* lab = a.label_logit ? a.label_logit : a.xyz;
+    const float* conf = a.orient_conf_log ? a.orient_conf_log : a.xyz;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         in.xyz[i] = a.xyz[3 * idx + i];
         in.ls[i] = a.log_scales[3 * idx + i];
         in.dc[i] = a.features_dc[3 * (size_t)idx + i];
-        in.dir[i] = a.dir3d ? a.dir3d[3 * idx + i] : 0.f;
+        const float d = dir[3 * idx + i];
+        in.dir[i] = a.dir3d ? d : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) in.q[i] = a.rotations[4 * idx + i];
-    in.op = a.opacity_logit ? a.opacity_logit[idx] : a.const_opacity;
-    in.lab = a.label_logit ? a.label_logit[idx] : a.const_label;
-    in.conf = a.orient_conf_log ? a.orient_conf_log[idx] : a.const_conf;
+    const float vo = op[idx], vl = lab[idx], vc = conf[idx];
+    in.op = a.opacity_logit ? vo : a.const_opacity;
+    in.lab = a.label_logit ? vl : a.const_label;
+    in.conf = a.orient_conf_log ? vc : a.const_conf;
 }
 
 // Everything both passes need, recomputed from the raw parameters (cheaper than storing it: 61 floats in, ~300 flop).
@@ -284,9 +293,10 @@ struct ProjOut {
     float ndc[3];   // get_mean_2d values, written for every row
 };
 
-// Forward for one Gaussian, nothing stored.  Returns false when culled.
-GHR_HD bool project_core(const ModelArgs& a, const RawIn& in, const float* rest, int& x0, int& y0, int& x1, int& y1,
-                         ProjOut& o)
+// Forward for one Gaussian, nothing stored, in two parts: everything but the colour (needs the raw parameters only -- the
+// kernel runs it while the coefficient slab is still on its way), then the colour (needs the higher SH coefficients).
+// project_geom returns false when culled (record all zero); the colour is only evaluated for survivors.
+GHR_HD bool project_geom(const ModelArgs& a, const RawIn& in, int& x0, int& y0, int& x1, int& y1, ProjOut& o)
 {
     o.radius = 0;
     o.depth = 0.f;
@@ -322,19 +332,6 @@ GHR_HD bool project_core(const ModelArgs& a, const RawIn& in, const float* rest,
     tile_rect(pixx, pixy, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return false;
 
-    // colours (gaussian_renderer/__init__.py:58-74)
-    const float dxv = mx - a.campos[0], dyv = my - a.campos[1], dzv = mz - a.campos[2];
-    const float dl = 1.0f / sqrtf(dxv * dxv + dyv * dyv + dzv * dzv);
-    float basis[GHR_SH_MAX];
-    sh_basis(a.sh_degree, dxv * dl, dyv * dl, dzv * dl, basis);
-    float rgb[3];
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, in, rest, k, ch);
-        rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
-    }
     float label, conf, opac, d2x, d2y;
     if (a.mode == 0) {
         label = sigmoidf_(in.lab);
@@ -358,12 +355,40 @@ GHR_HD bool project_core(const ModelArgs& a, const RawIn& in, const float* rest,
     }
 
     o.rec[0] = f4{pixx, pixy, cx, cy};
-    o.rec[1] = f4{cz, opac, rgb[0], rgb[1]};
-    o.rec[2] = f4{rgb[2], label, 1.0f, d2x};
+    o.rec[1] = f4{cz, opac, 0.0f, 0.0f};   // colour: project_colour
+    o.rec[2] = f4{0.0f, label, 1.0f, d2x};
     o.rec[3] = f4{d2y, 0.0f, conf, c.t[2]};
     o.depth = c.t[2];
     o.radius = (int)my_radius;
     return true;
+}
+
+// colours (gaussian_renderer/__init__.py:58-74) into the record of a Gaussian that passed project_geom
+GHR_HD void project_colour(const ModelArgs& a, const RawIn& in, const float* rest, ProjOut& o)
+{
+    const float dxv = in.xyz[0] - a.campos[0], dyv = in.xyz[1] - a.campos[1], dzv = in.xyz[2] - a.campos[2];
+    const float dl = 1.0f / sqrtf(dxv * dxv + dyv * dyv + dzv * dzv);
+    float basis[GHR_SH_MAX];
+    sh_basis(a.sh_degree, dxv * dl, dyv * dl, dzv * dl, basis);
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < GHR_SH_MAX; k++) acc += basis[k] * sh_coeff(a, in, rest, k, ch);
+        rgb[ch] = fmaxf(acc + 0.5f, 0.0f);
+    }
+    o.rec[1].z = rgb[0];
+    o.rec[1].w = rgb[1];
+    o.rec[2].x = rgb[2];
+}
+
+GHR_HD bool project_core(const ModelArgs& a, const RawIn& in, const float* rest, int& x0, int& y0, int& x1, int& y1,
+                         ProjOut& o)
+{
+    const bool ok = project_geom(a, in, x0, y0, x1, y1, o);
+    if (ok) project_colour(a, in, rest, o);
+    return ok;
 }
 
 // project_core + the stores of one Gaussian (tests/hostsim; k_project stores for itself).  Returns false when culled.
@@ -634,12 +659,15 @@ __device__ __forceinline__ void slab_wait() { asm volatile("s_waitcnt vmcnt(0)" 
 // `d4[i] = s4[i]` loop compiles to load / s_waitcnt vmcnt(0) / ds_write per trip, i.e. 12 serialized HBM round trips.
 __device__ __forceinline__ void slab_load(f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats, int tid)
 {
+    // No predication: pieces past the end re-read the last one (dropped by slab_to_lds).  A load under `if (i < n4)` is a
+    // branch around it, and behind loads that may or may not have been issued the compiler can only wait with vmcnt(0) --
+    // for the caller's OLDER loads too, which it wants to use while these are in flight.  n_floats >= 4.
     const uint32_t n4 = (uint32_t)(n_floats / 4);
     const f4* s4 = reinterpret_cast<const f4*>(src);
 #pragma unroll
     for (int it = 0; it < GHR_SLAB_IT; it++) {
         const uint32_t i = tid + GHR_BLOCK * it;
-        if (i < n4) v[it] = __builtin_nontemporal_load(s4 + i);
+        v[it] = __builtin_nontemporal_load(s4 + (i < n4 ? i : n4 - 1u));
     }
 }
 __device__ __forceinline__ void slab_to_lds(float* dst, const f4 (&v)[GHR_SLAB_IT], const float* src, size_t n_floats,
@@ -689,33 +717,32 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
 }
 #endif
 
+// REST: the model has SH coefficients beyond the DC term (a template parameter, not a test of sh_coeffs: see load_raw)
+template <bool REST>
 __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) float s_rest[GHR_BLOCK * GHR_REST_MAX];
-    const int row = 3 * (a.sh_coeffs - 1);
+    const int row = REST ? 3 * (a.sh_coeffs - 1) : 0;
     const int base = blockIdx.x * GHR_BLOCK;
     const int nb = min(GHR_BLOCK, a.P - base);
     const int idx = base + threadIdx.x;
+    // Issue order = return order: the raw parameters first, the coefficient slab behind them (registers, not slab_dma:
+    // 50.5 us against 54.3 for this kernel, which has the registers to spare: profiles/r05o).  Everything but the colour --
+    // cull, conic, radius, tile rect -- is computed while the slab is on its way, and the counting atomics (they hand out
+    // the instances' list positions: count_tiles; results needed at the very end) go out before the slab is even waited for.
     RawIn in;
-    // (registers, not slab_dma: measured 50.5 us against 54.3 for this kernel, which has the registers to spare;
-    // the raw parameters requested here instead of where the projection uses them: 52.8 -> 50.5, profiles/r05o)
-    if (row > 0) {
-        f4 v[GHR_SLAB_IT];
-        slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
-        load_raw(a, min(idx, a.P - 1), in);  // requested behind the slab, in flight with it
-        slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
-    } else {
-        load_raw(a, min(idx, a.P - 1), in);
-    }
-    __syncthreads();
+    load_raw(a, min(idx, a.P - 1), in);
+    f4 v[GHR_SLAB_IT];
+    if (REST) slab_load(v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     ProjOut o;
-    const bool ok = idx < a.P && project_core(a, in, s_rest + threadIdx.x * row, x0, y0, x1, y1, o);
-    // the counting atomics (they hand out the instances' list positions: count_tiles) go out now, their results are needed at
-    // the very end: the round trip runs under the stores below
+    const bool ok = idx < a.P && project_geom(a, in, x0, y0, x1, y1, o);
     TileCountPending tc;
     count_tiles_issue(a.tile_count, a.gx, x0, y0, x1, y1, tc);
+    if (REST) slab_to_lds(s_rest, v, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    __syncthreads();
+    if (ok) project_colour(a, in, s_rest + threadIdx.x * row, o);
     __shared__ uint32_t s_scan[4];
     uint32_t blk_total;
     const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
