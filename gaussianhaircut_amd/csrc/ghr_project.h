@@ -82,18 +82,11 @@ struct ModelGrads {
     int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN or +-inf
 };
 
-// Writes (or accumulates) one parameter-gradient element; returns whether the stored value is NON-FINITE.  The
+// Whether a parameter-gradient value about to be stored is NON-FINITE (project_bwd_store raises nan_flag for it).  The
 // reference's guard looks for NaN only (train_gaussians.py:174-177); raising the flag for +-inf as well costs nothing (an
 // infinite gradient turns the parameter into NaN in the very next Adam update anyway) and closes the data-parallel hole
 // in which +inf on one rank and -inf on another meet as a NaN only inside the all-reduced sum.
 GHR_HD bool nonfinite(float v) { return !(fabsf(v) <= 3.402823466e38f); }
-GHR_HD bool grad_out(float* p, float v, int accumulate)
-{
-    if (p == nullptr) return false;
-    if (accumulate) v += *p;
-    *p = v;
-    return nonfinite(v);
-}
 
 GHR_HD float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
@@ -160,6 +153,18 @@ GHR_HD void sh_basis_grad_dot(int deg, float x, float y, float z, const float* v
     }
     ox = gx; oy = gy; oz = gz;
 }
+
+// The camera's matrices and position are the same for every thread and not written while the kernels run: read through the
+// constant address space they become scalar loads (s_load -> SGPRs, counted in lgkmcnt).  As plain global loads they were
+// vector loads of one address by 64 lanes, each a stop at vmcnt in the middle of the arithmetic -- and vmcnt retires in
+// order, so such a stop also waits for everything requested before it (the coefficient slab still on its way).
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float* uniform_floats;
+#define GHR_UNIFORM(p) ((uniform_floats)(uintptr_t)(p))
+#else
+typedef const float* uniform_floats;
+#define GHR_UNIFORM(p) (p)
+#endif
 
 // One Gaussian's raw parameters (everything per-Gaussian but the higher SH coefficients, which the kernels stage through
 // LDS).  The kernels request them at the very top, next to the coefficient slab, so that the projection arithmetic finds
@@ -232,7 +237,7 @@ GHR_HD void proj_setup(const ModelArgs& a, const RawIn& in, ProjCtx& c)
     c.ax[0][0] = 1 - 2 * (y * y + z * z); c.ax[0][1] = 2 * (x * y + w * z); c.ax[0][2] = 2 * (x * z - w * y);
     c.ax[1][0] = 2 * (x * y - w * z); c.ax[1][1] = 1 - 2 * (x * x + z * z); c.ax[1][2] = 2 * (y * z + w * x);
     c.ax[2][0] = 2 * (x * z + w * y); c.ax[2][1] = 2 * (y * z - w * x); c.ax[2][2] = 1 - 2 * (x * x + y * y);
-    const float* V = a.view;  // V[4*row + col]; t = xyz @ V[:3,:3] + V[3,:3]
+    const uniform_floats V = GHR_UNIFORM(a.view);  // V[4*row + col]; t = xyz @ V[:3,:3] + V[3,:3]
 #pragma unroll
     for (int col = 0; col < 3; col++) {
         c.t[col] = mx * V[col] + my * V[4 + col] + mz * V[8 + col] + V[12 + col];
@@ -306,7 +311,7 @@ GHR_HD bool project_geom(const ModelArgs& a, const RawIn& in, int& x0, int& y0, 
     const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
 
     // get_mean_2d (gaussian_model.py:332-335); proj is used row-vector style: hom = xyz @ P[:3,:] + P[3,:]
-    const float* pm = a.proj;
+    const uniform_floats pm = GHR_UNIFORM(a.proj);
     const float hx = mx * pm[0] + my * pm[4] + mz * pm[8] + pm[12];
     const float hy = mx * pm[1] + my * pm[5] + mz * pm[9] + pm[13];
     const float hz = mx * pm[2] + my * pm[6] + mz * pm[10] + pm[14];
@@ -366,7 +371,8 @@ GHR_HD bool project_geom(const ModelArgs& a, const RawIn& in, int& x0, int& y0, 
 // colours (gaussian_renderer/__init__.py:58-74) into the record of a Gaussian that passed project_geom
 GHR_HD void project_colour(const ModelArgs& a, const RawIn& in, const float* rest, ProjOut& o)
 {
-    const float dxv = in.xyz[0] - a.campos[0], dyv = in.xyz[1] - a.campos[1], dzv = in.xyz[2] - a.campos[2];
+    const uniform_floats cam = GHR_UNIFORM(a.campos);
+    const float dxv = in.xyz[0] - cam[0], dyv = in.xyz[1] - cam[1], dzv = in.xyz[2] - cam[2];
     const float dl = 1.0f / sqrtf(dxv * dxv + dyv * dyv + dzv * dzv);
     float basis[GHR_SH_MAX];
     sh_basis(a.sh_degree, dxv * dl, dyv * dl, dzv * dl, basis);
@@ -415,21 +421,20 @@ GHR_HD bool project_one(const ModelArgs& a, int idx, const float* rest, int& x0,
 // the caller's staging block.  Returns whether any value stored was NaN.
 // `rest` / `d_rest`: this Gaussian's (K-1) x 3 blocks of features_rest and of its gradient (LDS in the kernel).
 // `in` / `radius`: load_raw(a, idx) and radii[row0 + idx] (requested by the kernel long before they are needed).
-GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, const RawIn& in, int radius, const float* ga,
-                             const float* rest, float* d_rest)
+// In three parts, like the forward: everything that does not touch the higher SH coefficients (the kernel runs it while the
+// coefficient slab is still on its way), the SH colour, the stores.
+struct ProjBwdOut {
+    float dxyz[3], dls[3], dq[4];
+    float dlo, dll, dlc;
+    float ddc[3], ddir[3];
+};
+
+GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, const float* ga, ProjBwdOut& o)
 {
-    bool bad = false;
-    const int acc = g.accumulate;
-    const int K = a.sh_coeffs;
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
-    float ddc[3] = {0, 0, 0};
-    const size_t row = (size_t)a.row0 + idx;
     float ddir[3] = {0, 0, 0};
     const float gmx = ga[0], gmy = ga[1];
-    g.d_means2D[3 * row] = gmx;
-    g.d_means2D[3 * row + 1] = gmy;
-    g.d_means2D[3 * row + 2] = 0.f;
 
     if (radius > 0) {
         ProjCtx c;
@@ -547,13 +552,13 @@ GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, c
             Lt[2] += (c.inx ? 0.f : c.clx * Ltxp) + (c.iny ? 0.f : c.cly * Ltyp);
             Lt[2] += gc[9];  // depth channel = view z
         }
-        const float* V = a.view;
+        const uniform_floats V = GHR_UNIFORM(a.view);
 #pragma unroll
         for (int row = 0; row < 3; row++) dxyz[row] += V[4 * row] * Lt[0] + V[4 * row + 1] * Lt[1] + V[4 * row + 2] * Lt[2];
 
         // ---- NDC mean
         {
-            const float* pm = a.proj;
+            const uniform_floats pm = GHR_UNIFORM(a.proj);
             const float hx = mx * pm[0] + my * pm[4] + mz * pm[8] + pm[12];
             const float hy = mx * pm[1] + my * pm[5] + mz * pm[9] + pm[13];
             const float hw = mx * pm[3] + my * pm[7] + mz * pm[11] + pm[15];
@@ -562,10 +567,28 @@ GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, c
 #pragma unroll
             for (int row = 0; row < 3; row++) dxyz[row] += pm[4 * row] * Lhx + pm[4 * row + 1] * Lhy + pm[4 * row + 3] * Lhw;
         }
-        // ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz.
-        // d_rest may alias rest: every element is read (cf) before it is overwritten, channel by channel.
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { o.dxyz[i] = dxyz[i]; o.dls[i] = dls[i]; o.ddir[i] = ddir[i]; o.ddc[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) o.dq[i] = dq[i];
+    o.dlo = dlo; o.dll = dll; o.dlc = dlc;
+}
+
+// ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz (added to o.dxyz behind the geometry
+// terms).  d_rest may alias rest: every element is read (cf) before it is overwritten, channel by channel.
+GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, const float* ga, const float* rest, float* d_rest,
+                           ProjBwdOut& o)
+{
+    const int K = a.sh_coeffs;
+    if (radius > 0) {
+        const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
+        const float* gc = ga + 6;  // colours: rgb 0-2
+        float* dxyz = o.dxyz;
+        float* ddc = o.ddc;
         {
-            const float dxv = mx - a.campos[0], dyv = my - a.campos[1], dzv = mz - a.campos[2];
+            const uniform_floats cam = GHR_UNIFORM(a.campos);
+            const float dxv = mx - cam[0], dyv = my - cam[1], dzv = mz - cam[2];
             const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
             const float x = dxv * il, y = dyv * il, z = dzv * il;
             float basis[GHR_SH_MAX], vk[GHR_SH_MAX];
@@ -599,21 +622,58 @@ GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, c
     } else {
         for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
     }
+}
+
+// Writes (or accumulates into) every output element except d_rest, which stays in the caller's staging block.  Returns
+// whether any value stored was non-finite.
+GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const ProjBwdOut& o)
+{
+    const int acc = g.accumulate;
+    const size_t row = (size_t)a.row0 + idx;
+    g.d_means2D[3 * row] = ga[0];
+    g.d_means2D[3 * row + 1] = ga[1];
+    g.d_means2D[3 * row + 2] = 0.f;
+    // the values in output order; accumulating, ALL old values are requested before the first is needed (element by
+    // element -- read, add, store -- the 22 of them were 22 dependent round trips per Gaussian in every view but the first)
+    float v[22];
+    float* p[22];
 #pragma unroll
     for (int i = 0; i < 3; i++) {
-        bad |= grad_out(g.d_xyz + 3 * idx + i, dxyz[i], acc);
-        bad |= grad_out(g.d_log_scales + 3 * idx + i, dls[i], acc);
+        v[i] = o.dxyz[i];          p[i] = g.d_xyz + 3 * idx + i;
+        v[3 + i] = o.dls[i];       p[3 + i] = g.d_log_scales + 3 * idx + i;
+        v[13 + i] = o.ddir[i];     p[13 + i] = g.d_dir3d ? g.d_dir3d + 3 * idx + i : nullptr;
+        v[16 + i] = o.ddc[i];      p[16 + i] = g.d_features_dc + 3 * (size_t)idx + i;
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) bad |= grad_out(g.d_rotations + 4 * idx + i, dq[i], acc);
-    bad |= grad_out(g.d_opacity_logit ? g.d_opacity_logit + idx : nullptr, dlo, acc);
-    bad |= grad_out(g.d_label_logit ? g.d_label_logit + idx : nullptr, dll, acc);
-    bad |= grad_out(g.d_orient_conf_log ? g.d_orient_conf_log + idx : nullptr, dlc, acc);
+    for (int i = 0; i < 4; i++) { v[6 + i] = o.dq[i]; p[6 + i] = g.d_rotations + 4 * idx + i; }
+    v[10] = o.dlo; p[10] = g.d_opacity_logit ? g.d_opacity_logit + idx : nullptr;
+    v[11] = o.dll; p[11] = g.d_label_logit ? g.d_label_logit + idx : nullptr;
+    v[12] = o.dlc; p[12] = g.d_orient_conf_log ? g.d_orient_conf_log + idx : nullptr;
+    const int n = 19;
+    if (acc) {
+        float old[19];
 #pragma unroll
-    for (int i = 0; i < 3; i++) bad |= grad_out(g.d_dir3d ? g.d_dir3d + 3 * idx + i : nullptr, ddir[i], acc);
+        for (int i = 0; i < n; i++) old[i] = p[i] ? *p[i] : 0.f;
 #pragma unroll
-    for (int ch = 0; ch < 3; ch++) bad |= grad_out(g.d_features_dc + 3 * (size_t)idx + ch, ddc[ch], acc);
+        for (int i = 0; i < n; i++) v[i] += old[i];
+    }
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < n; i++)
+        if (p[i]) {
+            *p[i] = v[i];
+            bad |= nonfinite(v[i]);
+        }
     return bad;
+}
+
+GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, const RawIn& in, int radius, const float* ga,
+                             const float* rest, float* d_rest)
+{
+    ProjBwdOut o;
+    project_bwd_geom(a, in, radius, ga, o);
+    project_bwd_sh(a, in, radius, ga, rest, d_rest, o);
+    return project_bwd_store(a, g, idx, ga, o);
 }
 
 // project_bwd_core with its inputs loaded on the spot (tests/hostsim)
@@ -788,10 +848,12 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     const int nb = min(GHR_BLOCK, a.P - base);
     const int idx = base + threadIdx.x;
     // ONE first round trip for everything that does not depend on something loaded (round 5; the phase profile of round 4's
-    // form, profiles/r05m, showed seven dependent trips per workgroup: rect -> record -> line numbers -> lines, then inside the
+    // form, profiles/r05o, showed seven dependent trips per workgroup: rect -> record -> line numbers -> lines, then inside the
     // compute phase radius -> raw parameters -> activations): the rect, the record k_project wrote (zeros for culled rows, so
-    // no need to know the rect first), the raw parameters, the radius, and the coefficient slab straight into LDS.  Two more
-    // trips follow: the instances' line numbers and the lines.
+    // no need to know the rect first), the raw parameters, the radius.  Two more trips follow: the instances' line numbers
+    // and the lines.  The coefficient slab (46 KB per workgroup, the bulk of the kernel's reads) is requested BEHIND them,
+    // straight into LDS, and only waited for in front of the SH part: vmcnt retires in order, so requested first it made the
+    // small dependent trips wait for the big transfer, and the geometry backward (two thirds of the arithmetic) needs none of it.
     const int idc = min(idx, a.P - 1);
     const size_t rowc = (size_t)a.row0 + idc;
     rect4 r = a.rects[rowc];
@@ -799,16 +861,25 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     RawIn in;
     load_raw(a, idc, in);
     const int radius = a.radii[rowc];
-    // (LDS-DMA, not registers: with the slab's 48 registers on top this kernel needs 180 VGPRs -- two waves per SIMD -- or
-    // spills at 168: 109 us against 89.6, profiles/r05o)
-    if (row > 0) slab_dma(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     if (idx >= a.P) r = make_rect4(0, 0, 0, 0, 0u);
     float ga[16];
     gather_inst_grads_wave(g.ginst, g.inst_line, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
+    // (LDS-DMA, not registers: with the slab's 48 registers on top this kernel needs 180 VGPRs -- two waves per SIMD -- or
+    // spills at 168: 109 us against 89.6, profiles/r05o)
+    // (everything requested so far has arrived -- the gather used it -- but the compiler cannot know on every path: told
+    // here, with a wait that costs nothing, or it would protect the first use of `radius` below with a vmcnt(0) that
+    // waits for the slab.  0x0f70 = vmcnt(0), expcnt / lgkmcnt untouched.)
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (row > 0) slab_dma(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    ProjBwdOut o;
+    if (idx < a.P) project_bwd_geom(a, in, radius, ga, o);
     slab_wait();
     __syncthreads();
     bool bad = false;
-    if (idx < a.P) bad = project_bwd_core(a, g, idx, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row);
+    if (idx < a.P) {
+        project_bwd_sh(a, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row, o);
+        bad = project_bwd_store(a, g, idx, ga, o);
+    }
     __syncthreads();
     if (row > 0) bad |= slab_out(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
