@@ -380,18 +380,23 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     // replayed, e.g. after a too small speculative capacity) and a forward pass of its image workspace (a recycled one skips
     // its zero-fill)
     // The tile's gradient lines are its n consecutive lines from s (they lie in list order): when the caller hands the
-    // backward pass's scratch over, they are zeroed here, under the sort's LDS round trips where the memory pipe is idle
-    // (the backward render kernel then starts accumulating at once: -10 % of its time inside the step).
-    if (ginst != nullptr) {
-        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    // backward pass's scratch over, they are zeroed by this kernel, whose memory pipe is mostly idle (the backward render
+    // kernel then starts accumulating at once: -10 % of its time inside the step).  As the workgroup's LAST act (round 5):
+    // stores count in vmcnt like loads, so issued first -- "under the sort's LDS round trips" -- every later wait for a
+    // load (keys, rects) also waited for their acknowledgements: 46.4 -> 42.6 us (44.4 behind the key loads; profiles/r05u).
+    auto zero_lines = [&]() {
+        if (ginst != nullptr) {
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
                              // (same call: K8 190.9 -> 189.4 us, loss forward 69.2 -> 66.2, step 0.857 -> 0.850 ms)
-        for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
-    }
+            for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
+        }
+    };
     // (tile_cursor = tile_count[2][T]: [0] is back at 0 since k_tile_scan, [1] the big rects' append cursors / the DONE mark)
     const bool sorted_already = tile_cursor[T + tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
     __syncthreads();
     if (tid == 0) tile_cursor[T + tile] = 0u;
-    if (n == 0 || sorted_already) return;
+    if (n == 0) return;
+    if (sorted_already) { zero_lines(); return; }
     uint64_t* g = keys + s;
     if (n <= GHR_SORT_CAP) {
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) s_keys[i] = g[i];
@@ -402,7 +407,9 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
             g[i] = k;
             sort_emit(point_list, inst_line, rects, s + i, (uint32_t)k, tile % gx, tile / gx, cap);
         }
+        zero_lines();
     } else {
+        zero_lines();
         // Rare: a single tile with more instances than fit in LDS.  Same network, in place in global memory
         // (one workgroup => same CU/L1, __syncthreads orders the accesses).
         __syncthreads();

@@ -807,6 +807,11 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
     uint32_t blk_total;
     const uint32_t slot0 = block_excl_scan_256(ok ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u, s_scan, &blk_total);
     // (the scan's barrier is also the one behind which nobody reads the coefficient slab any more)
+    // From here on the kernel only stores.  Stores count in vmcnt like loads: the counting atomics' results, collected at the
+    // very end, would wait for the acknowledgement of every store below (the phase profile's "atomics collected": 10 % of a
+    // wave's time).  They returned long ago -- under the slab's round trip and the colour arithmetic -- so they are taken in
+    // here, with a wait that costs nothing (0x0f70 = vmcnt(0), expcnt / lgkmcnt untouched), and the kernel's tail is stores only.
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     // The record is 64 B per Gaussian: stored by its own thread it is four 16-B pieces at a 64-B stride per instruction (2.47 M
     // partial write requests at 500k Gaussians, profiles/r02a).  Through LDS instead: thread t stores the 16-B pieces
     // t, t + 256, ... of the workgroup's 16 KB of records -- 1 KB contiguous per wave and instruction.  Culled rows get zeros.
