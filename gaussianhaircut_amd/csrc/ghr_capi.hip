@@ -517,7 +517,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
     mg.accumulate = accumulate; mg.nan_flag = nan_flag;
-    hipLaunchKernelGGL(ghr::k_project_bwd, dim3(n_blocks(a.P)), dim3(GHR_BLOCK), 0, s, a, mg);
+    hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), dim3(GHR_PBW_BLOCK), 0, s, a, mg);
     return finish(s, m->debug);
 }
 

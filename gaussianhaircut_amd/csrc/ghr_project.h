@@ -698,6 +698,7 @@ GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, co
 // and counted in vmcnt.  The 48 VGPRs the pieces used to wait in are what lets the kernels hold a Gaussian's raw
 // parameters from the first instruction on (RawIn) at the same occupancy.  The caller waits (slab_wait) before the barrier
 // that publishes the slab.
+template <int BLK>
 __device__ __forceinline__ void slab_dma(float* dst, const float* src, size_t n_floats, int tid)
 {
     // src starts 16-B aligned (256 * 3(K-1) * 4 bytes per block is a multiple of 16)
@@ -705,14 +706,14 @@ __device__ __forceinline__ void slab_dma(float* dst, const float* src, size_t n_
     const int wave0 = tid & ~63;
 #pragma unroll
     for (int it = 0; it < GHR_SLAB_IT; it++) {
-        const uint32_t i = tid + GHR_BLOCK * it;
+        const uint32_t i = tid + BLK * it;
         if (i < n4)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 4 * (size_t)i),
-                                             (__attribute__((address_space(3))) void*)(dst + 4 * (wave0 + GHR_BLOCK * it)),
+                                             (__attribute__((address_space(3))) void*)(dst + 4 * (wave0 + BLK * it)),
                                              16, 0, 2 /* nt: read once */);
     }
     // (the scalar tail of a partial last block)
-    for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
+    for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += BLK) dst[i] = src[i];
 }
 __device__ __forceinline__ void slab_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Global -> registers -> LDS (k_project): ALL of a thread's (up to 12) loads are issued back to back; a rolled
@@ -743,6 +744,7 @@ __device__ __forceinline__ void slab_to_lds(float* dst, const f4 (&v)[GHR_SLAB_I
     for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += GHR_BLOCK) dst[i] = src[i];
 }
 // LDS gradient slab -> global, assigning or accumulating; returns whether a stored value was NaN
+template <int BLK>
 __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_floats, int tid, int accumulate)
 {
     const uint32_t n4 = (uint32_t)(n_floats / 4);
@@ -753,13 +755,13 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
     if (accumulate) {  // the read half of the read-modify-write, all loads in flight together (see slab_load)
 #pragma unroll
         for (int it = 0; it < GHR_SLAB_IT; it++) {
-            const uint32_t i = tid + GHR_BLOCK * it;
+            const uint32_t i = tid + BLK * it;
             if (i < n4) old[it] = d4[i];
         }
     }
 #pragma unroll
     for (int it = 0; it < GHR_SLAB_IT; it++) {
-        const uint32_t i = tid + GHR_BLOCK * it;
+        const uint32_t i = tid + BLK * it;
         if (i < n4) {
             f4 v = s4[i];
             if (accumulate) v += old[it];
@@ -767,7 +769,7 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
             bad |= nonfinite(v.x) | nonfinite(v.y) | nonfinite(v.z) | nonfinite(v.w);
         }
     }
-    for (size_t i = 4 * n4 + tid; i < n_floats; i += GHR_BLOCK) {
+    for (size_t i = 4 * n4 + tid; i < n_floats; i += BLK) {
         float v = src[i];
         if (accumulate) v += dst[i];
         dst[i] = v;
@@ -844,13 +846,19 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
 #endif
 }
 
-__global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
+// One WAVE per workgroup (round 5): nothing in this kernel needs more than its own 64 Gaussians, the LDS budget (11.5 KB of
+// coefficient slab per wave) and the register budget (134 VGPRs: three waves per SIMD) allow the same 12 waves per CU as
+// 256-thread workgroups did, and single waves are dispatched as soon as any slot frees up instead of four at a time:
+// 79.3 -> 76.5 us (128 threads: 77.5; forcing 128 VGPRs for a fourth wave per SIMD spills and loses: profiles/r05o).
+#define GHR_PBW_BLOCK 64
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float s_rest[GHR_BLOCK * GHR_REST_MAX];  // coefficients in, gradients out
+    constexpr int BLK = GHR_PBW_BLOCK;
+    __shared__ __attribute__((aligned(16))) float s_rest[BLK * GHR_REST_MAX];  // coefficients in, gradients out
     const int row = 3 * (a.sh_coeffs - 1);
-    const int base = blockIdx.x * GHR_BLOCK;
-    const int nb = min(GHR_BLOCK, a.P - base);
+    const int base = blockIdx.x * BLK;
+    const int nb = min(BLK, a.P - base);
     const int idx = base + threadIdx.x;
     // ONE first round trip for everything that does not depend on something loaded (round 5; the phase profile of round 4's
     // form, profiles/r05o, showed seven dependent trips per workgroup: rect -> record -> line numbers -> lines, then inside the
@@ -875,7 +883,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
     // here, with a wait that costs nothing, or it would protect the first use of `radius` below with a vmcnt(0) that
     // waits for the slab.  0x0f70 = vmcnt(0), expcnt / lgkmcnt untouched.)
     __builtin_amdgcn_s_waitcnt(0x0f70);
-    if (row > 0) slab_dma(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
+    if (row > 0) slab_dma<BLK>(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     ProjBwdOut o;
     if (idx < a.P) project_bwd_geom(a, in, radius, ga, o);
     slab_wait();
@@ -886,7 +894,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project_bwd(ModelArgs a, ModelGra
         bad = project_bwd_store(a, g, idx, ga, o);
     }
     __syncthreads();
-    if (row > 0) bad |= slab_out(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
+    if (row > 0) bad |= slab_out<BLK>(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
 #endif
 }
