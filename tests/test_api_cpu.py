@@ -50,6 +50,21 @@ def test_workspace_sizes_and_error_codes():
         _lib.check(_lib.GHR_E_NOCOLORS)
 
 
+def test_model_args_sh_coeffs_must_be_a_square_of_the_degree_plus_one():
+    """include/ghr.h: K = (max_sh_degree + 1)^2.  The projection kernels stage features_rest in 16-B pieces and count on
+    rows of 0 or >= 9 floats: anything else is refused before a kernel is launched (no GPU needed to see the refusal)."""
+    L = _lib.lib()
+    m = _lib.ModelArgs()
+    m.P, m.W, m.H, m.sh_degree, m.mode = 0, 64, 64, 0, 0
+    r_host = ctypes.c_uint32(0)
+    for k in (2, 3, 5, 8, 15):
+        m.sh_coeffs = k
+        rc = L.ghr_model_forward_stage1(None, ctypes.byref(m), None, None, None, None,
+                                        ctypes.cast(ctypes.byref(r_host), ctypes.c_void_p))
+        assert rc == _lib.GHR_E_INVALID, k
+        assert b"sh_coeffs must be" in L.ghr_last_error(), L.ghr_last_error()
+
+
 def _settings(ri):
     return GaussianRasterizationSettings(ri["H"], ri["W"], ri["tanfovx"], ri["tanfovy"], ri["bg"], 1.0,
                                          ri["viewmatrix"], ri["projmatrix"], 3, ri["campos"], True, False)

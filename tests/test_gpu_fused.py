@@ -15,21 +15,25 @@ FUSED = SimpleNamespace(debug=False, fused_projection=True)
 GENERIC = SimpleNamespace(debug=False, fused_projection=False)
 
 
-def _model(spec, dev, deg):
-    model = syn.make_model(spec, dev)
+def _model(spec, dev, deg, max_deg=3):
+    model = syn.make_model(spec, dev, sh_degree=max_deg)
     model.active_sh_degree = deg
     return model
 
 
-def _run(spec, pipe, dev, weights, deg):
-    model = _model(spec, dev, deg)
+def _run(spec, pipe, dev, weights, deg, max_deg=3):
+    model = _model(spec, dev, deg, max_deg)
     cam = syn.make_view(spec, dev)
     pkg = render(cam, model, pipe, syn.background(dev))
     full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
     loss = (full * weights[:6]).sum() + (pkg["orient_angle"] * weights[6:7]).sum() * 0.1
     loss.backward()
-    grads = {n: getattr(model, n).grad.detach().cpu().numpy() for n in
-             ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest")}
+    grads = {}
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest"):
+        t = getattr(model, n)
+        if t.numel() == 0:  # a degree-0 model stores no higher SH coefficients
+            continue
+        grads[n] = t.grad.detach().cpu().numpy()
     grads["viewspace"] = pkg["viewspace_points"].grad.detach().cpu().numpy()
     return pkg, grads
 
@@ -60,25 +64,28 @@ def _assert_rows_close(name, a, b, tol=1e-4, floor=1e-5):
         name, (~ok).sum(), ok.size, np.abs(a - b)[~ok].max(), np.abs(b).max())
 
 
-@pytest.mark.parametrize("cfg,deg", [("tiny", 3), ("tiny_strands", 3), ("ragged", 1), ("cfg1", 2)])
-def test_fused_render_matches_generic_path(cfg, deg):
+@pytest.mark.parametrize("cfg,deg,max_deg", [("tiny", 3, 3), ("tiny_strands", 3, 3), ("ragged", 1, 3), ("cfg1", 2, 3),
+                                             ("ragged", 0, 0), ("tiny_strands", 1, 1)])
+def test_fused_render_matches_generic_path(cfg, deg, max_deg):
     """Fused projection (k_project / k_project_bwd) vs the generic PyTorch projection around the same HIP rasterizer.
     No quantiles: the pixels that may legitimately differ are named (`_pixel_mask`, from the oracle chain's state of the
-    same scene) and get zero weight on both sides; everything else must agree -- image 1e-4, every gradient row 1e-4."""
+    same scene) and get zero weight on both sides; everything else must agree -- image 1e-4, every gradient row 1e-4.
+    ``max_deg`` 0 / 1: models that store 1 / 4 SH coefficients per channel (k_project<false>: no coefficient slab at all;
+    9-float slab rows)."""
     from tests import oracle_backend as ob
     dev = torch.device("cuda:0")
     spec = syn.CONFIGS[cfg]
     g = torch.Generator().manual_seed(5)
     weights = torch.randn(7, spec.H, spec.W, generator=g)
     # the oracle chain of the same scene names the fragile pixels
-    mc = syn.make_model(spec, "cpu")
+    mc = syn.make_model(spec, "cpu", sh_degree=max_deg)
     mc.active_sh_degree = deg
     with ob.oracle_rasterizer():
         pc = render(syn.make_view(spec, "cpu"), mc, GENERIC, syn.background("cpu"))
     st = ob.LAST["state"]
     with torch.no_grad():
-        pf0 = render(syn.make_view(spec, dev), _model(spec, dev, deg), FUSED, syn.background(dev))
-        pg0 = render(syn.make_view(spec, dev), _model(spec, dev, deg), GENERIC, syn.background(dev))
+        pf0 = render(syn.make_view(spec, dev), _model(spec, dev, deg, max_deg), FUSED, syn.background(dev))
+        pg0 = render(syn.make_view(spec, dev), _model(spec, dev, deg, max_deg), GENERIC, syn.background(dev))
     rf, rg, rc = pf0["radii"].cpu().numpy(), pg0["radii"].cpu().numpy(), pc["radii"].numpy()
     m2d = pc["viewspace_points"].detach().numpy()
     mask, n1 = _pixel_mask(st, spec.H, spec.W, rf, rg, m2d)
@@ -93,8 +100,8 @@ def test_fused_render_matches_generic_path(cfg, deg):
     c = d[1] / nrm.clamp_min(1e-12)
     weights[6] *= ((nrm > 1e-2) & (d[0].abs() > 1e-3 * nrm) & (c.abs() < 0.998)).float()
     weights = weights.to(dev)
-    pf, gf = _run(spec, FUSED, dev, weights, deg)
-    pg, gg = _run(spec, GENERIC, dev, weights, deg)
+    pf, gf = _run(spec, FUSED, dev, weights, deg, max_deg)
+    pg, gg = _run(spec, GENERIC, dev, weights, deg, max_deg)
     assert torch.equal(pf["visibility_filter"], pf["radii"] > 0)
     ok = torch.from_numpy(~mask).to(dev)
     for k in ("render", "mask", "orient_conf"):
