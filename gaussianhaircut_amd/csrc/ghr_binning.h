@@ -17,14 +17,12 @@
 namespace ghr {
 
 #define GHR_SCAN_BLOCK 1024
-#define GHR_SORT_CAP 2048  // keys sorted in LDS (16 KiB); longer lists use the in-place global path
+#define GHR_SORT_CAP 1024  // keys one wave sorts in LDS (8.5 KiB); longer lists: k_tile_sort_big / the in-place global path
 #define GHR_SORT_BIG_CAP 8192   // keys per LDS block of k_tile_sort_big (64 KiB)
 #define GHR_SORT_BIG_BLOCK 1024
 #define GHR_SORT_BIG_MIN_AVG 256  // k_tile_sort_big is launched when the lists average at least this many instances
 #define GHR_SORT_DONE 0xffffffffu  // tile_cursor value k_tile_sort_big leaves for k_tile_sort: "this tile is sorted"
-#define GHR_SORT_BLOCK 256  // the sort is latency-bound (about one compare-exchange per thread and step at typical
-                            // list lengths): 16 KiB of LDS instead of 32 keeps 8 tiles in flight per CU (measured 72 -> 49 us;
-                            // 128-thread workgroups: 56 us)
+#define GHR_SORT_BLOCK 64   // one wave per tile (round 5; 256 threads and a barrier per step before)
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Exclusive scan of src[n] into dst[n] (may alias) by one 1024-thread workgroup; returns the total in every thread.
@@ -354,6 +352,164 @@ GHR_HD void bitonic_any_n(KeyPtr k, uint32_t n, int tid, int nthreads)
     GHR_SYNC();
 }
 
+// ---- the same kind of network, register-blocked (round 5) ---------------------------------------------------------------
+// The per-step form above moves every key through LDS once per compare-exchange step (16 B of LDS traffic per key and step):
+// at cfg3's list lengths that traffic -- not latency, not occupancy -- is what the tile sort waits for (profiles/r05u: removing
+// dependent global round trips or adding tiles in flight changed nothing).  Here a thread owns R = 2^r keys between one LDS
+// read and one LDS write and runs up to r consecutive steps of the network on them in registers: ceil(s / r) passes for a
+// stage of s steps instead of s.  Still the flip form (every compare-exchange moves the smaller key to the lower index, so
+// the virtual +inf padding beyond n never moves: positions >= n read as +inf and are never written).  Keys are unique
+// (depth | Gaussian), so ANY correct network leaves the same list: results are bit-identical to the per-step form's.
+GHR_HD void key_ce(uint64_t& lo, uint64_t& hi)  // smaller key to `lo`
+{
+    const uint64_t a = lo, b = hi;
+    const bool sw = b < a;
+    lo = sw ? b : a;
+    hi = sw ? a : b;
+}
+// LDS index of key i: one key of padding per 16 (a thread's contiguous chunk of R keys would otherwise put the lanes of a
+// wave R * 8 bytes apart: an R-way bank conflict)
+template <bool PAD>
+GHR_HD uint32_t key_slot(uint32_t i) { return PAD ? i + (i >> 4) : i; }
+#define GHR_KEY_INF 0xffffffffffffffffull
+
+// FULL: all np2 slots exist and the ones past n hold +inf (the kernel's LDS array): no bounds tests at all.  Otherwise
+// (tests/hostsim: a plain array of n keys) positions >= n read as +inf and are never written.
+// T consecutive disperse steps (partner distances 2^(lj + T - 1) ... 2^lj) on groups of 2^T keys {base + (m << lj)}
+template <int T, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_disperse_group(KeyPtr k, uint32_t n, uint32_t g, int lj)
+{
+    constexpr int G = 1 << T;
+    const uint32_t base = ((g >> lj) << (lj + T)) | (g & ((1u << lj) - 1u));
+    uint64_t v[G];
+    uint32_t at[G];
+#pragma unroll
+    for (int m = 0; m < G; m++) {
+        const uint32_t i = base + ((uint32_t)m << lj);
+        at[m] = key_slot<PAD>(i);
+        v[m] = (FULL || i < n) ? k[at[m]] : GHR_KEY_INF;
+    }
+#pragma unroll
+    for (int d = G / 2; d >= 1; d >>= 1)
+#pragma unroll
+        for (int m = 0; m < G; m++)
+            if (!(m & d)) key_ce(v[m], v[m + d]);
+#pragma unroll
+    for (int m = 0; m < G; m++)
+        if (FULL || base + ((uint32_t)m << lj) < n) k[at[m]] = v[m];
+}
+// the flip step of a stage of block size S = 2^ls and the T - 1 disperse steps behind it, on groups of 2^T keys:
+// {B + a + m * jl} and their mirror images {B + S - 1 - a - m * jl}, jl = S >> T
+template <int T, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_flip_group(KeyPtr k, uint32_t n, uint32_t g, int ls)
+{
+    constexpr int H = 1 << (T - 1);
+    const int ljl = ls - T;
+    const uint32_t B = (g >> ljl) << ls, a = g & ((1u << ljl) - 1u), top = B + (1u << ls) - 1u - a;
+    uint64_t x[H], y[H];  // x[m] ascending in index, y[m] descending
+    uint32_t ax[H], ay[H];
+#pragma unroll
+    for (int m = 0; m < H; m++) {
+        const uint32_t il = B + a + ((uint32_t)m << ljl), iu = top - ((uint32_t)m << ljl);
+        ax[m] = key_slot<PAD>(il);
+        ay[m] = key_slot<PAD>(iu);
+        x[m] = (FULL || il < n) ? k[ax[m]] : GHR_KEY_INF;
+        y[m] = (FULL || iu < n) ? k[ay[m]] : GHR_KEY_INF;
+    }
+#pragma unroll
+    for (int m = 0; m < H; m++) key_ce(x[m], y[m]);
+#pragma unroll
+    for (int d = H / 2; d >= 1; d >>= 1)
+#pragma unroll
+        for (int m = 0; m < H; m++)
+            if (!(m & d)) {
+                key_ce(x[m], x[m + d]);
+                key_ce(y[m + d], y[m]);  // y[m + d] is the LOWER index
+            }
+#pragma unroll
+    for (int m = 0; m < H; m++) {
+        if (FULL || B + a + ((uint32_t)m << ljl) < n) k[ax[m]] = x[m];
+        if (FULL || top - ((uint32_t)m << ljl) < n) k[ay[m]] = y[m];
+    }
+}
+// all stages up to block size R = 2^r on a thread's contiguous chunk of R keys
+template <int r, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_chunk_sort(KeyPtr k, uint32_t n, uint32_t c)
+{
+    constexpr int R = 1 << r;
+    uint64_t v[R];
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const uint32_t i = c * R + m;
+        v[m] = (FULL || i < n) ? k[key_slot<PAD>(i)] : GHR_KEY_INF;
+    }
+#pragma unroll
+    for (int S = 2; S <= R; S <<= 1) {
+#pragma unroll
+        for (int m = 0; m < R; m++) {  // flip: m <-> block end - offset
+            const int off = m & (S - 1);
+            if (off < S / 2) key_ce(v[m], v[(m - off) + (S - 1 - off)]);
+        }
+#pragma unroll
+        for (int d = S / 4; d >= 1; d >>= 1)
+#pragma unroll
+            for (int m = 0; m < R; m++)
+                if (!(m & d)) key_ce(v[m], v[m + d]);
+    }
+#pragma unroll
+    for (int m = 0; m < R; m++) {
+        const uint32_t i = c * R + m;
+        if (FULL || i < n) k[key_slot<PAD>(i)] = v[m];
+    }
+}
+// `t` disperse steps ending at distance 2^lj, every thread R keys per pass (R >> t groups of 2^t)
+template <int r, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_disperse_pass(KeyPtr k, uint32_t n, uint32_t np2, int t, int lj, int tid, int nthreads)
+{
+    constexpr int R = 1 << r;
+    for (uint32_t c = tid; c < np2 / R; c += nthreads) {
+        if (t == r) {
+            bitonic_disperse_group<r, PAD, FULL>(k, n, c, lj);
+        } else {
+            // (fewer steps left than a thread's keys allow: it takes R >> t smaller groups)
+            for (uint32_t q = 0; q < (uint32_t)(R >> t); q++) {
+                const uint32_t g = c * (uint32_t)(R >> t) + q;
+                if (t == 1) bitonic_disperse_group<1, PAD, FULL>(k, n, g, lj);
+                else if (t == 2) { if constexpr (r >= 2) bitonic_disperse_group<2, PAD, FULL>(k, n, g, lj); }
+                else if (t == 3) { if constexpr (r >= 3) bitonic_disperse_group<3, PAD, FULL>(k, n, g, lj); }
+            }
+        }
+    }
+}
+// the disperse steps of distances 2^(left-1) ... 1, r at a time (a synchronisation in front of every pass)
+template <int r, bool WAVE, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_disperse_tail(KeyPtr k, uint32_t n, uint32_t np2, int left, int tid, int nthreads)
+{
+    while (left > 0) {
+        const int t = left < r ? left : r;
+        left -= t;
+        if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
+        bitonic_disperse_pass<r, PAD, FULL>(k, n, np2, t, left, tid, nthreads);
+    }
+}
+// The whole sort.  r: log2 of the keys a thread owns (1..4); np2 = the power of two >= max(n, 2^r) keys are walked.  WAVE:
+// the workgroup is ONE wave (passes are separated by a wave-level fence instead of a barrier).
+template <int r, bool WAVE, bool PAD, bool FULL, typename KeyPtr>
+GHR_HD void bitonic_blocked(KeyPtr k, uint32_t n, int tid, int nthreads)
+{
+    constexpr int R = 1 << r;
+    uint32_t np2 = R;
+    int lp = r;
+    while (np2 < n) { np2 <<= 1; lp++; }
+    for (uint32_t c = tid; c < np2 / R; c += nthreads) bitonic_chunk_sort<r, PAD, FULL>(k, n, c);
+    for (int ls = r + 1; ls <= lp; ls++) {
+        if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
+        for (uint32_t g = tid; g < np2 / R; g += nthreads) bitonic_flip_group<r, PAD, FULL>(k, n, g, ls);
+        bitonic_disperse_tail<r, WAVE, PAD, FULL>(k, n, np2, ls - r, tid, nthreads);  // distances (S >> r) / 2 ... 1
+    }
+    if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
+}
+
 // Both sort kernels also write, for every instance, where its gradient line will be: inst_line[instance] = position in
 // the sorted lists (instances are numbered by rect4_slot; the lines lie in list order, ghr_device.h gather_inst_grads).
 GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* rects, uint32_t pos, uint32_t id, int tx,
@@ -364,21 +520,141 @@ GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* re
     if (inst < cap) inst_line[inst] = pos;
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// One wave sorts a list of up to 64 << r keys in LDS and writes it out (k_tile_sort).  Every phase keeps a lane's (up to)
+// 2^r memory operations in flight together: loads never sit under a branch (positions past n read the last key and drop it).
+template <int r>
+__device__ __forceinline__ void tile_sort_wave(uint64_t* g, uint32_t n, uint32_t s, uint64_t* s_keys, uint32_t* point_list,
+                                               uint32_t* inst_line, const rect4* __restrict__ rects, int tx, int ty,
+                                               uint32_t cap, int lane)
+{
+    constexpr int L = 1 << r;
+    uint64_t t[L];
+#pragma unroll
+    for (int q = 0; q < L; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        t[q] = g[i < n ? i : n - 1u];
+    }
+#pragma unroll
+    for (int q = 0; q < L; q++) {  // all 64 << r slots: the ones past n hold +inf, the network runs without bounds tests
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        s_keys[key_slot<true>(i)] = i < n ? t[q] : GHR_KEY_INF;
+    }
+    GHR_SYNC_WAVE();
+    if (n > 1) bitonic_blocked<r, true, true, true>(s_keys, n, lane, 64);
+    rect4 rc[L];
+#pragma unroll
+    for (int q = 0; q < L; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        t[q] = s_keys[key_slot<true>(i < n ? i : n - 1u)];
+        rc[q] = rects[(uint32_t)t[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < L; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        if (i < n) {
+            g[i] = t[q];
+            point_list[s + i] = (uint32_t)t[q];
+            const uint32_t inst = rect4_slot(rc[q], tx, ty);
+            if (inst < cap) inst_line[inst] = s + i;
+        }
+    }
+}
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// keys of one aligned block of the list (nb <= GHR_SORT_CAP of them) global <-> LDS, 16 per lane in flight
+__device__ __forceinline__ void sort_block_in(const uint64_t* g, uint32_t nb, uint64_t* s_keys, int lane)
+{
+    uint64_t t[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        t[q] = g[i < nb ? i : nb - 1u];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        s_keys[key_slot<true>(i)] = i < nb ? t[q] : GHR_KEY_INF;
+    }
+    GHR_SYNC_WAVE();
+}
+__device__ __forceinline__ void sort_block_out(uint64_t* g, uint32_t nb, const uint64_t* s_keys, int lane)
+{
+    GHR_SYNC_WAVE();
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const uint32_t i = (uint32_t)lane + 64u * q;
+        if (i < nb) g[i] = s_keys[key_slot<true>(i)];
+    }
+}
+// A list longer than GHR_SORT_CAP, by one wave (rare: dense tiles of dense scenes have gone through k_tile_sort_big).  Same
+// network: whatever stays inside an aligned block of GHR_SORT_CAP keys runs register-blocked in LDS, one load and one store
+// of the block per stage; only the steps whose partner distance reaches across blocks go through global memory.
+__device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uint64_t* s_keys, int lane)
+{
+    constexpr uint32_t C = GHR_SORT_CAP;
+    int logc = 0;
+    for (uint32_t j = C; j > 1; j >>= 1) logc++;
+    for (uint32_t b0 = 0; b0 < n; b0 += C) {
+        const uint32_t nb = min(C, n - b0);
+        sort_block_in(g + b0, nb, s_keys, lane);
+        bitonic_blocked<4, true, true, true>(s_keys, C, lane, 64);
+        sort_block_out(g + b0, nb, s_keys, lane);
+    }
+    uint32_t np2 = C;
+    while (np2 < n) np2 <<= 1;
+    auto global_step = [&](uint32_t size, uint32_t j) {  // j == 0: the flip of a stage of block size `size`; else disperse j
+        __syncthreads();  // (one wave: orders the global accesses of the previous step)
+        const uint32_t hs = size >> 1;
+        for (uint32_t i0 = lane; i0 < (np2 >> 1); i0 += 256u) {
+            uint32_t l[4], u[4];
+            uint64_t a[4], b[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t i = i0 + 64u * q;
+                if (j == 0u) { const uint32_t blk = i / hs, off = i - blk * hs; l[q] = blk * size + off; u[q] = blk * size + (size - 1u - off); }
+                else { l[q] = 2u * j * (i / j) + (i % j); u[q] = l[q] + j; }
+                const bool on = i < (np2 >> 1) && u[q] < n;
+                if (!on) { l[q] = 0u; u[q] = 0u; }  // reads key 0 twice, exchanges nothing
+                a[q] = g[l[q]];
+                b[q] = g[u[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (b[q] < a[q]) { g[l[q]] = b[q]; g[u[q]] = a[q]; }
+        }
+    };
+    for (uint32_t size = 2u * C; size <= np2; size <<= 1) {
+        global_step(size, 0u);
+        for (uint32_t j = size >> 2; j >= C; j >>= 1) global_step(size, j);
+        __syncthreads();
+        for (uint32_t b0 = 0; b0 < n; b0 += C) {
+            const uint32_t nb = min(C, n - b0);
+            sort_block_in(g + b0, nb, s_keys, lane);
+            bitonic_disperse_tail<4, true, true, true>(s_keys, C, C, logc, lane, 64);
+            sort_block_out(g + b0, nb, s_keys, lane);
+        }
+    }
+    __syncthreads();
+}
+#endif
+
+// ONE WAVE per tile (round 5; was four): lists up to GHR_SORT_CAP keys are sorted by the register-blocked network above in
+// 8.5 KiB of LDS with no workgroup barrier at all; the per-step form's LDS traffic was what the kernel waited for.
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                          uint32_t* tile_cursor, const rect4* __restrict__ rects,
                                                          uint32_t* inst_line, int gx, float* ginst,
                                                          const uint32_t* __restrict__ tile_order)
 {
-    __shared__ uint64_t s_keys[GHR_SORT_CAP];
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint64_t s_keys[GHR_SORT_CAP + GHR_SORT_CAP / 16 + 1];
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T);  // heaviest first (k_tile_scan)
     if (tile >= T) return;  // grid padding
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;
     const int tid = threadIdx.x;
-    // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may be
-    // replayed, e.g. after a too small speculative capacity) and a forward pass of its image workspace (a recycled one skips
-    // its zero-fill)
     // The tile's gradient lines are its n consecutive lines from s (they lie in list order): when the caller hands the
     // backward pass's scratch over, they are zeroed by this kernel, whose memory pipe is mostly idle (the backward render
     // kernel then starts accumulating at once: -10 % of its time inside the step).  As the workgroup's LAST act (round 5):
@@ -387,36 +663,31 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const 
     auto zero_lines = [&]() {
         if (ginst != nullptr) {
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
-                             // (same call: K8 190.9 -> 189.4 us, loss forward 69.2 -> 66.2, step 0.857 -> 0.850 ms)
             for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
         }
     };
     // (tile_cursor = tile_count[2][T]: [0] is back at 0 since k_tile_scan, [1] the big rects' append cursors / the DONE mark)
-    const bool sorted_already = tile_cursor[T + tile] == GHR_SORT_DONE;  // by k_tile_sort_big (read before the reset below)
-    __syncthreads();
+    // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may be
+    // replayed, e.g. after a too small speculative capacity) and a forward pass of its image workspace (a recycled one skips
+    // its zero-fill).  (One wave: the read below is one instruction of all lanes, the reset follows it in program order.)
+    const bool sorted_already = tile_cursor[T + tile] == GHR_SORT_DONE;  // by k_tile_sort_big
     if (tid == 0) tile_cursor[T + tile] = 0u;
     if (n == 0) return;
     if (sorted_already) { zero_lines(); return; }
     uint64_t* g = keys + s;
-    if (n <= GHR_SORT_CAP) {
-        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) s_keys[i] = g[i];
-        __syncthreads();
-        if (n > 1) bitonic_any_n<true>(s_keys, n, tid, GHR_SORT_BLOCK); else __syncthreads();
-        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK) {
-            const uint64_t k = s_keys[i];
-            g[i] = k;
-            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)k, tile % gx, tile / gx, cap);
-        }
-        zero_lines();
-    } else {
-        zero_lines();
-        // Rare: a single tile with more instances than fit in LDS.  Same network, in place in global memory
-        // (one workgroup => same CU/L1, __syncthreads orders the accesses).
-        __syncthreads();
-        bitonic_any_n<false>(g, n, tid, GHR_SORT_BLOCK);
+    const int tx = tile % gx, ty = tile / gx;
+    if (n <= 128u) tile_sort_wave<1>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else if (n <= 256u) tile_sort_wave<2>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else if (n <= 512u) tile_sort_wave<3>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else if (n <= GHR_SORT_CAP) tile_sort_wave<4>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else {
+        // Rare: a single tile with more instances than fit in LDS (and no k_tile_sort_big launch: sparse scene on average)
+        tile_sort_wave_long(g, n, s_keys, tid);
         for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK)
-            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], tile % gx, tile / gx, cap);
+            sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], tx, ty, cap);
     }
+    zero_lines();
+#endif
 }
 
 // Dense tiles (more than GHR_SORT_CAP instances; profiles/r02c: at the reference's strand-stage size the in-place global

@@ -319,6 +319,27 @@ int ghrsim_bitonic(uint64_t* keys, uint32_t n)
     return 1;
 }
 
+// the register-blocked form of the network (k_tile_sort's wave path): r = log2 of the keys a thread owns, `threads`
+// emulated one after the other inside each pass, `pad` = the LDS padding of the kernel (keys then live at key_slot<true>(i):
+// the caller's buffer must hold n + n / 16 + 1 keys).  Returns 1 if the result is ascending.
+int ghrsim_bitonic_blocked(uint64_t* keys, uint32_t n, int r, int threads)
+{
+    if (n > 1) {
+        for (int tid = 0; tid < 1; tid++) {  // (passes are separated by barriers: one "thread" walking all groups is the same)
+            switch (r) {
+            case 1: ghr::bitonic_blocked<1, false, false, false>(keys, n, 0, 1); break;
+            case 2: ghr::bitonic_blocked<2, false, false, false>(keys, n, 0, 1); break;
+            case 3: ghr::bitonic_blocked<3, false, false, false>(keys, n, 0, 1); break;
+            default: ghr::bitonic_blocked<4, false, false, false>(keys, n, 0, 1); break;
+            }
+        }
+    }
+    (void)threads;
+    for (uint32_t i = 1; i < n; i++)
+        if (keys[i - 1] > keys[i]) return 0;
+    return 1;
+}
+
 // ---- per-pixel / per-element arithmetic of the fused loss and of fused Adam (csrc/ghr_loss.h, csrc/ghr_adam.h) --------
 // out[i] = {l, dl/dd0, dl/dd1, dl/dconf} of the orientation term of one pixel
 void ghrsim_orient_pixel(int n, const float* d0, const float* d1, const float* conf, const float* gt, const float* m,

@@ -91,6 +91,21 @@ def test_bitonic_network_any_length(hostsim):
         np.testing.assert_array_equal(keys[:n], ref)
 
 
+@pytest.mark.parametrize("r", [1, 2, 3, 4])
+def test_register_blocked_bitonic_network_any_length(hostsim, r):
+    """k_tile_sort's wave path: a thread owns 2^r keys between LDS round trips and runs up to r steps on them in registers
+    (csrc/ghr_binning.h bitonic_blocked).  Every length, ties included, must come out as np.sort leaves it."""
+    import ctypes
+    rng = np.random.default_rng(r)
+    for n in list(range(0, 70)) + [127, 128, 129, 255, 256, 257, 511, 512, 513, 700, 1000, 1023, 1024, 1025, 3000]:
+        keys = rng.integers(0, 1 << 40, size=max(n, 1), dtype=np.uint64)
+        if n > 3 and n % 3 == 0:
+            keys[: n // 2] = keys[0]  # heavy ties
+        ref = np.sort(keys[:n])
+        assert hostsim.L.ghrsim_bitonic_blocked(ctypes.c_void_p(keys.ctypes.data), ctypes.c_uint32(n), r, 64) == 1, n
+        np.testing.assert_array_equal(keys[:n], ref)
+
+
 def test_alpha_bbox_is_conservative(hostsim):
     """The culling box AND the per-cell box+ellipse test of k_render_fwd / k_render_bwd must keep every pixel the per-pixel alpha test accepts,
     including needle-like conics, opacities at the 1/255 threshold, huge and degenerate splats."""
