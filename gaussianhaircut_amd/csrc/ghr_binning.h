@@ -22,7 +22,8 @@ namespace ghr {
 #define GHR_SORT_BIG_BLOCK 1024
 #define GHR_SORT_BIG_MIN_AVG 256  // k_tile_sort_big is launched when the lists average at least this many instances
 #define GHR_SORT_DONE 0xffffffffu  // tile_cursor value k_tile_sort_big leaves for k_tile_sort: "this tile is sorted"
-#define GHR_SORT_BLOCK 64   // one wave per tile (round 5; 256 threads and a barrier per step before)
+#define GHR_SORT_BLOCK 128  // two waves per tile (round 5; 256 threads and a barrier per step before)
+#define GHR_SORT_SOLO 256u  // lists up to this long are sorted by wave 0 alone
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // Exclusive scan of src[n] into dst[n] (may alias) by one 1024-thread workgroup; returns the total in every thread.
@@ -315,6 +316,9 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
         __builtin_amdgcn_wave_barrier();                          \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");    \
     } while (0)
+// one wave's own global stores complete (and visible to its later loads) before it goes on: no barrier -- the other waves
+// of the workgroup may have left already
+#define GHR_SYNC_GLOBAL_WAVE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
 #else
 #define GHR_SYNC() ((void)0)  // tests/hostsim runs the network with one "thread": steps are already ordered
 #define GHR_SYNC_WAVE() ((void)0)
@@ -367,6 +371,16 @@ GHR_HD void key_ce(uint64_t& lo, uint64_t& hi)  // smaller key to `lo`
     lo = sw ? b : a;
     hi = sw ? a : b;
 }
+// the same with the decision taken beforehand (the kernels decide all exchanges of a butterfly level first and move the keys
+// afterwards: one 64-bit compare per exchange instead of the two the compiler makes of key_ce, and independent compares
+// between a compare and the selects that wait for its mask)
+GHR_HD void key_swap_if(bool sw, uint64_t& lo, uint64_t& hi)
+{
+    const uint32_t al = (uint32_t)lo, ah = (uint32_t)(lo >> 32), bl = (uint32_t)hi, bh = (uint32_t)(hi >> 32);
+    const uint32_t ll = sw ? bl : al, lh = sw ? bh : ah, hl = sw ? al : bl, hh = sw ? ah : bh;
+    lo = ((uint64_t)lh << 32) | ll;
+    hi = ((uint64_t)hh << 32) | hl;
+}
 // LDS index of key i: one key of padding per 16 (a thread's contiguous chunk of R keys would otherwise put the lanes of a
 // wave R * 8 bytes apart: an R-way bank conflict)
 template <bool PAD>
@@ -390,10 +404,15 @@ GHR_HD void bitonic_disperse_group(KeyPtr k, uint32_t n, uint32_t g, int lj)
         v[m] = (FULL || i < n) ? k[at[m]] : GHR_KEY_INF;
     }
 #pragma unroll
-    for (int d = G / 2; d >= 1; d >>= 1)
+    for (int d = G / 2; d >= 1; d >>= 1) {
+        bool sw[G];
 #pragma unroll
         for (int m = 0; m < G; m++)
-            if (!(m & d)) key_ce(v[m], v[m + d]);
+            if (!(m & d)) sw[m] = v[m + d] < v[m];
+#pragma unroll
+        for (int m = 0; m < G; m++)
+            if (!(m & d)) key_swap_if(sw[m], v[m], v[m + d]);
+    }
 #pragma unroll
     for (int m = 0; m < G; m++)
         if (FULL || base + ((uint32_t)m << lj) < n) k[at[m]] = v[m];
@@ -416,16 +435,23 @@ GHR_HD void bitonic_flip_group(KeyPtr k, uint32_t n, uint32_t g, int ls)
         x[m] = (FULL || il < n) ? k[ax[m]] : GHR_KEY_INF;
         y[m] = (FULL || iu < n) ? k[ay[m]] : GHR_KEY_INF;
     }
+    {
+        bool sw[H];
 #pragma unroll
-    for (int m = 0; m < H; m++) key_ce(x[m], y[m]);
+        for (int m = 0; m < H; m++) sw[m] = y[m] < x[m];
 #pragma unroll
-    for (int d = H / 2; d >= 1; d >>= 1)
+        for (int m = 0; m < H; m++) key_swap_if(sw[m], x[m], y[m]);
+    }
+#pragma unroll
+    for (int d = H / 2; d >= 1; d >>= 1) {
+        bool sx[H], sy[H];
 #pragma unroll
         for (int m = 0; m < H; m++)
-            if (!(m & d)) {
-                key_ce(x[m], x[m + d]);
-                key_ce(y[m + d], y[m]);  // y[m + d] is the LOWER index
-            }
+            if (!(m & d)) { sx[m] = x[m + d] < x[m]; sy[m] = y[m] < y[m + d]; }  // y[m + d] is the LOWER index
+#pragma unroll
+        for (int m = 0; m < H; m++)
+            if (!(m & d)) { key_swap_if(sx[m], x[m], x[m + d]); key_swap_if(sy[m], y[m + d], y[m]); }
+    }
 #pragma unroll
     for (int m = 0; m < H; m++) {
         if (FULL || B + a + ((uint32_t)m << ljl) < n) k[ax[m]] = x[m];
@@ -445,16 +471,26 @@ GHR_HD void bitonic_chunk_sort(KeyPtr k, uint32_t n, uint32_t c)
     }
 #pragma unroll
     for (int S = 2; S <= R; S <<= 1) {
+        bool sw[R];
 #pragma unroll
         for (int m = 0; m < R; m++) {  // flip: m <-> block end - offset
             const int off = m & (S - 1);
-            if (off < S / 2) key_ce(v[m], v[(m - off) + (S - 1 - off)]);
+            if (off < S / 2) sw[m] = v[(m - off) + (S - 1 - off)] < v[m];
         }
 #pragma unroll
-        for (int d = S / 4; d >= 1; d >>= 1)
+        for (int m = 0; m < R; m++) {
+            const int off = m & (S - 1);
+            if (off < S / 2) key_swap_if(sw[m], v[m], v[(m - off) + (S - 1 - off)]);
+        }
+#pragma unroll
+        for (int d = S / 4; d >= 1; d >>= 1) {
 #pragma unroll
             for (int m = 0; m < R; m++)
-                if (!(m & d)) key_ce(v[m], v[m + d]);
+                if (!(m & d)) sw[m] = v[m + d] < v[m];
+#pragma unroll
+            for (int m = 0; m < R; m++)
+                if (!(m & d)) key_swap_if(sw[m], v[m], v[m + d]);
+        }
     }
 #pragma unroll
     for (int m = 0; m < R; m++) {
@@ -521,37 +557,41 @@ GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* re
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// One wave sorts a list of up to 64 << r keys in LDS and writes it out (k_tile_sort).  Every phase keeps a lane's (up to)
-// 2^r memory operations in flight together: loads never sit under a branch (positions past n read the last key and drop it).
-template <int r>
-__device__ __forceinline__ void tile_sort_wave(uint64_t* g, uint32_t n, uint32_t s, uint64_t* s_keys, uint32_t* point_list,
-                                               uint32_t* inst_line, const rect4* __restrict__ rects, int tx, int ty,
-                                               uint32_t cap, int lane)
+// NT threads (one wave: NT = 64, separated by wave-level fences; or NT / 64 cooperating waves, separated by barriers) sort a
+// list of up to NT << r keys in LDS and write it out (k_tile_sort).  Every phase keeps a thread's (up to) 2^r memory
+// operations in flight together: loads never sit under a branch (positions past n read the last key and drop it).
+template <int r, int NT>
+__device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_t s, uint64_t* s_keys, uint32_t* point_list,
+                                                uint32_t* inst_line, const rect4* __restrict__ rects, int tx, int ty,
+                                                uint32_t cap, int t_)
 {
     constexpr int L = 1 << r;
+    constexpr bool WAVE = NT == 64;
     uint64_t t[L];
 #pragma unroll
     for (int q = 0; q < L; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * q;
+        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
         t[q] = g[i < n ? i : n - 1u];
     }
 #pragma unroll
-    for (int q = 0; q < L; q++) {  // all 64 << r slots: the ones past n hold +inf, the network runs without bounds tests
-        const uint32_t i = (uint32_t)lane + 64u * q;
+    for (int q = 0; q < L; q++) {  // all NT << r slots: the ones past n hold +inf, the network runs without bounds tests
+        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
         s_keys[key_slot<true>(i)] = i < n ? t[q] : GHR_KEY_INF;
     }
-    GHR_SYNC_WAVE();
-    if (n > 1) bitonic_blocked<r, true, true, true>(s_keys, n, lane, 64);
+    if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
+#if !defined(GHR_SORT_SKIP_NETWORK)
+    if (n > 1) bitonic_blocked<r, WAVE, true, true>(s_keys, n, t_, NT);
+#endif
     rect4 rc[L];
 #pragma unroll
     for (int q = 0; q < L; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * q;
+        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
         t[q] = s_keys[key_slot<true>(i < n ? i : n - 1u)];
         rc[q] = rects[(uint32_t)t[q]];
     }
 #pragma unroll
     for (int q = 0; q < L; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * q;
+        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
         if (i < n) {
             g[i] = t[q];
             point_list[s + i] = (uint32_t)t[q];
@@ -563,49 +603,53 @@ __device__ __forceinline__ void tile_sort_wave(uint64_t* g, uint32_t n, uint32_t
 #endif
 
 #if defined(__HIP_DEVICE_COMPILE__)
-// keys of one aligned block of the list (nb <= GHR_SORT_CAP of them) global <-> LDS, 16 per lane in flight
+// keys of one aligned block of the list (nb <= C of them) global <-> LDS, C / 64 per lane in flight
+template <int C>
 __device__ __forceinline__ void sort_block_in(const uint64_t* g, uint32_t nb, uint64_t* s_keys, int lane)
 {
-    uint64_t t[16];
+    uint64_t t[C / 64];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < C / 64; q++) {
         const uint32_t i = (uint32_t)lane + 64u * q;
         t[q] = g[i < nb ? i : nb - 1u];
     }
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < C / 64; q++) {
         const uint32_t i = (uint32_t)lane + 64u * q;
         s_keys[key_slot<true>(i)] = i < nb ? t[q] : GHR_KEY_INF;
     }
     GHR_SYNC_WAVE();
 }
+template <int C>
 __device__ __forceinline__ void sort_block_out(uint64_t* g, uint32_t nb, const uint64_t* s_keys, int lane)
 {
     GHR_SYNC_WAVE();
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
+    for (int q = 0; q < C / 64; q++) {
         const uint32_t i = (uint32_t)lane + 64u * q;
         if (i < nb) g[i] = s_keys[key_slot<true>(i)];
     }
 }
-// A list longer than GHR_SORT_CAP, by one wave (rare: dense tiles of dense scenes have gone through k_tile_sort_big).  Same
-// network: whatever stays inside an aligned block of GHR_SORT_CAP keys runs register-blocked in LDS, one load and one store
-// of the block per stage; only the steps whose partner distance reaches across blocks go through global memory.
+// A list longer than the kernel's LDS holds (C keys), by one wave (rare: dense tiles of dense scenes have gone through
+// k_tile_sort_big).  Same network: whatever stays inside an aligned block of C keys runs register-blocked in LDS, one load and
+// one store of the block per stage; only the steps whose partner distance reaches across blocks go through global memory.
+template <int CAP>
 __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uint64_t* s_keys, int lane)
 {
-    constexpr uint32_t C = GHR_SORT_CAP;
+    constexpr uint32_t C = CAP;
+    constexpr int RB = CAP >= 1024 ? 4 : 3;  // keys per lane = 2^RB = C / 64
     int logc = 0;
     for (uint32_t j = C; j > 1; j >>= 1) logc++;
     for (uint32_t b0 = 0; b0 < n; b0 += C) {
         const uint32_t nb = min(C, n - b0);
-        sort_block_in(g + b0, nb, s_keys, lane);
-        bitonic_blocked<4, true, true, true>(s_keys, C, lane, 64);
-        sort_block_out(g + b0, nb, s_keys, lane);
+        sort_block_in<CAP>(g + b0, nb, s_keys, lane);
+        bitonic_blocked<RB, true, true, true>(s_keys, C, lane, 64);
+        sort_block_out<CAP>(g + b0, nb, s_keys, lane);
     }
     uint32_t np2 = C;
     while (np2 < n) np2 <<= 1;
     auto global_step = [&](uint32_t size, uint32_t j) {  // j == 0: the flip of a stage of block size `size`; else disperse j
-        __syncthreads();  // (one wave: orders the global accesses of the previous step)
+        GHR_SYNC_GLOBAL_WAVE();  // (orders the wave's global accesses of the previous step)
         const uint32_t hs = size >> 1;
         for (uint32_t i0 = lane; i0 < (np2 >> 1); i0 += 256u) {
             uint32_t l[4], u[4];
@@ -628,65 +672,64 @@ __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uin
     for (uint32_t size = 2u * C; size <= np2; size <<= 1) {
         global_step(size, 0u);
         for (uint32_t j = size >> 2; j >= C; j >>= 1) global_step(size, j);
-        __syncthreads();
+        GHR_SYNC_GLOBAL_WAVE();
         for (uint32_t b0 = 0; b0 < n; b0 += C) {
             const uint32_t nb = min(C, n - b0);
-            sort_block_in(g + b0, nb, s_keys, lane);
-            bitonic_disperse_tail<4, true, true, true>(s_keys, C, C, logc, lane, 64);
-            sort_block_out(g + b0, nb, s_keys, lane);
+            sort_block_in<CAP>(g + b0, nb, s_keys, lane);
+            bitonic_disperse_tail<RB, true, true, true>(s_keys, C, C, logc, lane, 64);
+            sort_block_out<CAP>(g + b0, nb, s_keys, lane);
         }
     }
-    __syncthreads();
+    GHR_SYNC_GLOBAL_WAVE();
 }
 #endif
 
-// ONE WAVE per tile (round 5; was four): lists up to GHR_SORT_CAP keys are sorted by the register-blocked network above in
-// 8.5 KiB of LDS with no workgroup barrier at all; the per-step form's LDS traffic was what the kernel waited for.
+// TWO waves per tile (round 5; four before, each moving every key through LDS once per compare-exchange step): lists are sorted
+// by the register-blocked network above.  Short lists (<= GHR_SORT_SOLO keys: 7 of 10 tiles of cfg3) by wave 0 alone, no
+// barrier at all, while wave 1 zero-fills the tile's gradient lines and leaves; longer ones by both waves (a wave per tile
+// throughout was measured too: the longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
+// (8.5 KiB); longer lists: tile_sort_wave_long.
+template <int CAP>
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                          uint32_t* tile_cursor, const rect4* __restrict__ rects,
-                                                         uint32_t* inst_line, int gx, float* ginst,
+                                                         uint32_t* inst_line, int gx,
                                                          const uint32_t* __restrict__ tile_order)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ uint64_t s_keys[GHR_SORT_CAP + GHR_SORT_CAP / 16 + 1];
+    static_assert(GHR_SORT_BLOCK == 128 && CAP == 1024, "two waves, 8 keys per thread at most");
+    __shared__ uint64_t s_keys[CAP + CAP / 16 + 1];
     const uint32_t tile = tile_order ? tile_order[blockIdx.x] : xcd_tile(blockIdx.x, T);  // heaviest first (k_tile_scan)
     if (tile >= T) return;  // grid padding
     const uint32_t s = min(tile_start[tile], cap);
     const uint32_t n = min(tile_start[tile + 1], cap) - s;
-    const int tid = threadIdx.x;
-    // The tile's gradient lines are its n consecutive lines from s (they lie in list order): when the caller hands the
-    // backward pass's scratch over, they are zeroed by this kernel, whose memory pipe is mostly idle (the backward render
-    // kernel then starts accumulating at once: -10 % of its time inside the step).  As the workgroup's LAST act (round 5):
-    // stores count in vmcnt like loads, so issued first -- "under the sort's LDS round trips" -- every later wait for a
-    // load (keys, rects) also waited for their acknowledgements: 46.4 -> 42.6 us (44.4 behind the key loads; profiles/r05u).
-    auto zero_lines = [&]() {
-        if (ginst != nullptr) {
-            const f4 zero = {0.f, 0.f, 0.f, 0.f};
-            for (uint32_t i = tid; i < 4u * n; i += GHR_SORT_BLOCK) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)s + i);
-        }
-    };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // (tile_cursor = tile_count[2][T]: [0] is back at 0 since k_tile_scan, [1] the big rects' append cursors / the DONE mark)
     // k_scatter is done with this tile's append cursor: leave it at 0, the state stage 2 expects on entry (stage 2 may be
     // replayed, e.g. after a too small speculative capacity) and a forward pass of its image workspace (a recycled one skips
-    // its zero-fill).  (One wave: the read below is one instruction of all lanes, the reset follows it in program order.)
+    // its zero-fill).  Read by both waves, then -- behind a barrier both reach -- reset by thread 0.
     const bool sorted_already = tile_cursor[T + tile] == GHR_SORT_DONE;  // by k_tile_sort_big
+    __syncthreads();
     if (tid == 0) tile_cursor[T + tile] = 0u;
     if (n == 0) return;
-    if (sorted_already) { zero_lines(); return; }
+    if (sorted_already) return;
     uint64_t* g = keys + s;
     const int tx = tile % gx, ty = tile / gx;
-    if (n <= 128u) tile_sort_wave<1>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
-    else if (n <= 256u) tile_sort_wave<2>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
-    else if (n <= 512u) tile_sort_wave<3>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
-    else if (n <= GHR_SORT_CAP) tile_sort_wave<4>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    if (n <= GHR_SORT_SOLO) {
+        if (wave == 1) return;
+        if (n <= 128u) tile_sort_group<1, 64>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
+        else tile_sort_group<2, 64>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
+        return;
+    }
+    if (n <= 512u) tile_sort_group<2, 128>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else if (n <= 1024u) tile_sort_group<3, 128>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
     else {
         // Rare: a single tile with more instances than fit in LDS (and no k_tile_sort_big launch: sparse scene on average)
-        tile_sort_wave_long(g, n, s_keys, tid);
-        for (uint32_t i = tid; i < n; i += GHR_SORT_BLOCK)
+        if (wave == 1) return;
+        tile_sort_wave_long<CAP>(g, n, s_keys, lane);
+        for (uint32_t i = lane; i < n; i += 64)
             sort_emit(point_list, inst_line, rects, s + i, (uint32_t)g[i], tx, ty, cap);
     }
-    zero_lines();
 #endif
 }
 

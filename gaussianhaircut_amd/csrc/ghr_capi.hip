@@ -293,17 +293,18 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // dense scenes (long lists on average) first get their dense tiles sorted in big LDS blocks; the regular kernel
         // then passes those by.  R is the capacity here, an upper bound of the count: a guess that is too high only
         // costs an idle 3-us launch.
-        if ((size_t)R >= (size_t)GHR_SORT_BIG_MIN_AVG * (size_t)T)
+        const bool dense = (size_t)R >= (size_t)GHR_SORT_BIG_MIN_AVG * (size_t)T;
+        if (dense)
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
                                im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
-        hipLaunchKernelGGL(ghr::k_tile_sort, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
-                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, grad_scratch,
+        hipLaunchKernelGGL(ghr::k_tile_sort<1024>, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
+                           im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx,
                            order_ptr(im.tile_order, 0));
     }
     if (g_ev[0]) GHR_HIP(hipEventRecord(g_ev[0], s));
     hipLaunchKernelGGL(ghr::k_render_fwd, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_BLOCK), 0, s, a->W, a->H, gx,
                        (uint32_t)T, im.tile_start, b.point_list, g.rec, a->background, out_color, im.final_T,
-                       im.n_contrib, R, b.cell_mask, im.cell_last, order_ptr(im.tile_order, 1));
+                       im.n_contrib, R, b.cell_mask, im.cell_last, order_ptr(im.tile_order, 1), grad_scratch);
     if (g_ev[1]) GHR_HIP(hipEventRecord(g_ev[1], s));
     return finish(s, a->debug);
 }

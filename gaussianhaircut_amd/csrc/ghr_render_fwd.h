@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
                                                           uint32_t* __restrict__ n_contrib, uint32_t cap,
                                                           unsigned long long* __restrict__ cell_mask,
                                                           uint32_t* __restrict__ cell_last,
-                                                          const uint32_t* __restrict__ tile_order)
+                                                          const uint32_t* __restrict__ tile_order, float* ginst)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ f4 s_r0[GHR_BLOCK], s_r1[GHR_BLOCK], s_r2[GHR_BLOCK], s_r3[GHR_BLOCK], s_bb[GHR_BLOCK], s_ep[GHR_BLOCK];
@@ -167,6 +167,16 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_render_fwd(int W, int H, int gx, 
         n_contrib[pix] = st.last;
 #pragma unroll
         for (int c = 0; c < GHR_C; c++) out_color[c * plane + pix] = st.C[c] + st.T * bg[c];
+    }
+    // The tile's gradient lines are its n consecutive lines from `beg` (they lie in list order): when the caller hands the
+    // backward pass's scratch over they are zeroed HERE, as the workgroup's last act (the backward render kernel then starts
+    // accumulating at once).  This kernel is bound by instruction issue and leaves two thirds of the memory pipe idle; the
+    // stores are behind every load of the workgroup, so nothing waits for their acknowledgement.  (Rounds 3-5 had them in the
+    // tile sort: 83 MB that had become more than half of that kernel's time once its network was register-blocked.)
+    if (ginst != nullptr) {
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        for (uint32_t i = tid; i < 4u * n; i += GHR_BLOCK)
+            __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(ginst) + 4 * (size_t)beg + i);
     }
     GHR_PROF(5);
 #ifdef GHR_K7_PROF
