@@ -582,21 +582,27 @@ __device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_
 #if !defined(GHR_SORT_SKIP_NETWORK)
     if (n > 1) bitonic_blocked<r, WAVE, true, true>(s_keys, n, t_, NT);
 #endif
-    rect4 rc[L];
+    // (four entries at a time: the rect gather of more would set the kernel's register count)
+    constexpr int E = L < 4 ? L : 4;
 #pragma unroll
-    for (int q = 0; q < L; q++) {
-        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
-        t[q] = s_keys[key_slot<true>(i < n ? i : n - 1u)];
-        rc[q] = rects[(uint32_t)t[q]];
-    }
+    for (int h = 0; h < L; h += E) {
+        uint64_t kq[E];
+        rect4 rc[E];
 #pragma unroll
-    for (int q = 0; q < L; q++) {
-        const uint32_t i = (uint32_t)t_ + (uint32_t)NT * q;
-        if (i < n) {
-            g[i] = t[q];
-            point_list[s + i] = (uint32_t)t[q];
-            const uint32_t inst = rect4_slot(rc[q], tx, ty);
-            if (inst < cap) inst_line[inst] = s + i;
+        for (int q = 0; q < E; q++) {
+            const uint32_t i = (uint32_t)t_ + (uint32_t)NT * (h + q);
+            kq[q] = s_keys[key_slot<true>(i < n ? i : n - 1u)];
+            rc[q] = rects[(uint32_t)kq[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < E; q++) {
+            const uint32_t i = (uint32_t)t_ + (uint32_t)NT * (h + q);
+            if (i < n) {
+                g[i] = kq[q];
+                point_list[s + i] = (uint32_t)kq[q];
+                const uint32_t inst = rect4_slot(rc[q], tx, ty);
+                if (inst < cap) inst_line[inst] = s + i;
+            }
         }
     }
 }
@@ -607,16 +613,18 @@ __device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_
 template <int C>
 __device__ __forceinline__ void sort_block_in(const uint64_t* g, uint32_t nb, uint64_t* s_keys, int lane)
 {
-    uint64_t t[C / 64];
+    for (int h = 0; h < C / 64; h += 8) {  // (eight loads in flight at a time)
+        uint64_t t[8];
 #pragma unroll
-    for (int q = 0; q < C / 64; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * q;
-        t[q] = g[i < nb ? i : nb - 1u];
-    }
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = (uint32_t)lane + 64u * (h + q);
+            t[q] = g[i < nb ? i : nb - 1u];
+        }
 #pragma unroll
-    for (int q = 0; q < C / 64; q++) {
-        const uint32_t i = (uint32_t)lane + 64u * q;
-        s_keys[key_slot<true>(i)] = i < nb ? t[q] : GHR_KEY_INF;
+        for (int q = 0; q < 8; q++) {
+            const uint32_t i = (uint32_t)lane + 64u * (h + q);
+            s_keys[key_slot<true>(i)] = i < nb ? t[q] : GHR_KEY_INF;
+        }
     }
     GHR_SYNC_WAVE();
 }
@@ -637,7 +645,8 @@ template <int CAP>
 __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uint64_t* s_keys, int lane)
 {
     constexpr uint32_t C = CAP;
-    constexpr int RB = CAP >= 1024 ? 4 : 3;  // keys per lane = 2^RB = C / 64
+    constexpr int RB = 3;  // 8 keys per lane and pass (two turns per pass at C = 1024: this rare path must not set the
+                           // kernel's register count)
     int logc = 0;
     for (uint32_t j = C; j > 1; j >>= 1) logc++;
     for (uint32_t b0 = 0; b0 < n; b0 += C) {
@@ -689,8 +698,11 @@ __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uin
 // barrier at all, while wave 1 zero-fills the tile's gradient lines and leaves; longer ones by both waves (a wave per tile
 // throughout was measured too: the longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
 // (8.5 KiB); longer lists: tile_sort_wave_long.
+#ifndef GHR_SORT_WAVES
+#define GHR_SORT_WAVES 6  // 80 VGPRs, no spills: 26.1 us (8: 64 VGPRs + 8 spilled dwords 26.8; 5: 27.4; profiles/r05u)
+#endif
 template <int CAP>
-__global__ void __launch_bounds__(GHR_SORT_BLOCK) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
+__global__ void __launch_bounds__(GHR_SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(GHR_SORT_WAVES, 8))) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                          uint32_t* tile_cursor, const rect4* __restrict__ rects,
                                                          uint32_t* inst_line, int gx,
