@@ -212,7 +212,7 @@ def main():
                         "retires ~17 G of them per second (profiles/r04k: 2.96 M hits = 0.174 ms on this workload; four more "
                         "per chunk cost 2.7x), with the wave's issue chain (~0.17 ms) and the chunk arithmetic (0.117 ms of "
                         "VALU) right behind; every L2 atomic is written through to HBM, hence traffic > algorithmic bytes; "
-                        "the zero-fill of the gradient lines runs under the forward pass's tile sort; DESIGN.md 10 / 11); "
+                        "the zero-fill of the gradient lines is the forward render kernel's last act; DESIGN.md 10 / 11); "
                         "algorithmic bytes 132 R + 48 N + 8 T per SURVEY.md 8(d) with R, N, T "
                         "of the measured view; kernel duration from HIP events the library records around the kernel on its "
                         "launch stream, %d solo passes" % n_ev}
