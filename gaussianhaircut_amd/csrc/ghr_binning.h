@@ -247,20 +247,22 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
                                                        const uint32_t* __restrict__ pos, uint64_t* keys, uint32_t cap)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    // A wavefront serves 16 Gaussians: lane = 16*q + i handles the rect ordinals q, q+4 of Gaussian i.  Small rects (up to
-    // GHR_BIG_RECT = 8 tiles): the instance's place in its tile's list was handed out by K1's counting atomic (count_tiles:
-    // pos[i][ordinal]) -- one gather of tile_start, one 8-B store, no atomic (round 5).
-    const int lane = threadIdx.x & 63, q = lane >> 4;
-    const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 16) + (lane & 15);
+    // A wavefront serves 32 Gaussians: lane = 32*q + i handles the rect ordinals q, q+2 of Gaussian i -- and q+4, q+6 in a second
+    // turn that only waves holding a rect of more than four tiles take (strand needles: 99.6 % of the rects have up to four;
+    // 16 Gaussians x 4 lanes x two ordinals before: cfg3 18.5 -> 15.9 us, cfg2's blobs 25.8 -> 25.7, profiles/r05u).
+    // Small rects (up to GHR_BIG_RECT = 8 tiles): the instance's place in its tile's list was handed out by K1's counting atomic
+    // (count_tiles: pos[i][ordinal]) -- one gather of tile_start, one 8-B store, no atomic (round 5).
+    const int lane = threadIdx.x & 63, q = lane >> 5;
+    const int idx = (int)((blockIdx.x * (GHR_BLOCK / 64) + (threadIdx.x >> 6)) * 32) + (lane & 31);
     rect4 r = rect4{0u, 0u, 0u, 0u};
     uint32_t sb = 0u, pq0 = 0u, pq1 = 0u;
     float dep = 0.f;
-    if (idx < P) {  // (all the loads together: one round trip; the two positions of a culled / big rect are never used)
+    if (idx < P) {  // (all the loads together: one round trip; the positions of a culled / big rect are never used)
         r = rects[idx];
         sb = slot_blk[idx >> 8];
         dep = depths[idx];
         pq0 = pos[(size_t)GHR_BIG_RECT * idx + q];
-        pq1 = pos[(size_t)GHR_BIG_RECT * idx + q + 4];
+        pq1 = pos[(size_t)GHR_BIG_RECT * idx + q + 2];
     }
     if (idx < P && q == 0) rects[idx].w = sb;  // gradient-slot base of the Gaussian's K1 workgroup (idempotent)
     const int x0 = r.x & 0xffffu, x1 = r.x >> 16, y0 = r.y & 0xffffu, y1 = r.y >> 16;
@@ -268,19 +270,25 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_scatter(int P, int gx, rect4* rec
     const bool big = full > GHR_BIG_RECT;  // expanded by the whole workgroup below
     const int area = big ? 0 : full;
     const uint64_t key = full ? (((uint64_t)__float_as_uint(dep) << 32) | (uint32_t)idx) : 0ull;
-    static_assert(GHR_BIG_RECT == 8, "two ordinals per lane: q and q + 4");
-    {
+    static_assert(GHR_BIG_RECT == 8, "four ordinals per lane: q, q + 2, q + 4, q + 6");
+    auto place = [&](int k0, int k1, uint32_t pa, uint32_t pb) {
         // ordinal k -> tile (row-major inside the rect, as count_tiles walks it); w >= 1 when area > 0
-        const bool on0 = q < area, on1 = q + 4 < area;
-        const int ky0 = on0 ? q / w : 0, kx0 = q - ky0 * w;
-        const int ky1 = on1 ? (q + 4) / w : 0, kx1 = q + 4 - ky1 * w;
+        const bool on0 = k0 < area, on1 = k1 < area;
+        const int ky0 = on0 ? k0 / w : 0, kx0 = k0 - ky0 * w;
+        const int ky1 = on1 ? k1 / w : 0, kx1 = k1 - ky1 * w;
         const int t0 = (y0 + ky0) * gx + x0 + kx0, t1 = (y0 + ky1) * gx + x0 + kx1;
         const uint32_t s0 = on0 ? tile_start[t0] : 0u, s1 = on1 ? tile_start[t1] : 0u;
-        const uint32_t p0 = s0 + pq0, p1 = s1 + pq1;
+        const uint32_t p0 = s0 + pa, p1 = s1 + pb;
         if (on0 && p0 < cap) keys[p0] = key;  // cap: see ghr_forward_stage2
         if (on1 && p1 < cap) keys[p1] = key;
+    };
+    place(q, q + 2, pq0, pq1);
+    if (__builtin_amdgcn_ballot_w64(area > 4) != 0ull) {  // wave-uniform
+        uint32_t pq2 = 0u, pq3 = 0u;
+        if (area > 4) { pq2 = pos[(size_t)GHR_BIG_RECT * idx + q + 4]; pq3 = pos[(size_t)GHR_BIG_RECT * idx + q + 6]; }
+        place(q + 4, q + 6, pq2, pq3);
     }
-    // big rects: every Gaussian is held by the four lanes i, i+16, i+32, i+48 -- row 0 speaks for it; the workgroup's big
+    // big rects: every Gaussian is held by the two lanes i, i+32 -- the first speaks for it; the workgroup's big
     // rects are expanded together, load-balanced (BigRects), two instances per thread and trip so that their returning
     // atomics are in flight together.  They go BEHIND the tile's small-rect instances: small_cnt[t] of those, then the
     // append cursor (the second plane of tile_count, at 0 on entry: k_tile_scan / the tile sort leave it there)

@@ -288,7 +288,8 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
     carve_bin(bin_ws ? align_base(bin_ws) : nullptr, (size_t)R, (size_t)T, &b);
     if (R > 0) {
         // append cursors are 0 on entry: k_tile_scan leaves them there and k_tile_sort resets them (replay-safe)
-        hipLaunchKernelGGL(ghr::k_scatter, dim3((a->P + 63) / 64), dim3(GHR_BLOCK), 0, s, a->P, gx,
+        const int scatter_blocks = (a->P + 127) / 128;  // a wave serves 32 Gaussians
+        hipLaunchKernelGGL(ghr::k_scatter, dim3(scatter_blocks), dim3(GHR_BLOCK), 0, s, a->P, gx,
                            g.rects, g.slot_blk, g.depths, im.tile_start, im.tile_count, (uint32_t)T, im.small_cnt, g.pos, b.keys, R);
         // dense scenes (long lists on average) first get their dense tiles sorted in big LDS blocks; the regular kernel
         // then passes those by.  R is the capacity here, an upper bound of the count: a guess that is too high only
