@@ -141,7 +141,7 @@ int ghr_backward_ex(void* stream, const ghr_view_args* a, uint32_t R, const int3
 typedef struct ghr_model_args {
     int32_t P, W, H;
     int32_t sh_degree;            /* active SH degree 0..3 */
-    int32_t sh_coeffs;            /* K = (max_sh_degree + 1)^2 <= 16 */
+    int32_t sh_coeffs;            /* K = (max_sh_degree + 1)^2: 1, 4, 9 or 16 (anything else: GHR_E_INVALID) */
     const float* xyz;             /* [P,3]   _xyz */
     const float* log_scales;      /* [P,3]   _scaling (exp activation) */
     const float* rotations;       /* [P,4]   _rotation, raw (normalised in-kernel like build_rotation) */
