@@ -5,6 +5,7 @@ cd ${GRAFT_REPO_ROOT:-/root/repo}
 TAG=${1:-r05}
 P=$PWD/gpurun_out/profiles; mkdir -p $P gpurun_out/tests; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 R=$PWD
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print(\"smoke ok\")" 2>&1 | tail -2
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -40 > gpurun_out/tests/pytest.log; tail -3 gpurun_out/tests/pytest.log
 timeout 600 python bench.py --steps 20 --warmup 5 > $P/${TAG}_bench.json 2> $P/${TAG}_bench.err; echo "bench rc=$?"
 B="python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-op-only --streams 1 --shard-views 0"
