@@ -20,7 +20,7 @@ def main():
     bench.main()
     L = _lib.lib()
     assert hasattr(L, "ghr_debug_prof"), "not a -DGHR_K8_PROF build"
-    n_waves = 4 * ((P_MODEL + 255) // 256)
+    n_waves = 65536  # (k_project: slot 4 b + wave; k_project_bwd, one wave per workgroup: slot 4 b; unused slots stay 0)
     buf = np.zeros((65536, 8), np.uint64)
     rc = L.ghr_debug_prof(ctypes.c_void_p(buf.ctypes.data), 65536, 0)
     assert rc == 0, rc
