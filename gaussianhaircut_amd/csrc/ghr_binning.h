@@ -587,9 +587,7 @@ __device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_
         s_keys[key_slot<true>(i)] = i < n ? t[q] : GHR_KEY_INF;
     }
     if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
-#if !defined(GHR_SORT_SKIP_NETWORK)
     if (n > 1) bitonic_blocked<r, WAVE, true, true>(s_keys, n, t_, NT);
-#endif
     // (four entries at a time: the rect gather of more would set the kernel's register count)
     constexpr int E = L < 4 ? L : 4;
 #pragma unroll
@@ -706,9 +704,7 @@ __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uin
 // barrier at all, while wave 1 zero-fills the tile's gradient lines and leaves; longer ones by both waves (a wave per tile
 // throughout was measured too: the longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
 // (8.5 KiB); longer lists: tile_sort_wave_long.
-#ifndef GHR_SORT_WAVES
-#define GHR_SORT_WAVES 6  // 80 VGPRs, no spills: 26.1 us (8: 64 VGPRs + 8 spilled dwords 26.8; 5: 27.4; profiles/r05u)
-#endif
+#define GHR_SORT_WAVES 6  // per SIMD: 80 VGPRs, no spills: 26.1 us (8: 64 VGPRs + 8 spilled dwords 26.8; 5: 27.4; profiles/r05u)
 template <int CAP>
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(GHR_SORT_WAVES, 8))) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
