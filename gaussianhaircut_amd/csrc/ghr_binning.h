@@ -701,8 +701,8 @@ __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uin
 
 // TWO waves per tile (round 5; four before, each moving every key through LDS once per compare-exchange step): lists are sorted
 // by the register-blocked network above.  Short lists (<= GHR_SORT_SOLO keys: 7 of 10 tiles of cfg3) by wave 0 alone, no
-// barrier at all, while wave 1 zero-fills the tile's gradient lines and leaves; longer ones by both waves (a wave per tile
-// throughout was measured too: the longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
+// barrier at all (wave 1 leaves at once); longer ones by both waves (a wave per tile throughout was measured too: the
+// longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
 // (8.5 KiB); longer lists: tile_sort_wave_long.
 #define GHR_SORT_WAVES 6  // per SIMD: 80 VGPRs, no spills: 26.1 us (8: 64 VGPRs + 8 spilled dwords 26.8; 5: 27.4; profiles/r05u)
 template <int CAP>
