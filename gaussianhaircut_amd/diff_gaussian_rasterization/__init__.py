@@ -227,7 +227,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
                 def launch(cap):
                     b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
-                    # the backward pass's gradient lines, zeroed under the tile sort (include/ghr.h, ghr_forward_stage2)
+                    # the backward pass's gradient lines, zeroed by stage 2 (include/ghr.h, ghr_forward_stage2)
                     sc = torch.empty((max(int(cap), 1), _lib.GRAD_STRIDE), **f32) if want_grad and cap > 0 else None
                     _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(args), cap, _ptr(geomBuffer),
                                                     _ptr(imgBuffer), _ptr(b), _ptr(color), _ptr(sc)))

@@ -99,7 +99,7 @@ class _RenderModelFused(torch.autograd.Function):
 
             def launch(cap):
                 b = torch.empty((_lib.binning_size(cap, W, H),), dtype=torch.uint8, device=dev)
-                # the backward pass's gradient lines, zeroed under the tile sort (include/ghr.h, ghr_forward_stage2)
+                # the backward pass's gradient lines, zeroed by stage 2 (include/ghr.h, ghr_forward_stage2)
                 sc = (torch.empty((max(int(cap), 1), _lib.GRAD_STRIDE), dtype=torch.float32, device=dev)
                       if want_grad and cap > 0 else None)
                 _lib.check(L.ghr_forward_stage2(_stream(), ctypes.byref(va), cap, _ptr(geom), _ptr(img), _ptr(b),
@@ -113,7 +113,7 @@ class _RenderModelFused(torch.autograd.Function):
                 ctx.img_lease = lease  # (lives as long as the graph: the backward pass reads the workspace)
         cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
-        ctx.scratch_clean = ctx.scratch is not None  # zeroed under stage 2's tile sort, untouched since
+        ctx.scratch_clean = ctx.scratch is not None  # zeroed by stage 2, untouched since
         # the leaf parameters themselves (not the detached views saved below): backward may add straight into their
         # .grad when those alias an optimizer's flat gradient buffer (cfg["grad_sink"])
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)

@@ -97,7 +97,7 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
  * (no GPU bubble behind the host round trip) and relaunch it only if the true count turned out larger: instances
  * beyond the capacity are dropped without touching memory outside bin_ws.  Stage 2 may be replayed.
  * grad_scratch (ABI 12, may be NULL): the scratch the backward call over this state will be given (>= R lines).  Its
- * lines are then zeroed here, under the tile sort, so that the backward call can be told `prezeroed` (below). */
+ * lines are then zeroed here, by the render kernel as its last act, so that the backward call can be told `prezeroed` (below). */
 int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* geom_ws, void* img_ws, void* bin_ws,
                        float* out_color, float* grad_scratch);
 

@@ -36,7 +36,7 @@ def main():
     tf, tb = [], []
     for i in range(iters + 3):
         # full forward (stage 1 + 2): stage 2 alone must not be replayed; like the product's op it hands the backward's
-        # scratch to stage 2 (zeroed under the tile sort) unless KBENCH_NO_PREZERO is set
+        # scratch to stage 2 (zeroed by stage 2) unless KBENCH_NO_PREZERO is set
         run = GpuRun(ri, "A", debug=False, scratch=None if os.environ.get("KBENCH_NO_PREZERO") else scratch)
         _lib.check(L.ghr_backward(_stream(), ctypes.byref(run.args), run.R, _ptr(run.radii), _ptr(run.geom),
                                   _ptr(run.img), _ptr(run.bin), _ptr(dL), _ptr(scratch), *[_ptr(t) for t in o],
