@@ -107,8 +107,8 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
  * summed in a fixed order -- no cross-tile float atomics.
  * prezeroed (ABI 13; the library keeps NO record of buffers -- it is stateless between calls): 0 = grad_scratch is
  * uninitialised, K8 zero-fills it.  != 0 = the CALLER guarantees that grad_scratch is exactly as
- * ghr_forward_stage2(..., bin_ws, ..., grad_scratch) of THIS state left it: same scratch, zeroed under that stage 2's tile
- * sort, and nothing written to it since -- in particular no other backward call (of this or any other state).  Sharing
+ * ghr_forward_stage2(..., bin_ws, ..., grad_scratch) of THIS state left it: same scratch, zeroed by that stage 2,
+ * and nothing written to it since -- in particular no other backward call (of this or any other state).  Sharing
  * rule: when several states share one scratch buffer, at most the state whose stage 2 was the LAST to be handed the
  * buffer may be backwarded with prezeroed != 0, and only as the first backward that touches the buffer after it; every
  * other backward over the shared buffer passes 0.  A second backward over the same state passes 0.  A caller that launched stage 2
