@@ -22,8 +22,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 NUM_CHANNELS = 10
 GRAD_STRIDE = 16
+CAM_PARTIALS = 32  # GHR_CAM_PARTIALS: rows of the camera-gradient partial table
+CAM_GRADS = 37     # GHR_CAM_GRADS: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2]
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 16  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 17  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -94,7 +96,9 @@ class ModelArgs(ctypes.Structure):
                [("debug", ctypes.c_int32), ("mode", ctypes.c_int32), ("row0", ctypes.c_int32),
                 ("dir3d", ctypes.c_void_p)] + \
                [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")] + \
-               [("img_ws_recycled", ctypes.c_int32)]
+               [("img_ws_recycled", ctypes.c_int32)] + \
+               [("tanfov_dev", ctypes.c_void_p), ("cam_partial", ctypes.c_void_p), ("cam_slot0", ctypes.c_int32),
+                ("cam_slots", ctypes.c_int32), ("cam_only", ctypes.c_int32), ("detach_means2D", ctypes.c_int32)]
 
 
 class LossArgs(ctypes.Structure):
@@ -123,7 +127,7 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
+           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range"]
 
 _lib = None
@@ -174,6 +178,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
     L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6 + [i32]
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
+    L.ghr_camera_slots.argtypes = [i32]
+    L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

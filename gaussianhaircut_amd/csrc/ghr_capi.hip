@@ -397,6 +397,7 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     a->focal_y = m->H / (2.0f * m->tan_fovy);
     a->focal_x = m->W / (2.0f * m->tan_fovx);
     a->conic_eps = m->conic_eps;
+    a->tanfov = m->tanfov_dev;
     a->rec = nullptr; a->depths = nullptr; a->rects = nullptr; a->radii = nullptr; a->means2D = nullptr;
     a->tile_count = nullptr; a->slot_blk = nullptr; a->pos = nullptr;
     return GHR_OK;
@@ -502,8 +503,14 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     hipStream_t s = (hipStream_t)stream;
     if (a.P == 0) return GHR_OK;
     const bool need_act = a.mode == 0;
-    if (!radii || !geom_ws || !d_means2D || !d_xyz || !d_log_scales || !d_rotations || !d_features_dc ||
-        (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) || (a.sh_coeffs > 1 && !d_features_rest))
+    const bool cam_only = m->cam_only != 0;
+    if (cam_only && !m->cam_partial) return fail(GHR_E_INVALID, "ghr_model_backward_segment: cam_only without cam_partial");
+    if (m->cam_partial && (m->cam_slot0 < 0 || (long long)m->cam_slot0 + ghr_camera_slots(a.P) > m->cam_slots))
+        return fail(GHR_E_INVALID, "ghr_model_backward_segment: the segment's camera columns exceed cam_slots");
+    if (!radii || !geom_ws)
+        return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
+    if (!cam_only && (!d_means2D || !d_xyz || !d_log_scales || !d_rotations || !d_features_dc ||
+        (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) || (a.sh_coeffs > 1 && !d_features_rest)))
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
     Geom g;
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
@@ -518,9 +525,27 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
     mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
-    mg.accumulate = accumulate; mg.nan_flag = nan_flag;
-    hipLaunchKernelGGL(ghr::k_project_bwd, dim3((a.P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), dim3(GHR_PBW_BLOCK), 0, s, a, mg);
+    mg.accumulate = accumulate; mg.nan_flag = cam_only ? nullptr : nan_flag;
+    mg.cam_partial = m->cam_partial; mg.cam_slot0 = (uint32_t)m->cam_slot0; mg.cam_stride = (uint32_t)m->cam_slots;
+    mg.cam_only = cam_only ? 1 : 0; mg.detach_means2D = m->detach_means2D != 0 ? 1 : 0;
+    const dim3 grid((a.P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), block(GHR_PBW_BLOCK);
+    if (mg.cam_partial) hipLaunchKernelGGL(ghr::k_project_bwd<true>, grid, block, 0, s, a, mg);
+    else hipLaunchKernelGGL(ghr::k_project_bwd<false>, grid, block, 0, s, a, mg);
     return finish(s, m->debug);
+}
+
+int32_t ghr_camera_slots(int32_t P) { return P > 0 ? (P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK : 0; }
+
+int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam)
+{
+    if (!d_cam || cam_slots < 0 || (cam_slots > 0 && !cam_partial)) return fail(GHR_E_INVALID, "ghr_camera_grad_fold: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    if (cam_slots == 0) {
+        GHR_HIP(hipMemsetAsync(d_cam, 0, sizeof(float) * GHR_CAM_GRADS, s));
+        return finish(s, 0);
+    }
+    hipLaunchKernelGGL(ghr::k_cam_fold, dim3(GHR_CAM_PARTIALS), dim3(256), 0, s, cam_partial, (uint32_t)cam_slots, d_cam);
+    return finish(s, 0);
 }
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,

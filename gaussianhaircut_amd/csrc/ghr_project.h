@@ -52,6 +52,8 @@ struct ModelArgs {
     const float* proj;            // [16] full_proj_transform
     const float* campos;          // [3]
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y, conic_eps;
+    const float* tanfov;          // [2] device {tan(FoVx / 2), tan(FoVy / 2)} or NULL: overrides tan_fov* / focal_* above
+                                  // (a trainable FoV changes every step: read here, the host never waits for its value)
     // forward outputs
     f4* rec;
     float* depths;
@@ -80,7 +82,27 @@ struct ModelGrads {
                               // d_orient_conf_log receive the gradients of the LINEAR quantities and may be NULL
     int accumulate;           // != 0: parameter gradients are ADDED to the output buffers (d_means2D is always assigned)
     int* nan_flag;            // optional: set to 1 when any parameter gradient value written is NaN or +-inf
+    // Camera gradients (k_project_bwd<true>): every workgroup leaves the sums over its 64 Gaussians of the GHR_CAM_PARTIALS
+    // camera cotangents in slot cam_slot0 + blockIdx.x of a component-major table [GHR_CAM_PARTIALS][cam_stride];
+    // k_cam_fold adds the slots up in a fixed order.
+    float* cam_partial;
+    uint32_t cam_slot0, cam_stride;
+    int cam_only;             // != 0: nothing but d_means2D and the camera partials is written (frozen head segment)
+    int detach_means2D;       // != 0: the NDC means are constants of the graph (render_hair() detaches the head's,
+                              // gaussian_renderer/__init__.py:136): no gradient through full_proj_transform
 };
+
+// Camera cotangents a Gaussian contributes (the reference's projection graph is differentiable w.r.t. the camera:
+// gaussian_model.py:258-266,279-294 view matrix inside t, W and J, tan(FoV / 2) inside focal and the clamp limits; :332-335
+// full_proj_transform; gaussian_renderer/__init__.py:59 camera_center; cameras.py:85-151 makes them functions of trainable
+// residuals).  Only the entries that can be non-zero are carried:
+//   [0..11]  d view[4 r + c], r = 0..3, c = 0..2  (column 3 of world_view_transform is never read)      at 3 r + c
+//   [12..23] d proj[4 r + c], r = 0..3, c in {0, 1, 3}  (NDC z carries no gradient, rasterize_points.cu:160) at 12 + 3 r + {0,1,2}
+//   [24..26] d camera_center     [27..28] d tan(FoVx / 2), d tan(FoVy / 2)     [29..31] zero
+#ifndef GHR_CAM_PARTIALS  // (include/ghr.h states the same two numbers for the callers)
+#define GHR_CAM_PARTIALS 32
+#define GHR_CAM_GRADS 37  // what k_cam_fold writes: view[16] | proj[16] | camera_center[3] | tanfov[2]
+#endif
 
 // Whether a parameter-gradient value about to be stored is NON-FINITE (project_bwd_store raises nan_flag for it).  The
 // reference's guard looks for NaN only (train_gaussians.py:174-177); raising the flag for +-inf as well costs nothing (an
@@ -217,6 +239,7 @@ struct ProjCtx {
                           // (dynamic indexing sends the arrays to scratch / LDS)
     float Wc[3][3];       // Wc[c] = column c of view[:3,:3]
     float j00, j20, j11, j21, txp, typ;
+    float tfx, tfy, fx, fy; // tan(FoV / 2) and focal lengths in use (ModelArgs' own or from ModelArgs::tanfov)
 };
 
 GHR_HD float sel3(const float* v, int j) { return j == 0 ? v[0] : (j == 1 ? v[1] : v[2]); }
@@ -244,7 +267,17 @@ GHR_HD void proj_setup(const ModelArgs& a, const RawIn& in, ProjCtx& c)
         c.Wc[col][0] = V[col]; c.Wc[col][1] = V[4 + col]; c.Wc[col][2] = V[8 + col];
     }
     const float tz = c.t[2];
-    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    {
+        // branch-free like load_raw: an absent table reads campos instead (always there) and the values are dropped
+        const uniform_floats tf = GHR_UNIFORM(a.tanfov ? a.tanfov : a.campos);
+        const float t0 = tf[0], t1 = tf[1];
+        c.tfx = a.tanfov ? t0 : a.tan_fovx;
+        c.tfy = a.tanfov ? t1 : a.tan_fovy;
+        // focal = dim / (2 tan), gaussian_model.py:264-265 / rasterizer_impl.cu:224-225 -- the expression the host evaluates
+        c.fx = a.tanfov ? a.W / (2.0f * t0) : a.focal_x;
+        c.fy = a.tanfov ? a.H / (2.0f * t1) : a.focal_y;
+    }
+    const float limx = 1.3f * c.tfx, limy = 1.3f * c.tfy;
     const float txtz = c.t[0] / tz, tytz = c.t[1] / tz;
     c.inx = !(txtz < -limx || txtz > limx);
     c.iny = !(tytz < -limy || tytz > limy);
@@ -252,10 +285,10 @@ GHR_HD void proj_setup(const ModelArgs& a, const RawIn& in, ProjCtx& c)
     c.cly = fminf(limy, fmaxf(-limy, tytz));
     c.txp = c.clx * tz;
     c.typ = c.cly * tz;
-    c.j00 = a.focal_x / tz;
-    c.j11 = a.focal_y / tz;
-    c.j20 = -(a.focal_x * c.txp) / (tz * tz);
-    c.j21 = -(a.focal_y * c.typ) / (tz * tz);
+    c.j00 = c.fx / tz;
+    c.j11 = c.fy / tz;
+    c.j20 = -(c.fx * c.txp) / (tz * tz);
+    c.j21 = -(c.fy * c.typ) / (tz * tz);
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         c.u[i] = c.Wc[0][i] * c.j00 + c.Wc[2][i] * c.j20;
@@ -429,12 +462,20 @@ struct ProjBwdOut {
     float ddc[3], ddir[3];
 };
 
-GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, const float* ga, ProjBwdOut& o)
+// CAM: also the Gaussian's camera cotangents into cam[GHR_CAM_PARTIALS] (layout above; campos by project_bwd_sh).
+// detach_m2d: the NDC mean is a constant of the graph (no gradient through proj, none to xyz from it).
+template <bool CAM>
+GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, const float* ga, ProjBwdOut& o, float* cam,
+                             bool detach_m2d)
 {
     float dxyz[3] = {0, 0, 0}, dls[3] = {0, 0, 0}, dq[4] = {0, 0, 0, 0};
     float dlo = 0, dll = 0, dlc = 0;
     float ddir[3] = {0, 0, 0};
-    const float gmx = ga[0], gmy = ga[1];
+    const float gmx = detach_m2d ? 0.f : ga[0], gmy = detach_m2d ? 0.f : ga[1];
+    if (CAM) {
+#pragma unroll
+        for (int i = 0; i < GHR_CAM_PARTIALS; i++) cam[i] = 0.f;
+    }
 
     if (radius > 0) {
         ProjCtx c;
@@ -542,7 +583,7 @@ GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, co
             const float Lj11 = Lv[0] * c.Wc[1][0] + Lv[1] * c.Wc[1][1] + Lv[2] * c.Wc[1][2];
             const float Lj21 = Lv[0] * c.Wc[2][0] + Lv[1] * c.Wc[2][1] + Lv[2] * c.Wc[2][2];
             const float tz = c.t[2], itz = 1.0f / tz, itz2 = itz * itz, itz3 = itz2 * itz;
-            const float fx = a.focal_x, fy = a.focal_y;
+            const float fx = c.fx, fy = c.fy;
             const float Ltxp = Lj20 * (-fx * itz2), Ltyp = Lj21 * (-fy * itz2);
             Lt[2] = Lj00 * (-fx * itz2) + Lj11 * (-fy * itz2) + Lj20 * (2.f * fx * c.txp * itz3) +
                     Lj21 * (2.f * fy * c.typ * itz3);
@@ -551,10 +592,37 @@ GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, co
             Lt[1] = c.iny ? Ltyp : 0.f;
             Lt[2] += (c.inx ? 0.f : c.clx * Ltxp) + (c.iny ? 0.f : c.cly * Ltyp);
             Lt[2] += gc[9];  // depth channel = view z
+            if (CAM) {
+                // W = view[:3,:3] inside T = W @ J (gaussian_model.py:290-292): u_i = W[i][0] j00 + W[i][2] j20, v_i = W[i][1] j11 + W[i][2] j21
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    cam[3 * i + 0] = Lu[i] * c.j00;
+                    cam[3 * i + 1] = Lv[i] * c.j11;
+                    cam[3 * i + 2] = Lu[i] * c.j20 + Lv[i] * c.j21;
+                }
+                // focal = dim / (2 tan): d focal / d tan = -focal / tan; the clamp limits 1.3 tan receive the gradient of a
+                // clamped tx / tz (torch.clamp with tensor bounds: to `max` where x > max, to `min` = -lim where x < min)
+                const float Lfx = Lj00 * itz - Lj20 * (c.txp * itz2);
+                const float Lfy = Lj11 * itz - Lj21 * (c.typ * itz2);
+                const float Llimx = c.inx ? 0.f : (c.clx > 0.f ? Ltxp * tz : -(Ltxp * tz));
+                const float Llimy = c.iny ? 0.f : (c.cly > 0.f ? Ltyp * tz : -(Ltyp * tz));
+                cam[27] = 1.3f * Llimx - Lfx * (fx / c.tfx);
+                cam[28] = 1.3f * Llimy - Lfy * (fy / c.tfy);
+            }
         }
         const uniform_floats V = GHR_UNIFORM(a.view);
 #pragma unroll
         for (int row = 0; row < 3; row++) dxyz[row] += V[4 * row] * Lt[0] + V[4 * row + 1] * Lt[1] + V[4 * row + 2] * Lt[2];
+        if (CAM) {
+            // t = xyz @ view[:3,:3] + view[3,:3] (gaussian_model.py:268; the depth channel is its z, :339-342)
+            const float m[3] = {mx, my, mz};
+#pragma unroll
+            for (int row = 0; row < 3; row++)
+#pragma unroll
+                for (int col = 0; col < 3; col++) cam[3 * row + col] += m[row] * Lt[col];
+#pragma unroll
+            for (int col = 0; col < 3; col++) cam[9 + col] = Lt[col];
+        }
 
         // ---- NDC mean
         {
@@ -566,6 +634,16 @@ GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, co
             const float Lhx = gmx * w_, Lhy = gmy * w_, Lhw = -w_ * w_ * (gmx * hx + gmy * hy);
 #pragma unroll
             for (int row = 0; row < 3; row++) dxyz[row] += pm[4 * row] * Lhx + pm[4 * row + 1] * Lhy + pm[4 * row + 3] * Lhw;
+            if (CAM) {  // p_hom = xyz @ proj[:3,:] + proj[3] (gaussian_model.py:333)
+                const float m[3] = {mx, my, mz};
+#pragma unroll
+                for (int row = 0; row < 3; row++) {
+                    cam[12 + 3 * row + 0] = m[row] * Lhx;
+                    cam[12 + 3 * row + 1] = m[row] * Lhy;
+                    cam[12 + 3 * row + 2] = m[row] * Lhw;
+                }
+                cam[21] = Lhx; cam[22] = Lhy; cam[23] = Lhw;
+            }
         }
     }
 #pragma unroll
@@ -577,8 +655,9 @@ GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, co
 
 // ---- SH colour (clamp_min(sh + .5, 0)) incl. the view-direction dependence on xyz (added to o.dxyz behind the geometry
 // terms).  d_rest may alias rest: every element is read (cf) before it is overwritten, channel by channel.
+template <bool CAM>
 GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, const float* ga, const float* rest, float* d_rest,
-                           ProjBwdOut& o)
+                           ProjBwdOut& o, float* cam)
 {
     const int K = a.sh_coeffs;
     if (radius > 0) {
@@ -587,8 +666,8 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
         float* dxyz = o.dxyz;
         float* ddc = o.ddc;
         {
-            const uniform_floats cam = GHR_UNIFORM(a.campos);
-            const float dxv = mx - cam[0], dyv = my - cam[1], dzv = mz - cam[2];
+            const uniform_floats cpos = GHR_UNIFORM(a.campos);
+            const float dxv = mx - cpos[0], dyv = my - cpos[1], dzv = mz - cpos[2];
             const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
             const float x = dxv * il, y = dyv * il, z = dzv * il;
             float basis[GHR_SH_MAX], vk[GHR_SH_MAX];
@@ -615,9 +694,12 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
             float Ld[3];
             sh_basis_grad_dot(a.sh_degree, x, y, z, vk, Ld[0], Ld[1], Ld[2]);
             const float dotp = Ld[0] * x + Ld[1] * y + Ld[2] * z;  // d(normalize)
-            dxyz[0] += (Ld[0] - x * dotp) * il;
-            dxyz[1] += (Ld[1] - y * dotp) * il;
-            dxyz[2] += (Ld[2] - z * dotp) * il;
+            const float dd[3] = {(Ld[0] - x * dotp) * il, (Ld[1] - y * dotp) * il, (Ld[2] - z * dotp) * il};
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                dxyz[m] += dd[m];
+                if (CAM) cam[24 + m] = -dd[m];  // dir = xyz - camera_center (gaussian_renderer/__init__.py:59)
+            }
         }
     } else {
         for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
@@ -628,6 +710,7 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
 // whether any value stored was non-finite.
 GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const ProjBwdOut& o)
 {
+    if (g.cam_only) return false;  // a frozen segment: only its camera cotangents are wanted
     const int acc = g.accumulate;
     const size_t row = (size_t)a.row0 + idx;
     g.d_means2D[3 * row] = ga[0];
@@ -668,21 +751,26 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
 }
 
 GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, const RawIn& in, int radius, const float* ga,
-                             const float* rest, float* d_rest)
+                             const float* rest, float* d_rest, float* cam = nullptr)
 {
     ProjBwdOut o;
-    project_bwd_geom(a, in, radius, ga, o);
-    project_bwd_sh(a, in, radius, ga, rest, d_rest, o);
+    if (cam) {
+        project_bwd_geom<true>(a, in, radius, ga, o, cam, g.detach_means2D != 0);
+        project_bwd_sh<true>(a, in, radius, ga, rest, d_rest, o, cam);
+    } else {
+        project_bwd_geom<false>(a, in, radius, ga, o, nullptr, g.detach_means2D != 0);
+        project_bwd_sh<false>(a, in, radius, ga, rest, d_rest, o, nullptr);
+    }
     return project_bwd_store(a, g, idx, ga, o);
 }
 
 // project_bwd_core with its inputs loaded on the spot (tests/hostsim)
 GHR_HD bool project_bwd_one(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const float* rest,
-                            float* d_rest)
+                            float* d_rest, float* cam = nullptr)
 {
     RawIn in;
     load_raw(a, idx, in);
-    return project_bwd_core(a, g, idx, in, a.radii[(size_t)a.row0 + idx], ga, rest, d_rest);
+    return project_bwd_core(a, g, idx, in, a.radii[(size_t)a.row0 + idx], ga, rest, d_rest, cam);
 }
 
 // features_rest is [P, K-1, 3]: one thread's 3(K-1) floats are contiguous but 180 B apart from its neighbour's, so
@@ -851,6 +939,35 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
 // 256-thread workgroups did, and single waves are dispatched as soon as any slot frees up instead of four at a time:
 // 79.3 -> 76.5 us (128 threads: 77.5; forcing 128 VGPRs for a fourth wave per SIMD spills and loses: profiles/r05o).
 #define GHR_PBW_BLOCK 64
+#if defined(__HIP_DEVICE_COMPILE__)
+// Sum of each of the 32 values v[.] over the 64 lanes of the wave in 32 exchanges instead of 32 x 6: at every step a lane keeps
+// one half of its values and hands the other half to its partner (lane ^ 1, 2, 4, 8, 16), so the number of live values halves
+// while the number of lanes summed doubles; one more exchange joins the two halves of the wave.  Returns, on every lane, the
+// wave's total of component cam_butterfly_component(lane).  The order of the additions is fixed.
+__device__ __forceinline__ float cam_butterfly(float (&v)[GHR_CAM_PARTIALS], int lane)
+{
+#pragma unroll
+    for (int s = 0; s < 5; s++) {
+        const int n = GHR_CAM_PARTIALS >> (s + 1);
+        const bool hi = (lane >> s) & 1;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const float keep = hi ? v[i + n] : v[i];
+            const float send = hi ? v[i] : v[i + n];
+            v[i] = keep + __shfl_xor(send, 1 << s);
+        }
+    }
+    return v[0] + __shfl_xor(v[0], 32);
+}
+// lane bit s chose the half of size 16 >> s: the component is the bit-reversed low five bits of the lane
+__device__ __forceinline__ int cam_butterfly_component(int lane)
+{
+    return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+}
+#endif
+
+// CAM: the camera cotangents as well (ModelGrads::cam_partial); the default instantiation carries none of it.
+template <bool CAM>
 __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -885,17 +1002,60 @@ __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, Mode
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (row > 0) slab_dma<BLK>(s_rest, a.features_rest + (size_t)base * row, (size_t)nb * row, threadIdx.x);
     ProjBwdOut o;
-    if (idx < a.P) project_bwd_geom(a, in, radius, ga, o);
+    float cam[CAM ? GHR_CAM_PARTIALS : 1];
+    if (CAM) {
+#pragma unroll
+        for (int i = 0; i < (CAM ? GHR_CAM_PARTIALS : 1); i++) cam[i] = 0.f;
+    }
+    if (idx < a.P) project_bwd_geom<CAM>(a, in, radius, ga, o, cam, g.detach_means2D != 0);
     slab_wait();
     __syncthreads();
     bool bad = false;
     if (idx < a.P) {
-        project_bwd_sh(a, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row, o);
+        project_bwd_sh<CAM>(a, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row, o, cam);
         bad = project_bwd_store(a, g, idx, ga, o);
     }
     __syncthreads();
-    if (row > 0) bad |= slab_out<BLK>(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
+    if (row > 0 && !g.cam_only)
+        bad |= slab_out<BLK>(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
+    if constexpr (CAM) {
+        const int lane = threadIdx.x & 63;
+        const float tot = cam_butterfly(cam, lane);
+        if (lane < GHR_CAM_PARTIALS)
+            g.cam_partial[(size_t)cam_butterfly_component(lane) * g.cam_stride + g.cam_slot0 + blockIdx.x] = tot;
+    }
+#endif
+}
+
+// Adds up the per-workgroup camera partials (component-major [GHR_CAM_PARTIALS][n_slots]) in a fixed order, in double, and
+// writes d_cam[GHR_CAM_GRADS] = d view[16] | d proj[16] | d camera_center[3] | d tanfov[2] (entries the projection never
+// reads -- column 3 of the view matrix, column 2 of the projection matrix -- are written as zeros).  One workgroup per component.
+__global__ void __launch_bounds__(256) k_cam_fold(const float* partial, uint32_t n_slots, float* d_cam)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ double s_sum[256];
+    const int comp = blockIdx.x;
+    const float* p = partial + (size_t)comp * n_slots;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < n_slots; i += 256) acc += (double)p[i];
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float v = (float)s_sum[0];
+        if (comp < 12) d_cam[4 * (comp / 3) + comp % 3] = v;
+        else if (comp < 24) { const int c = (comp - 12) % 3; d_cam[16 + 4 * ((comp - 12) / 3) + (c == 2 ? 3 : c)] = v; }
+        else if (comp < 27) d_cam[32 + comp - 24] = v;
+        else if (comp < 29) d_cam[35 + comp - 27] = v;
+        else if (comp == 29) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { d_cam[4 * r + 3] = 0.f; d_cam[16 + 4 * r + 2] = 0.f; }
+        }
+    }
 #endif
 }
 

@@ -7,7 +7,8 @@ direction is turned into an orientation angle in [0,1) (``:102-105``).
 
 ``pc`` / ``pc_hair`` only need the reference's model interface (get_conic, get_mean_2d, get_direction_2d,
 get_depths, filter_points, get_xyz, get_opacity, get_features, get_label, get_orient_conf, cov, ...), so the
-reference's own model classes work here too.
+reference's own model classes work here too -- and they, too, take the fused HIP path when they keep the reference's
+parametrisation (``is_free_gaussian_model``), with constant or trainable cameras.
 """
 from __future__ import annotations
 
@@ -120,8 +121,8 @@ def camera_requires_grad(cam) -> bool:
     """True when autograd is recording and any tensor of the camera the projection reads is being trained.  The
     reference optimises camera pose and FoV by default (``src/arguments/__init__.py:61-62``, ``src/scene/cameras.py:
     83-151``, stepped at ``src/train_gaussians.py:183-196``); their gradients flow through get_conic / get_mean_2d /
-    get_direction_2d / get_depths.  The fused projection kernels take the camera as constants, so such a camera must
-    take the generic (PyTorch autograd) projection path -- it is never silently detached."""
+    get_direction_2d / get_depths and the SH view direction.  The fused path returns them too (ABI 17: the projection
+    backward reduces the camera cotangents, ``fused._camera_grads``), so such a camera no longer forces the generic path."""
     if not torch.is_grad_enabled():
         return False
     for name in _CAMERA_TENSORS:
@@ -131,14 +132,45 @@ def camera_requires_grad(cam) -> bool:
     return False
 
 
-def _use_fused(pc, pipe, cam=None) -> bool:
-    """The fused HIP path covers exactly the free-Gaussian ``GaussianModel`` parametrisation (exp / sigmoid / normalize
-    activations, longest-axis direction) seen through a CONSTANT camera; anything else (strand models, the reference's
-    own classes, a camera whose tensors require grad) takes the generic path below, which only relies on the model's
-    public interface and on PyTorch autograd."""
+_RAW_FIELDS = ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest")
+_FREE_ACTIVATIONS = (("scaling_activation", torch.exp), ("opacity_activation", torch.sigmoid),
+                     ("label_activation", torch.sigmoid), ("orient_conf_activation", torch.exp),
+                     ("rotation_activation", F.normalize))
+
+
+def is_free_gaussian_model(pc) -> bool:
+    """Whether ``pc`` is parametrised like the reference's free-Gaussian ``scene.gaussian_model.GaussianModel``
+    (``src/scene/gaussian_model.py:30-43,107-141``): the eight raw tensors, exp / sigmoid / normalize activations (checked by
+    identity: the reference binds ``torch.exp`` etc. in ``setup_functions``), SH degree counters -- this package's own class,
+    the reference's, or any class that keeps that interface.  Strand models (their per-Gaussian quantities are DERIVED from
+    strand parameters: ``_dir``, ``initialize_gaussians_hair``) are not."""
     from ..scene.gaussian_model import GaussianModel
-    return (type(pc) is GaussianModel and getattr(pipe, "fused_projection", True) and pc.get_xyz.is_cuda and
-            not (cam is not None and camera_requires_grad(cam)))
+    if type(pc) is GaussianModel:
+        return True
+    if hasattr(pc, "_dir") or hasattr(pc, "initialize_gaussians_hair"):
+        return False
+    if not all(isinstance(getattr(pc, f, None), torch.Tensor) for f in _RAW_FIELDS):
+        return False
+    if not all(getattr(pc, n, None) is f for n, f in _FREE_ACTIVATIONS):
+        return False
+    try:
+        K = (int(pc.max_sh_degree) + 1) ** 2
+        P = pc._xyz.shape[0]
+        return (0 <= int(pc.active_sh_degree) <= int(pc.max_sh_degree) <= 3 and
+                tuple(pc._features_dc.shape) == (P, 1, 3) and tuple(pc._features_rest.shape) == (P, K - 1, 3) and
+                tuple(pc._xyz.shape) == (P, 3) and tuple(pc._scaling.shape) == (P, 3) and
+                tuple(pc._rotation.shape) == (P, 4) and pc._opacity.numel() == P and pc._label.numel() == P and
+                pc._orient_conf.numel() == P)
+    except Exception:
+        return False
+
+
+def _use_fused(pc, pipe, cam=None) -> bool:
+    """The fused HIP path covers the free-Gaussian parametrisation (exp / sigmoid / normalize activations, longest-axis
+    direction; ``is_free_gaussian_model``) on a ROCm device, through constant AND trainable cameras; anything else (strand
+    models here, exotic classes) takes the generic path below, which only relies on the model's public interface and on
+    PyTorch autograd."""
+    return (getattr(pipe, "fused_projection", True) and is_free_gaussian_model(pc) and pc._xyz.is_cuda)
 
 
 def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):
@@ -181,13 +213,14 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
 
 
 def _use_fused_hair(pc, pc_hair, pipe, cam=None) -> bool:
-    """Fused strand-stage path: a ``GaussianModel`` head with its ``*_precomp`` attributes and a
-    ``GaussianModelStrands`` on a ROCm device, constant camera (anything else takes the generic path)."""
-    from ..scene.gaussian_model import GaussianModel
-    from ..scene.gaussian_model_strands import GaussianModelLatentStrands, GaussianModelStrands
-    return (type(pc) is GaussianModel and type(pc_hair) in (GaussianModelStrands, GaussianModelLatentStrands) and
-            getattr(pipe, "fused_projection", True) and pc_hair.get_xyz.is_cuda and hasattr(pc, "shs_view") and
-            not (cam is not None and camera_requires_grad(cam)))
+    """Fused strand-stage path: a free-Gaussian head with its ``*_precomp`` attributes (``src/train_strands.py:65-73``) and a
+    strand model exposing the explicit per-Gaussian quantities of ``src/scene/gaussian_model_strands.py:230-452`` (``_dir``,
+    ``get_scaling``, ``_rotation``, ``get_orient_conf``, SH features) on a ROCm device; constant or trainable camera."""
+    hair_ok = all(hasattr(pc_hair, n) for n in ("_dir", "_rotation", "_features_dc", "_features_rest", "get_scaling",
+                                                  "get_orient_conf", "get_xyz", "active_sh_degree"))
+    head_ok = is_free_gaussian_model(pc) and all(hasattr(pc, n) for n in ("xyz_precomp", "opacity_precomp", "scaling_precomp",
+                                                                           "rotation_precomp", "mask_precomp", "shs_view"))
+    return bool(getattr(pipe, "fused_projection", True) and hair_ok and head_ok and pc_hair.get_xyz.is_cuda)
 
 
 def render_hair(viewpoint_camera, pc, pc_hair, pipe, bg_color: torch.Tensor, scaling_modifier=1.0):

@@ -27,13 +27,16 @@ class _ImgLease:
     back at zero (``k_tile_scan`` turns the counts into append cursors starting at 0, stage 2's tile sort resets them), so a
     pass that gets such a buffer says so (``ghr_model_args.img_ws_recycled``) and the launch is dropped.  The lease lives
     in the autograd node: the buffer goes back to the pool when the graph is freed (after backward, or when the outputs
-    go out of scope; a retained graph keeps it), and only if stage 2 was launched.  Pools are per (device, size, stream):
-    the next pass on the same stream is ordered behind everything that still reads the buffer."""
+    go out of scope; a retained graph keeps it), and only if stage 1 AND stage 2 actually ran their kernels on it (a pass
+    over an empty model launches nothing: its buffer is never pooled).  Pools are per (device, W, H, stream): the next
+    pass on the same stream is ordered behind everything that still reads the buffer."""
     _pools = {}
     MAX_POOLED = 4
 
-    def __init__(self, dev, nbytes):
-        self.key = (dev.index, int(nbytes), torch.cuda.current_stream(dev).cuda_stream)
+    def __init__(self, dev, nbytes, W, H):
+        # keyed on the image size, not the byte count: the carve offsets of the counters depend on W x H (two sizes may round
+        # to the same number of bytes), and include/ghr.h only allows recycling between passes of the SAME W x H
+        self.key = (dev.index, int(W), int(H), torch.cuda.current_stream(dev).cuda_stream)
         pool = _ImgLease._pools.get(self.key)
         if pool:
             self.buf, self.recycled = pool.pop(), True
@@ -51,8 +54,10 @@ class _ImgLease:
             pass
 
 
-def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug):
+def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug,
+                tanfov_dev=None):
     m = _lib.ModelArgs()
+    m.tanfov_dev = _ptr(tanfov_dev) if tanfov_dev is not None else None
     m.P, m.W, m.H, m.sh_degree, m.sh_coeffs = int(P), int(W), int(H), int(sh_degree), int(K)
     (m.xyz, m.log_scales, m.rotations, m.opacity_logit, m.label_logit, m.orient_conf_log, m.features_dc,
      m.features_rest) = [_ptr(t) for t in tensors]
@@ -65,7 +70,7 @@ def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_mo
 class _RenderModelFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest,
-                screenspace_points, cfg):
+                screenspace_points, view, proj, campos, tanfov, cfg):
         L = _lib.lib()
         if not xyz.is_cuda:
             raise RuntimeError("gaussianhaircut_amd: parameters are on %s; the HIP renderer has no CPU path" % xyz.device)
@@ -74,17 +79,22 @@ class _RenderModelFused(torch.autograd.Function):
         params = [t.detach().float().contiguous() for t in (xyz, log_scales, rotations, opacity_logit, label_logit,
                                                             orient_conf_log, f_dc, f_rest)]
         K = 1 + f_rest.shape[1]
-        view, proj = cfg["view"].float().contiguous(), cfg["proj"].float().contiguous()
-        campos, bg = cfg["campos"].float().contiguous(), cfg["bg"].float().contiguous()
+        # the camera's tensors are inputs of the op: when they are functions of trainable pose / FoV residuals
+        # (src/scene/cameras.py:85-151) the backward pass returns their gradients (_camera_grads)
+        cam_in = (view, proj, campos, tanfov)
+        view, proj = view.detach().float().contiguous(), proj.detach().float().contiguous()
+        campos, bg = campos.detach().float().contiguous(), cfg["bg"].float().contiguous()
+        tanfov = tanfov.detach().float().reshape(-1).contiguous() if tanfov is not None else None
+        ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in cam_in]
         with torch.cuda.device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             gbytes, ibytes = _lib.forward_sizes(P, W, H, False)
             geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
-            lease = _ImgLease(dev, ibytes) if RECYCLE_IMG_WS else None
+            lease = _ImgLease(dev, ibytes, W, H) if RECYCLE_IMG_WS else None
             img = lease.buf if lease is not None else torch.empty((ibytes,), dtype=torch.uint8, device=dev)
             m = _model_args(P, W, H, cfg["sh_degree"], K, params, view, proj, campos, bg, cfg["scale_modifier"],
-                            cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+                            cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"], tanfov)
             m.img_ws_recycled = int(lease is not None and lease.recycled)
             pinned = _pinned(dev)
             _lib.check(L.ghr_model_forward_stage1(_stream(), ctypes.byref(m), _ptr(geom), _ptr(img), _ptr(radii),
@@ -109,7 +119,9 @@ class _RenderModelFused(torch.autograd.Function):
             # speculative (see diff_gaussian_rasterization.run_stage2); with cfg["defer_count"] R is a PendingCount
             R, cap, (binb, ctx.scratch) = run_stage2(dev, P, pinned, launch, defer=bool(cfg.get("defer_count")))
             if lease is not None:
-                lease.complete = True  # stage 2 has been launched: the counters end up at zero again
+                # stage 2 has been launched: the counters end up at zero again.  With P == 0 the library returns early from
+                # both stages and never touches the workspace (an uninitialised buffer must not enter the pool)
+                lease.complete = P > 0
                 ctx.img_lease = lease  # (lives as long as the graph: the backward pass reads the workspace)
         cfg["count"] = R  # handed to the caller through render_model_fused (cfg is this call's private dict)
         ctx.cfg, ctx.R, ctx.K, ctx.cap = cfg, R, K, cap
@@ -119,6 +131,7 @@ class _RenderModelFused(torch.autograd.Function):
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
+        ctx.tanfov = tanfov
         ctx.save_for_backward(*params, view, proj, campos, bg, radii, geom, img, binb)
         return color, radii
 
@@ -161,7 +174,10 @@ class _RenderModelFused(torch.autograd.Function):
             ctx.scratch_clean = False
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
-                            cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"])
+                            cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"],
+                            ctx.tanfov)
+            want_cam = any(ctx.needs_input_grad[9:13])
+            cam_partial = _camera_partials(m, [P], dev) if want_cam and P > 0 else None
             # the step's first gradients into a buffer that is known to hold zeros are assigned, not added (optim.py)
             acc = 1
             if P > 0 and direct and sink.take_known_zero():
@@ -185,10 +201,39 @@ class _RenderModelFused(torch.autograd.Function):
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
                                                 _ptr(d_fdc), _ptr(d_frest), acc if direct else 0,
                                                 sink.nan_flag_ptr() if direct else None, prezeroed))
+            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[9:13], dev) if want_cam else (None,) * 4
         if direct:
             sink.note_direct_backward()
-            return None, None, None, None, None, None, None, None, d_m2d, None
-        return d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d, None
+            return (None, None, None, None, None, None, None, None, d_m2d) + d_cam + (None,)
+        return (d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d) + d_cam + (None,)
+
+
+def _camera_partials(m, seg_sizes, dev):
+    """The camera-gradient partial table of one view (include/ghr.h, ghr_model_args.cam_partial): one column per 64 Gaussians
+    of every segment; points `m` (the first segment's arguments) at its columns.  Returns (table, columns, [slot0 ...])."""
+    L = _lib.lib()
+    slots = [int(L.ghr_camera_slots(int(n))) for n in seg_sizes]
+    total = sum(slots)
+    table = torch.empty((_lib.CAM_PARTIALS, max(total, 1)), dtype=torch.float32, device=dev)
+    starts = [sum(slots[:i]) for i in range(len(slots))]
+    m.cam_partial, m.cam_slot0, m.cam_slots = _ptr(table), starts[0], total
+    return table, total, starts
+
+
+def _camera_grads(cam_partial, meta, needs, dev):
+    """Fold the partial table into dL/d(world_view_transform, full_proj_transform, camera_center, tan(FoV / 2)) -- what
+    autograd hands those tensors in the reference's render() -- shaped like the op's inputs."""
+    d_cam = torch.empty((_lib.CAM_GRADS,), dtype=torch.float32, device=dev)
+    if cam_partial is None:
+        d_cam.zero_()
+    else:
+        table, total, _ = cam_partial
+        _lib.check(_lib.lib().ghr_camera_grad_fold(_stream(), _ptr(table), total, _ptr(d_cam)))
+    parts = (d_cam[0:16], d_cam[16:32], d_cam[32:35], d_cam[35:37])
+    out = []
+    for g, mt, need in zip(parts, meta, needs):
+        out.append(g.reshape(mt[0]).to(mt[1]) if (need and mt is not None) else None)
+    return tuple(out)
 
 
 def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False):
@@ -201,10 +246,9 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
     # here it also carries the NDC means as values, like the reference's get_mean_2d() output.
     # k_project writes all P rows (culled Gaussians included), so no zero-fill is needed
     screenspace_points = torch.empty((P, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
-    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
-               proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
-               sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier),
-               tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
+    view, proj, campos, tanfov, tfx, tfy = camera_inputs(cam)
+    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), bg=bg_color,
+               sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier), tanfovx=tfx, tanfovy=tfy,
                conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug), defer_count=bool(defer_count),
                grad_enabled=torch.is_grad_enabled())  # (inside Function.forward grad mode is always off)
     from ..optim import FusedAdam
@@ -212,8 +256,24 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
     if isinstance(opt, FusedAdam) and opt.direct_grads:
         cfg["grad_sink"] = opt
     renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
-                                             pc._features_dc, pc._features_rest, screenspace_points, cfg)
+                                             pc._features_dc, pc._features_rest, screenspace_points, view, proj, campos,
+                                             tanfov, cfg)
     return renders, radii, screenspace_points, cfg.get("count")
+
+
+def camera_inputs(cam):
+    """(world_view_transform, full_proj_transform, camera_center, tanfov tensor | None, tan_fovx, tan_fovy) of a camera, each
+    property read ONCE (the reference's trainable Camera rebuilds its matrices on every access, src/scene/cameras.py:113-151).
+    A FoV that is part of the autograd graph (trainable intrinsics, :93-105) goes to the kernels as a DEVICE tensor
+    {tan(FoVx / 2), tan(FoVy / 2)} -- differentiable, and never read back by the host; a constant FoV as two host floats."""
+    view, proj, campos = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
+    fx, fy = cam.FoVx, cam.FoVy
+    live = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (fx, fy))
+    if live:
+        dev = view.device
+        both = torch.stack([torch.as_tensor(fx, device=dev).reshape(()).float(), torch.as_tensor(fy, device=dev).reshape(()).float()])
+        return view, proj, campos, torch.tan(both * 0.5), 1.0, 1.0  # (the floats are ignored: tanfov_dev overrides them)
+    return view, proj, campos, None, _tan_half(fx), _tan_half(fy)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -231,9 +291,10 @@ def _seg_args(P, row0, W, H, sh_degree, K, t, cam_t, cfg, eps, consts):
     m.orient_conf_log = _ptr(t["conf"]) if t.get("conf") is not None else None
     m.dir3d = _ptr(t["dir"]) if t.get("dir") is not None else None
     m.features_dc, m.features_rest = _ptr(t["fdc"]), _ptr(t["frest"])
-    m.viewmatrix, m.projmatrix, m.campos, m.background = [_ptr(x) for x in cam_t]
+    m.viewmatrix, m.projmatrix, m.campos, m.background = [_ptr(x) for x in cam_t[:4]]
     m.scale_modifier, m.tan_fovx, m.tan_fovy = cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"]
     m.conic_eps = eps
+    m.tanfov_dev = _ptr(cam_t[4]) if len(cam_t) > 4 and cam_t[4] is not None else None
     m.debug = int(bool(cfg["debug"]))
     m.mode, m.row0 = 1, int(row0)
     m.const_opacity, m.const_label, m.const_conf = consts
@@ -242,7 +303,8 @@ def _seg_args(P, row0, W, H, sh_degree, K, t, cam_t, cfg, eps, consts):
 
 class _RenderHairFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, dirs, conf, f_dc, f_rest, screenspace_points, head, cfg):
+    def forward(ctx, xyz, scaling, rotation, dirs, conf, f_dc, f_rest, screenspace_points, view, proj, campos, tanfov,
+                head, cfg):
         L = _lib.lib()
         if not xyz.is_cuda:
             raise RuntimeError("gaussianhaircut_amd: parameters are on %s; the HIP renderer has no CPU path" % xyz.device)
@@ -255,7 +317,9 @@ class _RenderHairFused(torch.autograd.Function):
         row0 = (n_head + 255) // 256 * 256
         rows = row0 + n_hair
         K = 1 + f_rest.shape[1]
-        cam_t = [cfg[k].float().contiguous() for k in ("view", "proj", "campos", "bg")]
+        ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in (view, proj, campos, tanfov)]
+        cam_t = [t.detach().float().contiguous() for t in (view, proj, campos, cfg["bg"])]
+        cam_t.append(tanfov.detach().float().reshape(-1).contiguous() if tanfov is not None else None)
         with torch.cuda.device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii_ws = torch.empty((rows,), dtype=torch.int32, device=dev)
@@ -297,7 +361,9 @@ class _RenderHairFused(torch.autograd.Function):
         ctx.scratch_clean = ctx.scratch is not None
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
-        ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t,
+        ctx.tanfov = cam_t[4]
+        ctx.head = head  # (the frozen head contributes to the camera's gradients)
+        ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t[:4],
                               radii_ws, geom, img, binb)
         return color, radii
 
@@ -325,18 +391,32 @@ class _RenderHairFused(torch.autograd.Function):
             ctx.scratch_clean = False
             dL = grad_color.float().contiguous()
             hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
-            m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, [view, proj, campos, bg], cfg,
-                               cfg["eps_hair"], (1.0, 1.0, 0.0))
+            cam_t = [view, proj, campos, bg, ctx.tanfov]
+            m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, cam_t, cfg, cfg["eps_hair"], (1.0, 1.0, 0.0))
+            want_cam = any(ctx.needs_input_grad[8:12])
+            cam_partial = None
+            if want_cam and rows > 0:
+                # the camera's gradients are sums over BOTH segments: the head is frozen but seen through the same camera
+                # (its NDC means are detached in the reference, gaussian_renderer/__init__.py:136: no term through proj)
+                m_head = _seg_args(n_head, 0, W, H, cfg["sh_degree"], K, ctx.head, cam_t, cfg, cfg["eps_head"], (1.0, 0.0, 0.0))
+                cam_partial = _camera_partials(m_head, [n_head, n_hair], dev)
+                m_head.cam_only, m_head.detach_means2D = 1, 1
+                m_hair.cam_partial, m_hair.cam_slot0, m_hair.cam_slots = m_head.cam_partial, cam_partial[2][1], cam_partial[1]
             if rows > 0:
                 _lib.check(L.ghr_render_backward(_stream(), rows, W, H, ctx.cap, _ptr(bg), _ptr(geom), _ptr(img),
                                                  _ptr(binb), _ptr(dL), _ptr(scratch), prezeroed))
+            if cam_partial is not None and n_head > 0:
+                _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_head), rows, _ptr(radii_ws), _ptr(geom),
+                                                        _ptr(scratch), None, None, None, None, None, None, None, None, None,
+                                                        None, 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
             if n_hair > 0:
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
                                                         _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
                                                         _ptr(d_dir), 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
-        return d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d, None, None
+            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:12], dev) if want_cam else (None,) * 4
+        return (d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d) + d_cam + (None, None)
 
 
 def head_segment(pc):
@@ -363,13 +443,12 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
     xyz = pc_hair.get_xyz
     n = head["xyz"].shape[0] + xyz.shape[0]
     screenspace_points = torch.empty((n, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
-    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), view=cam.world_view_transform,
-               proj=cam.full_proj_transform, campos=cam.camera_center, bg=bg_color,
-               sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier),
-               tanfovx=_tan_half(cam.FoVx), tanfovy=_tan_half(cam.FoVy),
+    view, proj, campos, tanfov, tfx, tfy = camera_inputs(cam)
+    cfg = dict(W=int(cam.image_width), H=int(cam.image_height), bg=bg_color,
+               sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier), tanfovx=tfx, tanfovy=tfy,
                eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
                debug=bool(debug), grad_enabled=torch.is_grad_enabled())
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
                                             pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
-                                            screenspace_points, head, cfg)
+                                            screenspace_points, view, proj, campos, tanfov, head, cfg)
     return renders, radii, screenspace_points

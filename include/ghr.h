@@ -38,11 +38,13 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 16
+#define GHR_ABI_VERSION 17
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
+#define GHR_CAM_PARTIALS 32 /* rows of the camera-gradient partial table (ghr_model_args.cam_partial) */
+#define GHR_CAM_GRADS 37    /* floats ghr_camera_grad_fold writes: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2] */
 
 #define GHR_OK 0
 #define GHR_E_INVALID (-1)  /* bad argument (NULL where required, C != GHR_NUM_CHANNELS, ...) */
@@ -171,6 +173,25 @@ typedef struct ghr_model_args {
      * per-tile counters are then back at zero -- k_tile_scan turns the counts into append cursors starting at 0 and stage 2's
      * tile sort resets every cursor -- so stage 1 does not launch its zero-fill (one ~5-us launch per view).  0: any buffer. */
     int32_t img_ws_recycled;
+    /* ---- ABI 17: trainable cameras.  The reference's projection graph is differentiable w.r.t. the camera
+     * (src/scene/gaussian_model.py:258-266,279-294,332-335; src/gaussian_renderer/__init__.py:59), whose tensors are functions
+     * of trainable pose / FoV residuals (src/scene/cameras.py:85-151) stepped by an optimizer of their own
+     * (src/train_gaussians.py:45-60,183-196; on by default: src/arguments/__init__.py:61-62).
+     * tanfov_dev: [2] DEVICE floats {tan(FoVx / 2), tan(FoVy / 2)} or NULL.  Non-NULL: forward and backward kernels read the
+     * half-angle tangents from there (and derive focal = dim / (2 tan) themselves) instead of tan_fovx / tan_fovy above, so a FoV
+     * that changes every step never costs a device-to-host read.
+     * cam_partial (backward calls only; NULL = no camera gradients): table of GHR_CAM_PARTIALS rows of cam_slots floats.  The
+     * segment's backward writes one column per 64 Gaussians -- columns cam_slot0 .. cam_slot0 + ghr_camera_slots(P) - 1, every
+     * row of them -- and ghr_camera_grad_fold adds the columns up.  Several segments of one view share a table.
+     * cam_only != 0: a frozen segment (render_hair()'s head Gaussians): its backward writes NOTHING but its camera columns (the
+     * parameter-gradient and d_means2D pointers may be NULL).
+     * detach_means2D != 0: the segment's NDC means are constants of the graph (render_hair() detaches the head's,
+     * src/gaussian_renderer/__init__.py:136): no gradient flows through projmatrix for it. */
+    const float* tanfov_dev;
+    float* cam_partial;
+    int32_t cam_slot0, cam_slots;
+    int32_t cam_only;
+    int32_t detach_means2D;
 } ghr_model_args;
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
@@ -208,6 +229,14 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
                                float* d_orient_conf_log, float* d_features_dc, float* d_features_rest, float* d_dir3d,
                                int32_t accumulate, int32_t* nan_flag, uint32_t grad_rows, const void* bin_ws,
                                uint32_t R);
+
+/* ABI 17.  Columns of ghr_model_args.cam_partial a segment of P Gaussians fills (host only). */
+int32_t ghr_camera_slots(int32_t P);
+/* Adds the cam_slots columns of a partial table up (fixed order, double accumulation) into d_cam[GHR_CAM_GRADS]:
+ * dL/d world_view_transform [4,4] (column 3 zero: never read) | dL/d full_proj_transform [4,4] (column 2 zero: the NDC z carries
+ * no gradient) | dL/d camera_center [3] | dL/d {tan(FoVx / 2), tan(FoVy / 2)} -- the gradients autograd hands the camera tensors
+ * in the reference's render() (torch.clamp's tensor bounds 1.3 tan included). */
+int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam);
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,

@@ -239,6 +239,9 @@ void ghrsim_project_forward(const ghr::ModelArgs* a_in, float* out_rec, int* out
     std::memcpy(out_rec, rec.data(), sizeof(float) * 16 * (size_t)P);
 }
 
+void ghrsim_project_backward3(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
+                              float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
+                              float* d_fdc, float* d_frest, float* d_dir, float* cam, int detach_means2D);
 void ghrsim_project_backward2(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
                               float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
                               float* d_fdc, float* d_frest, float* d_dir);
@@ -254,6 +257,14 @@ void ghrsim_project_backward2(const ghr::ModelArgs* a_in, const int* radii, cons
                               float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
                               float* d_fdc, float* d_frest, float* d_dir)
 {
+    ghrsim_project_backward3(a_in, radii, gacc, d_means2D, d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_dir,
+                             nullptr, 0);
+}
+// + the per-Gaussian camera cotangents: cam [P][GHR_CAM_PARTIALS] (may be NULL), layout in ghr_project.h
+void ghrsim_project_backward3(const ghr::ModelArgs* a_in, const int* radii, const float* gacc, float* d_means2D,
+                              float* d_xyz, float* d_ls, float* d_rot, float* d_op, float* d_label, float* d_conf,
+                              float* d_fdc, float* d_frest, float* d_dir, float* cam, int detach_means2D)
+{
     ghr::ModelArgs a = *a_in;
     a.gx = (a.W + 15) / 16; a.gy = (a.H + 15) / 16;
     a.radii = const_cast<int*>(radii);
@@ -262,9 +273,11 @@ void ghrsim_project_backward2(const ghr::ModelArgs* a_in, const int* radii, cons
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
     g.d_features_rest = d_frest; g.d_dir3d = d_dir;
     g.accumulate = 0; g.nan_flag = nullptr;
+    g.cam_partial = nullptr; g.cam_slot0 = 0; g.cam_stride = 0; g.cam_only = 0; g.detach_means2D = detach_means2D;
     const int row = 3 * (a.sh_coeffs - 1);
     for (int i = 0; i < a.P; i++)
-        ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row);
+        ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row,
+                             cam ? cam + (size_t)GHR_CAM_PARTIALS * i : nullptr);
 }
 
 int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ghr_abi_version() == _lib.ABI_VERSION == 16
+    assert L.ghr_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_workspace_sizes_and_error_codes():
@@ -302,9 +302,10 @@ def test_adam_reduce_plan_covers_the_buffer_and_skips_inactive_sh_bands(deg):
         assert sent == n - 45 * P + 3 * P * act
 
 
-def test_camera_that_requires_grad_never_takes_the_fused_projection():
-    """The fused kernels take the camera as constants; a trainable camera (reference default: src/arguments/__init__.py:
-    61-62) must fall back to the autograd projection (gaussian_renderer._use_fused / _use_fused_hair)."""
+def test_camera_requires_grad_detects_every_trainable_camera_tensor():
+    """A trainable camera (reference default: src/arguments/__init__.py:61-62) is recognised whichever of its tensors carries
+    the graph; since ABI 17 the fused path returns the camera's gradients itself (tests/test_camera_grads.py) instead of
+    falling back to the autograd projection."""
     import torch
     from gaussianhaircut_amd.gaussian_renderer import camera_requires_grad
     from gaussianhaircut_amd.utils import synthetic as syn

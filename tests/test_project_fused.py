@@ -237,3 +237,113 @@ def test_fused_projection_explicit_mode_matches_strand_pipeline(hostsim):
         rowscale = np.abs(r.reshape(P, -1)).max(axis=1, keepdims=True).reshape((P,) + (1,) * (r.ndim - 1))
         err = np.abs(got - r) / (rowscale + 1e-3 * scale)
         assert err.max() < 1e-4 and np.isfinite(got).all(), (k, err.max())   # every element (measured: <= 1.5e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Camera cotangents (ABI 17): the reference's projection graph is differentiable w.r.t. the camera tensors
+# (/root/reference/src/scene/gaussian_model.py:258-266,279-294,332-335; src/gaussian_renderer/__init__.py:59) -- the fused
+# backward's per-Gaussian contributions, summed, against fp64 autograd of that graph with the camera tensors as leaves.
+CAM_LAYOUT = {"view": [(4 * (c // 3) + c % 3) for c in range(12)],
+              "proj": [(4 * (c // 3) + (3 if c % 3 == 2 else c % 3)) for c in range(12)]}
+
+
+def cam_vector_to_tensors(cam32):
+    """[32] partial-table column sums -> (d view [4,4], d proj [4,4], d campos [3], d tanfov [2]) like k_cam_fold"""
+    dv, dp = np.zeros(16), np.zeros(16)
+    dv[CAM_LAYOUT["view"]] = cam32[0:12]
+    dp[CAM_LAYOUT["proj"]] = cam32[12:24]
+    return dv.reshape(4, 4), dp.reshape(4, 4), cam32[24:27].copy(), cam32[27:29].copy()
+
+
+class LeafCamera:
+    """The tensors render() reads from a camera, as fp64 leaves; tan(FoV / 2) enters through FoVx / FoVy exactly like the
+    reference's `torch.tan(viewpoint_camera.FoVx * 0.5)`."""
+
+    def __init__(self, cam):
+        self.image_width, self.image_height = cam.image_width, cam.image_height
+        self.world_view_transform = cam.world_view_transform.detach().double().clone().requires_grad_(True)
+        self.full_proj_transform = cam.full_proj_transform.detach().double().clone().requires_grad_(True)
+        self.camera_center = cam.camera_center.detach().double().clone().requires_grad_(True)
+        self.tanfov = torch.tan(torch.stack([cam.FoVx.detach().double(), cam.FoVy.detach().double()]) * 0.5).requires_grad_(True)
+        self.FoVx = 2.0 * torch.atan(self.tanfov[0])
+        self.FoVy = 2.0 * torch.atan(self.tanfov[1])
+
+
+@pytest.mark.parametrize("cfg,camname,deg", [("tiny", "ring13roll", 3), ("tiny_strands", "ring13roll", 2), ("tiny", "front", 0)])
+def test_fused_projection_camera_cotangents(hostsim, cfg, camname, deg):
+    spec = syn.CONFIGS[cfg]
+    model = syn.make_model(spec)
+    model.active_sh_degree = deg
+    cam = syn.make_view(spec, "cpu", camname)
+    narrow = camname == "ring13roll" and cfg == "tiny"
+    if narrow:
+        # narrow the field of view so that part of the Gaussians sits outside the 1.3 tan(FoV / 2) clamp of tx / tz, ty / tz:
+        # only those feed gradient into the clamp's tensor bounds
+        import math
+        from gaussianhaircut_amd.scene.cameras import Camera
+        cam = Camera(cam.R, cam.T, math.radians(14.0), math.radians(9.0), spec.W, spec.H)
+    P = spec.P
+    keep_alive = []
+    a = hp.model_args_from(model, cam, keep_alive)
+    md, _ = to_double(model, cam)
+    lc = LeafCamera(cam)
+    conic, means2D, colors, opac, keep = torch_pipeline(md, lc)
+    keep = keep.numpy()
+    txtz = (md.get_xyz.detach() @ lc.world_view_transform.detach()[:3, :3] + lc.world_view_transform.detach()[3, :3])
+    outside = ((txtz[:, 0] / txtz[:, 2]).abs() > 1.3 * lc.tanfov[0].item()) | ((txtz[:, 1] / txtz[:, 2]).abs() > 1.3 * lc.tanfov[1].item())
+    if narrow:
+        assert (outside.numpy() & keep).sum() > 10  # the clamp-bound terms are exercised
+    g = torch.Generator().manual_seed(29)
+    g_conic = torch.randn(P, 3, generator=g, dtype=torch.float64)
+    g_m = torch.randn(P, 2, generator=g, dtype=torch.float64)
+    g_col = torch.randn(P, 10, generator=g, dtype=torch.float64)
+    g_op = torch.randn(P, 1, generator=g, dtype=torch.float64)
+    mask = torch.from_numpy(keep.astype(np.float64))[:, None]
+    gacc = np.zeros((P, 16), np.float32)
+    gacc[:, 0:2] = g_m.numpy()
+    gacc[:, 2] = g_conic[:, 0].numpy()
+    gacc[:, 3] = 0.5 * g_conic[:, 1].numpy()
+    gacc[:, 4] = g_conic[:, 2].numpy()
+    gacc[:, 5] = g_op[:, 0].numpy()
+    gacc[:, 6:16] = g_col.numpy()
+    gacc *= keep[:, None]
+    radii_in = (keep * 1).astype(np.int32)
+    for detach in (0, 1):
+        for t in (lc.world_view_transform, lc.full_proj_transform, lc.camera_center, lc.tanfov):
+            t.grad = None
+        m2 = means2D.detach() if detach else means2D
+        L = ((conic * g_conic).sum(-1, keepdim=True) * mask).sum() + ((m2[:, :2] * g_m).sum(-1, keepdim=True) * mask).sum() \
+            + ((colors * g_col).sum(-1, keepdim=True) * mask).sum() + (opac * g_op * mask).sum()
+        L.backward(retain_graph=True)
+        K = 16
+        outs = dict(d_means2D=np.zeros((P, 3), np.float32), d_xyz=np.zeros((P, 3), np.float32),
+                    d_ls=np.zeros((P, 3), np.float32), d_rot=np.zeros((P, 4), np.float32), d_op=np.zeros(P, np.float32),
+                    d_label=np.zeros(P, np.float32), d_conf=np.zeros(P, np.float32),
+                    d_fdc=np.zeros((P, 1, 3), np.float32), d_frest=np.zeros((P, K - 1, 3), np.float32))
+        camv = np.full((P, 32), np.nan, np.float32)
+        hostsim.L.ghrsim_project_backward3(ctypes.byref(a), ctypes.c_void_p(radii_in.ctypes.data),
+                                           ctypes.c_void_p(gacc.ctypes.data),
+                                           *[ctypes.c_void_p(outs[k].ctypes.data) for k in
+                                             ("d_means2D", "d_xyz", "d_ls", "d_rot", "d_op", "d_label", "d_conf", "d_fdc",
+                                              "d_frest")], None, ctypes.c_void_p(camv.ctypes.data), detach)
+        assert np.isfinite(camv).all() and np.all(camv[:, 29:] == 0) and np.all(camv[~keep] == 0)
+        dv, dp, dc, dt = cam_vector_to_tensors(camv.astype(np.float64).sum(0))
+        gz = lambda t: np.zeros(tuple(t.shape)) if t.grad is None else t.grad.numpy()  # (degree 0: no view direction)
+        ref = dict(view=gz(lc.world_view_transform), proj=np.zeros((4, 4)) if detach else gz(lc.full_proj_transform),
+                   campos=gz(lc.camera_center), tanfov=gz(lc.tanfov))
+        got = dict(view=dv, proj=dp, campos=dc, tanfov=dt)
+        for k in ref:
+            scale = np.abs(ref[k]).max()
+            # fp32 per-Gaussian terms summed in double against fp64 autograd, relative to the tensor's largest entry
+            assert np.abs(got[k] - ref[k]).max() <= 1e-4 * scale + 1e-30, (k, detach, got[k], ref[k])
+        if narrow and not detach:
+            assert np.abs(ref["tanfov"]).min() > 0 and np.abs(ref["campos"]).max() > 0
+        # the parameter gradients are those of the camera-less instantiation, bit for bit
+        outs2 = {k: np.zeros_like(v) for k, v in outs.items()}
+        hostsim.L.ghrsim_project_backward3(ctypes.byref(a), ctypes.c_void_p(radii_in.ctypes.data),
+                                           ctypes.c_void_p(gacc.ctypes.data),
+                                           *[ctypes.c_void_p(outs2[k].ctypes.data) for k in
+                                             ("d_means2D", "d_xyz", "d_ls", "d_rot", "d_op", "d_label", "d_conf", "d_fdc",
+                                              "d_frest")], None, None, detach)
+        for k in outs:
+            assert np.array_equal(outs[k], outs2[k]), k
