@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "ghr_binning.h"
 #include "ghr_device.h"
@@ -420,6 +421,16 @@ int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t row
     carve_img(align_base(img_ws), (size_t)a.W * a.H, (size_t)T, &im);
     // (a recycled workspace -- ghr_model_args.img_ws_recycled -- has its counters at zero already: k_tile_sort left them there)
     if (first && !m->img_ws_recycled) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
+    if (first && m->img_ws_recycled && m->debug) {
+        // the promise is otherwise taken on trust: under `debug` the counters are read back and must all be zero
+        std::vector<uint32_t> h(2 * (size_t)T);
+        GHR_HIP(hipMemcpyAsync(h.data(), im.tile_count, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, s));
+        GHR_HIP(hipStreamSynchronize(s));
+        for (uint32_t v : h)
+            if (v != 0)
+                return fail(GHR_E_INVALID, "ghr_model_args.img_ws_recycled is set but the workspace's per-tile counters are not zero "
+                                           "(was it through stage 1 AND stage 2 of a pass with P > 0 at the same W x H?)");
+    }
     // rows between the end of this segment and the next multiple of 256 are padding: culled, no gradient slots
     const int end = a.row0 + a.P;
     const int pad_end = (int)std::min<long long>((long long)n_blocks(end) * GHR_BLOCK, rows_total);

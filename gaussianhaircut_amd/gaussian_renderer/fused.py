@@ -266,8 +266,11 @@ def camera_inputs(cam):
     property read ONCE (the reference's trainable Camera rebuilds its matrices on every access, src/scene/cameras.py:113-151).
     A FoV that is part of the autograd graph (trainable intrinsics, :93-105) goes to the kernels as a DEVICE tensor
     {tan(FoVx / 2), tan(FoVy / 2)} -- differentiable, and never read back by the host; a constant FoV as two host floats."""
-    view, proj, campos = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
-    fx, fy = cam.FoVx, cam.FoVy
+    if hasattr(cam, "tensors"):  # (scene.cameras.TrainableCamera: all five from one evaluation of the camera's graph)
+        view, proj, campos, fx, fy = cam.tensors()[:5]
+    else:
+        view, proj, campos = cam.world_view_transform, cam.full_proj_transform, cam.camera_center
+        fx, fy = cam.FoVx, cam.FoVy
     live = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (fx, fy))
     if live:
         dev = view.device

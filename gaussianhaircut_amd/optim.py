@@ -454,7 +454,9 @@ class FusedAdam:
     def moments_stale(self) -> bool:
         """True when this rank's moments are current only on the slices it owns (after a sharded step on more than one
         rank): state_dict() / capture() then need sync_moments() -- on every rank -- first."""
-        return self._moment_shards is not None and collectives_on()
+        # (one rank under GHR_FORCE_COLLECTIVES=1 runs the collectives but owns every slice: nothing is stale there)
+        return (self._moment_shards is not None and dist.is_available() and dist.is_initialized() and
+                dist.get_world_size() > 1)
 
     def sync_moments(self):
         """All-gather the Adam moments of the sharded ranges so that every rank holds all of them again (no-op when the

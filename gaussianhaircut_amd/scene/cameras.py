@@ -33,9 +33,77 @@ class Camera:
 
     def to(self, device):
         for k, v in list(self.__dict__.items()):
-            if isinstance(v, torch.Tensor):
-                setattr(self, k, v.to(device))
+            if isinstance(v, torch.nn.Parameter):
+                self.__dict__[k] = torch.nn.Parameter(v.detach().to(device), requires_grad=v.requires_grad)
+            elif isinstance(v, torch.Tensor):
+                self.__dict__[k] = v.to(device)
         return self
+
+
+def ortho2rotation(poses: torch.Tensor) -> torch.Tensor:
+    """6D rotation parametrisation -> rotation matrix with columns (x, y, z): Gram-Schmidt of the two 3-vectors, z = x cross y
+    (semantics of the reference's ``ortho2rotation``, src/scene/cameras.py:170-197, incl. its clamp(|x|^2, 1e-8) + 1e-10)."""
+    x_raw, y_raw = poses[..., 0:3], poses[..., 3:6]
+    x = torch.nn.functional.normalize(x_raw, dim=-1)
+    factor = (x * y_raw).sum(-1, keepdim=True) / (torch.clamp((x ** 2).sum(-1, keepdim=True), min=1e-8) + 1e-10)
+    y = torch.nn.functional.normalize(y_raw - factor * x, dim=-1)
+    z = torch.cross(x, y, dim=-1)
+    return torch.stack([x, y, z], -1)
+
+
+class TrainableCamera(Camera):
+    """A camera whose pose and field of view are functions of trainable residuals, as the reference trains them by default
+    (src/arguments/__init__.py:61-62; parametrisation of src/scene/cameras.py:85-151, the ``use_barf = False`` branch):
+    ``world_view_transform = (W2C @ [[R(rotation_res), translation_res], [0, 1]])^T``, ``FoV = FoV0 + fov_res``.  The reference
+    rebuilds every matrix on every property access (and inverts a 4x4 for the camera centre); here ``tensors()`` builds all
+    five once per call under autograd -- ``render()`` asks for them once per view (``fused.camera_inputs``) -- and the
+    properties are thin views of the same computation for code that reads them one by one.  BARF's se(3) parametrisation
+    (utils/camera_opt_utils.py) is out of scope: any camera class whose five tensors carry a graph works the same way."""
+
+    def __init__(self, R, T, FoVx, FoVy, width, height, znear=0.01, zfar=100.0, device="cpu", image_name="synthetic",
+                 trainable_cameras=True, trainable_intrinsics=True):
+        base = Camera(R, T, FoVx, FoVy, width, height, znear, zfar, device, image_name)
+        dev = torch.device(device)
+        fixed = dict(base.__dict__)
+        self._colmap_transform = fixed.pop("world_view_transform").transpose(0, 1).contiguous()   # W2C
+        self._FoVx, self._FoVy = fixed.pop("FoVx"), fixed.pop("FoVy")
+        for k in ("projection_matrix", "full_proj_transform", "camera_center"):
+            fixed.pop(k)
+        self.__dict__.update(fixed)  # image size, znear / zfar, R / T, name, ground-truth slots
+        self.trainable_cameras, self.trainable_intrinsics = bool(trainable_cameras), bool(trainable_intrinsics)
+        self._rotation_res = torch.nn.Parameter(torch.eye(3, 3)[:2].reshape(-1).clone().to(dev), requires_grad=self.trainable_cameras)
+        self._translation_res = torch.nn.Parameter(torch.zeros(3, device=dev), requires_grad=self.trainable_cameras)
+        self._fov_res = torch.nn.Parameter(torch.zeros(2, device=dev), requires_grad=self.trainable_intrinsics)
+        P0 = torch.zeros(4, 4)
+        P0[2, 3], P0[2, 2], P0[3, 2] = 1.0, zfar / (zfar - znear), -(zfar * znear) / (zfar - znear)  # (already transposed)
+        self._proj_const = P0.to(dev)
+        e = torch.zeros(2, 4, 4)
+        e[0, 0, 0] = e[1, 1, 1] = 1.0
+        self._proj_slots = e.to(dev)
+        self._bottom = torch.tensor([[0.0, 0.0, 0.0, 1.0]], device=dev)
+
+    def parameters(self):
+        return [self._rotation_res, self._translation_res, self._fov_res]
+
+    def tensors(self):
+        """(world_view_transform, full_proj_transform, camera_center, FoVx, FoVy, projection_matrix), one graph."""
+        R_a = ortho2rotation(self._rotation_res)
+        residual = torch.cat([torch.cat([R_a, self._translation_res[:, None]], dim=1), self._bottom], dim=0)
+        view = (self._colmap_transform @ residual).transpose(0, 1)
+        fov = torch.stack([self._FoVx, self._FoVy]) + self._fov_res
+        inv_tan = 1.0 / torch.tan(fov * 0.5)   # P[0,0] = 2 n / (2 n tan(FoVx / 2)), graphics_utils.py:64-65
+        proj = self._proj_const + (self._proj_slots * inv_tan[:, None, None]).sum(0)
+        full = view @ proj
+        # camera centre: the reference inverts the 4x4 (cameras.py:150); for a rigid transform inverse(view)[3, :3] = -t R^T
+        center = -(view[3, :3] @ view[:3, :3].transpose(0, 1))
+        return view, full, center, fov[0], fov[1], proj
+
+    world_view_transform = property(lambda self: self.tensors()[0])
+    full_proj_transform = property(lambda self: self.tensors()[1])
+    camera_center = property(lambda self: self.tensors()[2])
+    FoVx = property(lambda self: self.tensors()[3])
+    FoVy = property(lambda self: self.tensors()[4])
+    projection_matrix = property(lambda self: self.tensors()[5])
 
 
 def make_camera(width, height, fovy_deg=40.0, distance=4.0, device="cpu") -> Camera:
@@ -45,7 +113,7 @@ def make_camera(width, height, fovy_deg=40.0, distance=4.0, device="cpu") -> Cam
     return Camera(np.eye(3), np.array([0.0, 0.0, distance]), fovx, fovy, width, height, device=device)
 
 
-def ring_cameras(n, width, height, radius=4.0, fovy_deg=40.0, device="cpu", roll_deg=0.0):
+def ring_cameras(n, width, height, radius=4.0, fovy_deg=40.0, device="cpu", roll_deg=0.0, cls=None):
     """SURVEY.md 8(d) cfg 4: azimuth 360*k/n, elevation 10*sin(2*pi*k/n) degrees, looking at the origin.
     ``roll_deg`` turns every camera about its own viewing axis (COLMAP poses are never upright: the parity tests use it
     so that all nine entries of the view rotation are non-trivial)."""
@@ -64,7 +132,7 @@ def ring_cameras(n, width, height, radius=4.0, fovy_deg=40.0, device="cpu", roll
             right, up = cr * right + sr * up, -sr * right + cr * up
         R_c2w = np.stack([right, up, fwd], axis=1)  # columns = camera axes in world
         T = -R_c2w.T @ c
-        cams.append(Camera(R_c2w, T, fovx, fovy, width, height, device=device, image_name="ring%03d" % k))
+        cams.append((cls or Camera)(R_c2w, T, fovx, fovy, width, height, device=device, image_name="ring%03d" % k))
     return cams
 
 

@@ -171,7 +171,9 @@ typedef struct ghr_model_args {
     /* ABI 16.  != 0: img_ws is the image workspace of an EARLIER forward pass of the same W x H whose stage 1 AND stage 2 were
      * both launched, ordered before this call on the stream (or through events), and which nobody has written since.  Its
      * per-tile counters are then back at zero -- k_tile_scan turns the counts into append cursors starting at 0 and stage 2's
-     * tile sort resets every cursor -- so stage 1 does not launch its zero-fill (one ~5-us launch per view).  0: any buffer. */
+     * tile sort resets every cursor -- so stage 1 does not launch its zero-fill (one ~5-us launch per view).  0: any buffer.
+     * A pass with P == 0 does NOT qualify (both stages return before touching the workspace).  With `debug` set the library
+     * reads the counters back and fails with GHR_E_INVALID if any is non-zero; otherwise the promise is taken on trust. */
     int32_t img_ws_recycled;
     /* ---- ABI 17: trainable cameras.  The reference's projection graph is differentiable w.r.t. the camera
      * (src/scene/gaussian_model.py:258-266,279-294,332-335; src/gaussian_renderer/__init__.py:59), whose tensors are functions

@@ -545,55 +545,49 @@ def _trainable_camera(spec, dev):
     return cam
 
 
-def test_trainable_camera_takes_the_generic_path_and_keeps_its_gradients(monkeypatch):
-    """VERDICT r2 missing #2: the fused projection kernels take the camera as constants, so a camera whose tensors
-    require grad must not take the fused path (its gradients would be dropped silently).  render() with the DEFAULT pipe
-    on a GaussianModel + trainable camera: the fused entry point is never called, and d loss / d (view matrix, FoV) of
-    the HIP path agree with the same PyTorch projection graph around the CPU oracle (the chain every other parity test
-    is anchored to); under no_grad the same camera takes the fused path again."""
+def test_trainable_camera_takes_the_fused_path_and_keeps_its_gradients(monkeypatch):
+    """ABI 17 (VERDICT r5 missing #1; rounds 2-5 sent such a camera down the generic path): render() with the DEFAULT pipe on
+    a GaussianModel + a camera whose tensors are FUNCTIONS of trainable leaves (full_proj = view @ P, centre = inverse(view),
+    as src/scene/cameras.py:113-151 builds them) takes the fused entry point, and d loss / d (view matrix, FoV) -- the camera
+    cotangents of k_project_bwd<CAM> + k_cam_fold carried on by autograd through the camera's own graph -- agree with the same
+    PyTorch projection graph around the CPU oracle (the chain every other parity test is anchored to)."""
     from tests import oracle_backend as ob
     import gaussianhaircut_amd.gaussian_renderer.fused as fused_mod
     dev = torch.device("cuda:0")
     spec, deg = syn.CONFIGS["tiny"], 2
     g = torch.Generator().manual_seed(11)
     weights = torch.randn(6, spec.H, spec.W, generator=g)
+    called = []
+    orig = fused_mod.render_model_fused
+    monkeypatch.setattr(fused_mod, "render_model_fused", lambda *a, **k: (called.append(1), orig(*a, **k))[1])
 
-    def run(device, pipe, guard):
+    def run(device, pipe):
         model = _model(spec, device, deg)
         cam = _trainable_camera(spec, device)
-        if guard:
-            monkeypatch.setattr(fused_mod, "render_model_fused",
-                                lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused path taken")))
         pkg = render(cam, model, pipe, syn.background(device))
         full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
         (full * weights.to(device)).sum().backward()
-        monkeypatch.undo()
         return (pkg, cam.world_view_transform.grad.cpu().numpy(), cam.FoVx.grad.item(), cam.FoVy.grad.item(),
                 model._xyz.grad.cpu().numpy())
 
     with ob.oracle_rasterizer():
-        pc, vc, fxc, fyc, xc = run("cpu", GENERIC, False)
+        pc, vc, fxc, fyc, xc = run("cpu", GENERIC)
     st = ob.LAST["state"]
-    ph, vh, fxh, fyh, xh = run(dev, FUSED, True)   # FUSED = the default pipe: fused_projection=True
+    assert not called
     mask = np.asarray(st.fragile).reshape(spec.H, spec.W).astype(bool)
     assert mask.mean() < 0.02
     weights = weights * torch.from_numpy(~mask).float()
     with ob.oracle_rasterizer():
-        pc, vc, fxc, fyc, xc = run("cpu", GENERIC, False)
-    ph, vh, fxh, fyh, xh = run(dev, FUSED, True)
+        pc, vc, fxc, fyc, xc = run("cpu", GENERIC)
+    ph, vh, fxh, fyh, xh = run(dev, FUSED)   # FUSED = the default pipe: fused_projection=True
+    assert called, "the fused path must serve a trainable camera"
     assert np.abs(vc).max() > 0 and np.isfinite(vh).all()
-    # rows 0..2 x cols 0..2 and the translation row carry gradient; column 3 of W2C^T does not enter the projection
-    tol = 1e-4 * (np.abs(vc) + np.abs(vc).max())
+    # rows 0..2 x cols 0..2 and the translation row carry gradient; column 3 of W2C^T does not enter the projection.
+    # The camera's gradients are sums over all Gaussians: relative to the tensor's largest entry
+    tol = 2e-4 * np.abs(vc).max()
     assert (np.abs(vh - vc) <= tol).all(), (vh, vc)
-    assert abs(fxh - fxc) <= 1e-4 * (abs(fxc) + abs(fyc)) and abs(fyh - fyc) <= 1e-4 * (abs(fxc) + abs(fyc))
+    assert abs(fxh - fxc) <= 2e-4 * (abs(fxc) + abs(fyc)) and abs(fyh - fyc) <= 2e-4 * (abs(fxc) + abs(fyc))
     _assert_rows_close("xyz", xh, xc)
-    # without autograd recording nothing can be lost: the fused path serves the same camera
-    called = []
-    orig = fused_mod.render_model_fused
-    monkeypatch.setattr(fused_mod, "render_model_fused", lambda *a, **k: (called.append(1), orig(*a, **k))[1])
-    with torch.no_grad():
-        render(_trainable_camera(spec, dev), _model(spec, dev, deg), FUSED, syn.background(dev))
-    assert called
 
 
 @pytest.mark.parametrize("pipe", [FUSED, GENERIC])
@@ -633,7 +627,7 @@ def test_deferred_gradient_zeroing_is_invisible_or_loud():
     to the eager run (GHR_DEFER_GRAD_ZEROING=0 semantics: trainer.DEFER_GRAD_ZEROING = False); (b) a step() without a
     backward in between sees zeros; (c) optimizer surgery in between (reset_opacity) works; (d) accumulating gradients by
     other means while the buffer is undefined fails loudly at the next step instead of stepping on garbage; (e) a step
-    that cannot take the fused path (trainable camera) gets the zeros first."""
+    that does not take the fused path (pipe.fused_projection = False) gets the zeros first."""
     import gaussianhaircut_amd.trainer as tr
     from gaussianhaircut_amd import _lib
     from gaussianhaircut_amd.scene.cameras import ring_cameras
@@ -703,11 +697,12 @@ def test_deferred_gradient_zeroing_is_invisible_or_loud():
         tr.DEFER_GRAD_ZEROING = False
         training_step(ref, cams[:1], bg, opt, 1)
         tr.DEFER_GRAD_ZEROING = True
+        generic = SimpleNamespace(**{**vars(tr.PIPE), "fused_projection": False})
         for m in (model, ref):
             cam = _trainable_camera(spec, dev)              # a fresh graph per model: full_proj = f(view matrix)
             with torch.no_grad():
                 make_ground_truth(gt, [cam], bg)
-            training_step(m, [cam], bg, opt, 2)             # generic path: gradients through autograd
+            training_step(m, [cam], bg, opt, 2, pipe=generic)   # generic path: gradients through autograd
         torch.cuda.synchronize()
         assert model.optimizer._deferred is None
         assert torch.equal(model.optimizer.flat_param, ref.optimizer.flat_param)
@@ -736,8 +731,8 @@ def test_recycled_image_workspace_skips_the_zero_fill_and_changes_nothing():
         seen = []
         orig = fused._ImgLease.__init__
 
-        def spy(self, d, n, _orig=orig, _seen=seen):
-            _orig(self, d, n)
+        def spy(self, d, n, w, h, _orig=orig, _seen=seen):
+            _orig(self, d, n, w, h)
             _seen.append(self.recycled)
         fused._ImgLease.__init__ = spy
         try:
@@ -757,3 +752,37 @@ def test_recycled_image_workspace_skips_the_zero_fill_and_changes_nothing():
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
         # (the gradient walk's atomics are unordered: same sums, last-bit differences between any two runs)
         assert torch.allclose(a[2], b[2], rtol=1e-5, atol=1e-7 * float(a[2].abs().max()))
+
+
+def test_empty_model_pass_never_pools_its_image_workspace():
+    """with P == 0 the library returns from stage 1 and stage 2 without touching the image workspace, so
+    that pass's (uninitialised) buffer must not enter the recycling pool -- the next P > 0 pass at the same size would skip the
+    counters' zero-fill over garbage.  Render an empty model, then a real one, same W x H, same stream, in debug mode (the
+    library then verifies a recycled workspace's counters itself); result == a fresh-pool render, bit for bit."""
+    from gaussianhaircut_amd.gaussian_renderer import fused
+    from gaussianhaircut_amd.scene.gaussian_model import GaussianModel
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    cam = syn.make_view(spec, dev)
+    model = _model(spec, dev, 2)
+    dbg = SimpleNamespace(debug=True, fused_projection=True)
+    fused._ImgLease._pools.clear()
+    with torch.no_grad():
+        ref = render(cam, model, dbg, syn.background(dev))
+        ref_img, ref_radii = ref["render"].clone(), ref["radii"].clone()
+    del ref
+    fused._ImgLease._pools.clear()
+    empty = GaussianModel(3)
+    for n in ("_xyz", "_scaling", "_rotation", "_opacity", "_label", "_orient_conf", "_features_dc", "_features_rest"):
+        setattr(empty, n, torch.nn.Parameter(getattr(model, n).detach()[:0].clone()))
+    empty.active_sh_degree = 2
+    # poison whatever buffer the allocator hands the empty pass (and, if it were pooled, the next pass)
+    junk = torch.full((64 << 20,), 0x7F, dtype=torch.uint8, device=dev)
+    del junk
+    pkg0 = render(cam, empty, dbg, syn.background(dev))
+    assert float(pkg0["render"].abs().max()) == 0.0 and pkg0["radii"].numel() == 0
+    del pkg0
+    assert not any(fused._ImgLease._pools.values()), "the empty pass's workspace was pooled"
+    with torch.no_grad():
+        pkg = render(cam, model, dbg, syn.background(dev))
+    assert torch.equal(pkg["render"], ref_img) and torch.equal(pkg["radii"], ref_radii)
