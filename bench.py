@@ -325,6 +325,23 @@ def main():
         out["fixed_camera_step"] = {"ms_per_step": round(1e3 * e1 / K, 4), "steps": K,
                                     "headline_over_fixed": round(ms_per_step / (1e3 * e1 / K), 4)}
 
+    # ---- ... and with the stage-1 loop's per-iteration densification statistics (train_gaussians.py:161-165: every iteration
+    # below densify_until_iter, half of a run) kept by k_project_bwd itself
+    if world == 1 and len(pool) > 1:
+        def stats_steps(n_warm, n_steps, it0):
+            for i in range(n_warm + n_steps):
+                if i == n_warm:
+                    sync_all()
+                    t_ = time.perf_counter()
+                training_step(model, [pool[(i * V + j) % len(pool)] for j in range(V)], bg, opt, it0 + i + 1,
+                              global_views=V * world, streams=args.streams, densify_stats=True)
+            sync_all()
+            return time.perf_counter() - t_
+        e2 = stats_steps(3, K, Wm + 2 * K + 3)
+        out["densify_stats_step"] = {"ms_per_step": round(1e3 * e2 / K, 4), "steps": K,
+                                     "over_headline_us": round(1e3 * (1e3 * e2 / K - ms_per_step), 2),
+                                     "seen_fraction": round(float((model.denom > 0).float().mean().item()), 4)}
+
     # ---- BASELINE configs[3]'s per-GPU shard: VS views per GPU per global step (every N; same model, continues training)
     if VS > 0 and VS != V:
         K4 = max(5, K // 2)

@@ -97,8 +97,10 @@ class ModelArgs(ctypes.Structure):
                 ("dir3d", ctypes.c_void_p)] + \
                [(n, ctypes.c_float) for n in ("const_opacity", "const_label", "const_conf")] + \
                [("img_ws_recycled", ctypes.c_int32)] + \
-               [("tanfov_dev", ctypes.c_void_p), ("cam_partial", ctypes.c_void_p), ("cam_slot0", ctypes.c_int32),
-                ("cam_slots", ctypes.c_int32), ("cam_only", ctypes.c_int32), ("detach_means2D", ctypes.c_int32)]
+               [("fovx_dev", ctypes.c_void_p), ("fovy_dev", ctypes.c_void_p), ("cam_partial", ctypes.c_void_p), ("cam_slot0", ctypes.c_int32),
+                ("cam_slots", ctypes.c_int32), ("cam_only", ctypes.c_int32), ("detach_means2D", ctypes.c_int32),
+                ("dens_grad_accum", ctypes.c_void_p), ("dens_denom", ctypes.c_void_p), ("dens_max_radii2D", ctypes.c_void_p),
+                ("dens_img_ws", ctypes.c_void_p)]
 
 
 class LossArgs(ctypes.Structure):
@@ -179,7 +181,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_render_backward.argtypes = [vp, i32, i32, i32, u32] + [vp] * 6 + [i32]
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_camera_slots.argtypes = [i32]
-    L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp]
+    L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp, vp, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

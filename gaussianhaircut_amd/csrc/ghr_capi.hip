@@ -398,7 +398,8 @@ int fill_model(const ghr_model_args* m, ghr::ModelArgs* a)
     a->focal_y = m->H / (2.0f * m->tan_fovy);
     a->focal_x = m->W / (2.0f * m->tan_fovx);
     a->conic_eps = m->conic_eps;
-    a->tanfov = m->tanfov_dev;
+    if ((m->fovx_dev != nullptr) != (m->fovy_dev != nullptr)) return fail(GHR_E_INVALID, "ghr_model_args: fovx_dev and fovy_dev: both or neither");
+    a->fovx = m->fovx_dev; a->fovy = m->fovy_dev;
     a->rec = nullptr; a->depths = nullptr; a->rects = nullptr; a->radii = nullptr; a->means2D = nullptr;
     a->tile_count = nullptr; a->slot_blk = nullptr; a->pos = nullptr;
     return GHR_OK;
@@ -539,6 +540,16 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     mg.accumulate = accumulate; mg.nan_flag = cam_only ? nullptr : nan_flag;
     mg.cam_partial = m->cam_partial; mg.cam_slot0 = (uint32_t)m->cam_slot0; mg.cam_stride = (uint32_t)m->cam_slots;
     mg.cam_only = cam_only ? 1 : 0; mg.detach_means2D = m->detach_means2D != 0 ? 1 : 0;
+    const int n_dens = (m->dens_grad_accum != nullptr) + (m->dens_denom != nullptr) + (m->dens_max_radii2D != nullptr);
+    if (n_dens != 0 && n_dens != 3)
+        return fail(GHR_E_INVALID, "ghr_model_backward_segment: dens_grad_accum / dens_denom / dens_max_radii2D: all three or none");
+    mg.dens_grad_accum = m->dens_grad_accum; mg.dens_denom = m->dens_denom; mg.dens_max_radii = m->dens_max_radii2D;
+    mg.dens_count = nullptr; mg.dens_cap = R;
+    if (n_dens == 3 && m->dens_img_ws) {
+        Img im;
+        carve_img(align_base(m->dens_img_ws), (size_t)a.W * a.H, (size_t)a.gx * a.gy, &im);
+        mg.dens_count = im.R_dev;
+    }
     const dim3 grid((a.P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), block(GHR_PBW_BLOCK);
     if (mg.cam_partial) hipLaunchKernelGGL(ghr::k_project_bwd<true>, grid, block, 0, s, a, mg);
     else hipLaunchKernelGGL(ghr::k_project_bwd<false>, grid, block, 0, s, a, mg);
@@ -547,15 +558,18 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
 
 int32_t ghr_camera_slots(int32_t P) { return P > 0 ? (P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK : 0; }
 
-int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam)
+int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam, const float* fovx_dev,
+                         const float* fovy_dev)
 {
-    if (!d_cam || cam_slots < 0 || (cam_slots > 0 && !cam_partial)) return fail(GHR_E_INVALID, "ghr_camera_grad_fold: bad args");
+    if (!d_cam || cam_slots < 0 || (cam_slots > 0 && !cam_partial) || ((fovx_dev != nullptr) != (fovy_dev != nullptr)))
+        return fail(GHR_E_INVALID, "ghr_camera_grad_fold: bad args");
     hipStream_t s = (hipStream_t)stream;
     if (cam_slots == 0) {
         GHR_HIP(hipMemsetAsync(d_cam, 0, sizeof(float) * GHR_CAM_GRADS, s));
         return finish(s, 0);
     }
-    hipLaunchKernelGGL(ghr::k_cam_fold, dim3(GHR_CAM_PARTIALS), dim3(256), 0, s, cam_partial, (uint32_t)cam_slots, d_cam);
+    hipLaunchKernelGGL(ghr::k_cam_fold, dim3(GHR_CAM_PARTIALS), dim3(GHR_CAM_FOLD_BLOCK), 0, s, cam_partial, (uint32_t)cam_slots,
+                       d_cam, fovx_dev, fovy_dev);
     return finish(s, 0);
 }
 

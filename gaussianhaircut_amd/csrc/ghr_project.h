@@ -52,8 +52,8 @@ struct ModelArgs {
     const float* proj;            // [16] full_proj_transform
     const float* campos;          // [3]
     float scale_modifier, tan_fovx, tan_fovy, focal_x, focal_y, conic_eps;
-    const float* tanfov;          // [2] device {tan(FoVx / 2), tan(FoVy / 2)} or NULL: overrides tan_fov* / focal_* above
-                                  // (a trainable FoV changes every step: read here, the host never waits for its value)
+    const float* fovx;            // device scalars FoVx, FoVy (radians) or NULL, NULL: override tan_fov* / focal_* above --
+    const float* fovy;            // a trainable FoV changes every step: tan(FoV / 2) is taken here, the host never waits for it
     // forward outputs
     f4* rec;
     float* depths;
@@ -90,6 +90,16 @@ struct ModelGrads {
     int cam_only;             // != 0: nothing but d_means2D and the camera partials is written (frozen head segment)
     int detach_means2D;       // != 0: the NDC means are constants of the graph (render_hair() detaches the head's,
                               // gaussian_renderer/__init__.py:136): no gradient through full_proj_transform
+    // Per-iteration densification statistics of the stage-1 loop (train_gaussians.py:161-165, gaussian_model.py:739-741), folded
+    // into this pass (all three or none): for every Gaussian the view sees (radius > 0)
+    //   xyz_gradient_accum += |d_means2D.xy|,  denom += 1,  max_radii2D = max(max_radii2D, radius)
+    float* dens_grad_accum;   // [P] (tensor [P,1])
+    float* dens_denom;        // [P] (tensor [P,1])
+    float* dens_max_radii;    // [P] float, like the reference's
+    const uint32_t* dens_count;  // optional: the view's instance count on the device (k_tile_scan's R_dev) ...
+    uint32_t dens_cap;           // ... the update is skipped when it exceeds this capacity: the view was rasterized with a guessed
+                                 // capacity that turned out too small (include/ghr.h, ghr_forward_stage2), its gradients are
+                                 // invalid and the caller recomputes the view -- statistics must not be counted twice
 };
 
 // Camera cotangents a Gaussian contributes (the reference's projection graph is differentiable w.r.t. the camera:
@@ -98,7 +108,7 @@ struct ModelGrads {
 // residuals).  Only the entries that can be non-zero are carried:
 //   [0..11]  d view[4 r + c], r = 0..3, c = 0..2  (column 3 of world_view_transform is never read)      at 3 r + c
 //   [12..23] d proj[4 r + c], r = 0..3, c in {0, 1, 3}  (NDC z carries no gradient, rasterize_points.cu:160) at 12 + 3 r + {0,1,2}
-//   [24..26] d camera_center     [27..28] d tan(FoVx / 2), d tan(FoVy / 2)     [29..31] zero
+//   [24..25] d tan(FoVx / 2), d tan(FoVy / 2)     [26..28] d camera_center     [29..31] zero
 #ifndef GHR_CAM_PARTIALS  // (include/ghr.h states the same two numbers for the callers)
 #define GHR_CAM_PARTIALS 32
 #define GHR_CAM_GRADS 37  // what k_cam_fold writes: view[16] | proj[16] | camera_center[3] | tanfov[2]
@@ -267,15 +277,15 @@ GHR_HD void proj_setup(const ModelArgs& a, const RawIn& in, ProjCtx& c)
         c.Wc[col][0] = V[col]; c.Wc[col][1] = V[4 + col]; c.Wc[col][2] = V[8 + col];
     }
     const float tz = c.t[2];
-    {
-        // branch-free like load_raw: an absent table reads campos instead (always there) and the values are dropped
-        const uniform_floats tf = GHR_UNIFORM(a.tanfov ? a.tanfov : a.campos);
-        const float t0 = tf[0], t1 = tf[1];
-        c.tfx = a.tanfov ? t0 : a.tan_fovx;
-        c.tfy = a.tanfov ? t1 : a.tan_fovy;
+    if (a.fovx != nullptr) {
+        // (a uniform branch around scalar loads: they count in lgkmcnt, not in the vmcnt the kernels' waits are written for)
+        c.tfx = tanf(GHR_UNIFORM(a.fovx)[0] * 0.5f);   // torch.tan(viewpoint_camera.FoVx * 0.5), gaussian_model.py:258-259
+        c.tfy = tanf(GHR_UNIFORM(a.fovy)[0] * 0.5f);
         // focal = dim / (2 tan), gaussian_model.py:264-265 / rasterizer_impl.cu:224-225 -- the expression the host evaluates
-        c.fx = a.tanfov ? a.W / (2.0f * t0) : a.focal_x;
-        c.fy = a.tanfov ? a.H / (2.0f * t1) : a.focal_y;
+        c.fx = a.W / (2.0f * c.tfx);
+        c.fy = a.H / (2.0f * c.tfy);
+    } else {
+        c.tfx = a.tan_fovx; c.tfy = a.tan_fovy; c.fx = a.focal_x; c.fy = a.focal_y;
     }
     const float limx = 1.3f * c.tfx, limy = 1.3f * c.tfy;
     const float txtz = c.t[0] / tz, tytz = c.t[1] / tz;
@@ -606,8 +616,8 @@ GHR_HD void project_bwd_geom(const ModelArgs& a, const RawIn& in, int radius, co
                 const float Lfy = Lj11 * itz - Lj21 * (c.typ * itz2);
                 const float Llimx = c.inx ? 0.f : (c.clx > 0.f ? Ltxp * tz : -(Ltxp * tz));
                 const float Llimy = c.iny ? 0.f : (c.cly > 0.f ? Ltyp * tz : -(Ltyp * tz));
-                cam[27] = 1.3f * Llimx - Lfx * (fx / c.tfx);
-                cam[28] = 1.3f * Llimy - Lfy * (fy / c.tfy);
+                cam[24] = 1.3f * Llimx - Lfx * (fx / c.tfx);
+                cam[25] = 1.3f * Llimy - Lfy * (fy / c.tfy);
             }
         }
         const uniform_floats V = GHR_UNIFORM(a.view);
@@ -698,17 +708,19 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
 #pragma unroll
             for (int m = 0; m < 3; m++) {
                 dxyz[m] += dd[m];
-                if (CAM) cam[24 + m] = -dd[m];  // dir = xyz - camera_center (gaussian_renderer/__init__.py:59)
+                if (CAM) cam[26 + m] = -dd[m];  // dir = xyz - camera_center (gaussian_renderer/__init__.py:59)
             }
         }
     } else {
         for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
+        if (CAM) cam[26] = cam[27] = cam[28] = 0.f;
     }
 }
 
 // Writes (or accumulates into) every output element except d_rest, which stays in the caller's staging block.  Returns
 // whether any value stored was non-finite.
-GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const ProjBwdOut& o)
+GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const ProjBwdOut& o,
+                              int radius)
 {
     if (g.cam_only) return false;  // a frozen segment: only its camera cotangents are wanted
     const int acc = g.accumulate;
@@ -716,6 +728,15 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
     g.d_means2D[3 * row] = ga[0];
     g.d_means2D[3 * row + 1] = ga[1];
     g.d_means2D[3 * row + 2] = 0.f;
+    if (g.dens_grad_accum != nullptr && radius > 0 &&
+        (g.dens_count == nullptr || *reinterpret_cast<const volatile uint32_t*>(g.dens_count) <= g.dens_cap)) {
+        // torch.norm(grad[:, :2], dim=-1): sqrt of the sum of squares accumulated in index order (x^2 first, then + y * y as one
+        // fused multiply-add: ATen's reduction kernels are compiled with contraction on; verified bit for bit against
+        // add_densification_stats on the device, tests/test_gpu_fused.py)
+        g.dens_grad_accum[idx] += sqrtf(ga[0] * ga[0] + ga[1] * ga[1]);
+        g.dens_denom[idx] += 1.0f;
+        g.dens_max_radii[idx] = fmaxf(g.dens_max_radii[idx], (float)radius);
+    }
     // the values in output order; accumulating, ALL old values are requested before the first is needed (element by
     // element -- read, add, store -- the 22 of them were 22 dependent round trips per Gaussian in every view but the first)
     float v[22];
@@ -761,7 +782,7 @@ GHR_HD bool project_bwd_core(const ModelArgs& a, const ModelGrads& g, int idx, c
         project_bwd_geom<false>(a, in, radius, ga, o, nullptr, g.detach_means2D != 0);
         project_bwd_sh<false>(a, in, radius, ga, rest, d_rest, o, nullptr);
     }
-    return project_bwd_store(a, g, idx, ga, o);
+    return project_bwd_store(a, g, idx, ga, o, radius);
 }
 
 // project_bwd_core with its inputs loaded on the spot (tests/hostsim)
@@ -940,37 +961,51 @@ __global__ void __launch_bounds__(GHR_BLOCK) k_project(ModelArgs a)
 // 79.3 -> 76.5 us (128 threads: 77.5; forcing 128 VGPRs for a fourth wave per SIMD spills and loses: profiles/r05o).
 #define GHR_PBW_BLOCK 64
 #if defined(__HIP_DEVICE_COMPILE__)
-// Sum of each of the 32 values v[.] over the 64 lanes of the wave in 32 exchanges instead of 32 x 6: at every step a lane keeps
-// one half of its values and hands the other half to its partner (lane ^ 1, 2, 4, 8, 16), so the number of live values halves
-// while the number of lanes summed doubles; one more exchange joins the two halves of the wave.  Returns, on every lane, the
-// wave's total of component cam_butterfly_component(lane).  The order of the additions is fixed.
-__device__ __forceinline__ float cam_butterfly(float (&v)[GHR_CAM_PARTIALS], int lane)
+// Sum of each of the N (a power of two <= 32) values v[.] over the 64 lanes of the wave in N - 1 + (6 - log2 N) exchanges instead of
+// 6 N: at every halving step a lane keeps one half of its values and hands the other half to its partner (lane ^ 1, 2, 4, ...),
+// so the number of live values halves while the number of lanes summed doubles; the remaining steps are plain butterflies.
+// Returns, on every lane, the wave's total of component cam_butterfly_component<N>(lane).  The order of the additions is fixed.
+template <int N>
+__device__ __forceinline__ float cam_butterfly(float (&v)[N], int lane)
 {
+    constexpr int LOG = N == 32 ? 5 : (N == 16 ? 4 : (N == 8 ? 3 : (N == 4 ? 2 : 1)));
+    static_assert((1 << LOG) == N, "N must be 2, 4, 8, 16 or 32");
 #pragma unroll
-    for (int s = 0; s < 5; s++) {
-        const int n = GHR_CAM_PARTIALS >> (s + 1);
+    for (int s = 0; s < LOG; s++) {  // (a canonical loop: fully unrolled, every v[.] index a constant -- registers, not scratch)
+        const int n = N >> (s + 1);
         const bool hi = (lane >> s) & 1;
 #pragma unroll
         for (int i = 0; i < n; i++) {
-            const float keep = hi ? v[i + n] : v[i];
-            const float send = hi ? v[i] : v[i + n];
+            // (both values pinned in registers first: left to itself the compiler selects between the two ADDRESSES and the
+            // array moves to scratch)
+            float lo_v = v[i], hi_v = v[i + n];
+            asm volatile("" : "+v"(lo_v), "+v"(hi_v));
+            const float keep = hi ? hi_v : lo_v;
+            const float send = hi ? lo_v : hi_v;
             v[i] = keep + __shfl_xor(send, 1 << s);
         }
     }
-    return v[0] + __shfl_xor(v[0], 32);
+    float r = v[0];
+#pragma unroll
+    for (int w = N; w < 64; w <<= 1) r += __shfl_xor(r, w);
+    return r;
 }
-// lane bit s chose the half of size 16 >> s: the component is the bit-reversed low five bits of the lane
+// lane bit s chose the half of size N >> (s + 1): the component is the bit-reversed low log2(N) bits of the lane
+template <int N>
 __device__ __forceinline__ int cam_butterfly_component(int lane)
 {
-    return ((lane & 1) << 4) | ((lane & 2) << 2) | (lane & 4) | ((lane & 8) >> 2) | ((lane & 16) >> 4);
+    int c = 0;
+#pragma unroll
+    for (int s = 0; (N >> (s + 1)) >= 1; s++) c |= ((lane >> s) & 1) ? (N >> (s + 1)) : 0;
+    return c;
 }
 #endif
 
 // CAM: the camera cotangents as well (ModelGrads::cam_partial); the default instantiation carries none of it.
-template <bool CAM>
-__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g)
-{
 #if defined(__HIP_DEVICE_COMPILE__)
+template <bool CAM>
+__device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const ModelGrads& g)
+{
     constexpr int BLK = GHR_PBW_BLOCK;
     __shared__ __attribute__((aligned(16))) float s_rest[BLK * GHR_REST_MAX];  // coefficients in, gradients out
     const int row = 3 * (a.sh_coeffs - 1);
@@ -1008,12 +1043,22 @@ __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, Mode
         for (int i = 0; i < (CAM ? GHR_CAM_PARTIALS : 1); i++) cam[i] = 0.f;
     }
     if (idx < a.P) project_bwd_geom<CAM>(a, in, radius, ga, o, cam, g.detach_means2D != 0);
+    float cam_pos[4] = {0.f, 0.f, 0.f, 0.f};
+    float cam_geo = 0.f;
+    if constexpr (CAM) {
+        // the 26 cotangents of the geometry part are summed over the wave HERE, while the coefficient slab is still on its way
+        // (the exchanges are LDS-crossbar operations: lgkmcnt, not the vmcnt the slab is waited for with), so that only the
+        // wave total and the three camera-centre terms of the SH part stay live to the end of the kernel
+        // (in place: project_bwd_sh writes cam[26..28] afterwards, nothing else of cam[] is read again)
+        cam_geo = cam_butterfly<GHR_CAM_PARTIALS>(cam, threadIdx.x & 63);
+    }
     slab_wait();
     __syncthreads();
     bool bad = false;
+    if (CAM) cam[CAM ? 26 : 0] = cam[CAM ? 27 : 0] = cam[CAM ? 28 : 0] = 0.f;   // (lanes past the end of the segment)
     if (idx < a.P) {
         project_bwd_sh<CAM>(a, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row, o, cam);
-        bad = project_bwd_store(a, g, idx, ga, o);
+        bad = project_bwd_store(a, g, idx, ga, o, radius);
     }
     __syncthreads();
     if (row > 0 && !g.cam_only)
@@ -1021,36 +1066,86 @@ __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, Mode
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
     if constexpr (CAM) {
         const int lane = threadIdx.x & 63;
-        const float tot = cam_butterfly(cam, lane);
-        if (lane < GHR_CAM_PARTIALS)
-            g.cam_partial[(size_t)cam_butterfly_component(lane) * g.cam_stride + g.cam_slot0 + blockIdx.x] = tot;
+#pragma unroll
+        for (int i = 0; i < 3; i++) cam_pos[i] = cam[26 + i];
+        const float pos_tot = cam_butterfly<4>(cam_pos, lane);
+        float* col = g.cam_partial + g.cam_slot0 + blockIdx.x;
+        if (lane < GHR_CAM_PARTIALS) {
+            const int c = cam_butterfly_component<GHR_CAM_PARTIALS>(lane);
+            if (c < 26 || c >= 29) col[(size_t)c * g.cam_stride] = cam_geo;   // (rows 29..31: zeros)
+        } else if (lane < GHR_CAM_PARTIALS + 4) {
+            const int c = cam_butterfly_component<4>(lane);
+            if (c < 3) col[(size_t)(26 + c) * g.cam_stride] = pos_tot;
+        }
     }
+}
+#endif
+
+template <bool CAM>
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g);
+template <>
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd<false>(ModelArgs a, ModelGrads g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    project_bwd_body<false>(a, g);
+#endif
+}
+// (the LDS footprint allows three waves per SIMD either way: told so, the compiler takes the 168 registers that go with them
+// instead of holding this instantiation to the default one's 134 and spilling the camera cotangents)
+template <>
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_project_bwd<true>(ModelArgs a, ModelGrads g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    project_bwd_body<true>(a, g);
 #endif
 }
 
 // Adds up the per-workgroup camera partials (component-major [GHR_CAM_PARTIALS][n_slots]) in a fixed order, in double, and
 // writes d_cam[GHR_CAM_GRADS] = d view[16] | d proj[16] | d camera_center[3] | d tanfov[2] (entries the projection never
 // reads -- column 3 of the view matrix, column 2 of the projection matrix -- are written as zeros).  One workgroup per component.
-__global__ void __launch_bounds__(256) k_cam_fold(const float* partial, uint32_t n_slots, float* d_cam)
+// fovx / fovy (both or neither): the last two entries become dL/dFoVx, dL/dFoVy: d tan(FoV / 2) / d FoV = (1 + tan^2) / 2.
+#define GHR_CAM_FOLD_BLOCK 1024
+__global__ void __launch_bounds__(GHR_CAM_FOLD_BLOCK) k_cam_fold(const float* partial, uint32_t n_slots, float* d_cam,
+                                                                 const float* fovx, const float* fovy)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ double s_sum[256];
+    __shared__ double s_sum[GHR_CAM_FOLD_BLOCK / 64];
     const int comp = blockIdx.x;
     const float* p = partial + (size_t)comp * n_slots;
     double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < n_slots; i += 256) acc += (double)p[i];
-    s_sum[threadIdx.x] = acc;
-    __syncthreads();
-    for (int w = 128; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) s_sum[threadIdx.x] += s_sum[threadIdx.x + w];
-        __syncthreads();
+    // eight loads in flight per thread and trip (a rolled load - convert - add loop is one dependent round trip per element)
+    for (uint32_t base = 0; base < n_slots; base += 8u * GHR_CAM_FOLD_BLOCK) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t i = base + (uint32_t)j * GHR_CAM_FOLD_BLOCK + threadIdx.x;
+            v[j] = p[i < n_slots ? i : n_slots - 1u];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t i = base + (uint32_t)j * GHR_CAM_FOLD_BLOCK + threadIdx.x;
+            acc += i < n_slots ? (double)v[j] : 0.0;
+        }
     }
+#pragma unroll
+    for (int w = 32; w >= 1; w >>= 1) acc += __shfl_xor(acc, w);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = acc;
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const float v = (float)s_sum[0];
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < GHR_CAM_FOLD_BLOCK / 64; w++) tot += s_sum[w];
+        float v = (float)tot;
         if (comp < 12) d_cam[4 * (comp / 3) + comp % 3] = v;
         else if (comp < 24) { const int c = (comp - 12) % 3; d_cam[16 + 4 * ((comp - 12) / 3) + (c == 2 ? 3 : c)] = v; }
-        else if (comp < 27) d_cam[32 + comp - 24] = v;
-        else if (comp < 29) d_cam[35 + comp - 27] = v;
+        else if (comp < 26) {
+            if (fovx != nullptr) {
+                const float t = tanf((comp == 24 ? fovx[0] : fovy[0]) * 0.5f);
+                v = v * (0.5f * (1.0f + t * t));
+            }
+            d_cam[35 + comp - 24] = v;
+        } else if (comp < 29) d_cam[32 + comp - 26] = v;
         else if (comp == 29) {
 #pragma unroll
             for (int r = 0; r < 4; r++) { d_cam[4 * r + 3] = 0.f; d_cam[16 + 4 * r + 2] = 0.f; }

@@ -112,6 +112,9 @@ struct B3Shared {
     f4 rec[GHR_B3_NW][GHR_B3_NBUF][64];                        // per wave: gathered records, 16 entries x 64 B per buffer
     uint32_t cslot[GHR_B3_NW][GHR_B3_NBUF][16];                // per wave: ... and their gradient lines
     uint32_t next;                                     // next cell of the tile nobody has taken yet
+#ifdef GHR_B3_PAD_LDS
+    char pad[GHR_B3_PAD_LDS];                          // experiment knob: workgroups per CU as a function of the LDS footprint
+#endif
 };
 
 // The cells of one tile.  SMALL: the tile's ids and mask words are in LDS (n <= GHR_B3_CACHE) and the gather runs

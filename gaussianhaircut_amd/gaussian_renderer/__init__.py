@@ -71,6 +71,7 @@ class RenderPackage(dict):
         self._cov2d = cov2d
         self.renders_packed = renders
         self.count = None  # fused path: num_rendered (int) or a PendingCount
+        self.densify_stats_done = False  # fused path with pipe.densify_stats: the backward pass keeps the statistics
 
     def _materialise(self, k=None):
         if k in (None, "orient_angle") and not dict.__contains__(self, "orient_angle"):
@@ -179,11 +180,15 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         from .fused import render_model_fused
         # pipe.defer_count (set by trainer.training_step, which owns the recovery): queue the view without ever
         # reading num_rendered back; the package then carries a PendingCount in `.count`
+        # pipe.densify_stats: the view's backward pass also keeps the model's densification statistics (the package says so:
+        # trainer.densification_step then skips its own PyTorch form)
+        dens = bool(getattr(pipe, "densify_stats", False)) and torch.is_grad_enabled()
         renders, radii, screenspace_points, count = render_model_fused(
             viewpoint_camera, pc, bg_color, scaling_modifier, getattr(pipe, "debug", False),
-            defer_count=getattr(pipe, "defer_count", False) and not getattr(pipe, "debug", False))
+            defer_count=getattr(pipe, "defer_count", False) and not getattr(pipe, "debug", False), densify_stats=dens)
         pkg = _package(renders, screenspace_points, radii)
         pkg.count = count
+        pkg.densify_stats_done = dens
         return pkg
     conic = pc.get_conic(viewpoint_camera, scaling_modifier)  # must precede direction / filter (cached state)
     screenspace_points = pc.get_mean_2d(viewpoint_camera)

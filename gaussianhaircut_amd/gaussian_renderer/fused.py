@@ -55,9 +55,10 @@ class _ImgLease:
 
 
 def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug,
-                tanfov_dev=None):
+                fov_dev=None):
     m = _lib.ModelArgs()
-    m.tanfov_dev = _ptr(tanfov_dev) if tanfov_dev is not None else None
+    if fov_dev is not None:  # (FoVx, FoVy) as device scalars: the kernels take tan(FoV / 2) themselves
+        m.fovx_dev, m.fovy_dev = _ptr(fov_dev[0]), _ptr(fov_dev[1])
     m.P, m.W, m.H, m.sh_degree, m.sh_coeffs = int(P), int(W), int(H), int(sh_degree), int(K)
     (m.xyz, m.log_scales, m.rotations, m.opacity_logit, m.label_logit, m.orient_conf_log, m.features_dc,
      m.features_rest) = [_ptr(t) for t in tensors]
@@ -70,7 +71,7 @@ def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_mo
 class _RenderModelFused(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest,
-                screenspace_points, view, proj, campos, tanfov, cfg):
+                screenspace_points, view, proj, campos, fovx, fovy, cfg):
         L = _lib.lib()
         if not xyz.is_cuda:
             raise RuntimeError("gaussianhaircut_amd: parameters are on %s; the HIP renderer has no CPU path" % xyz.device)
@@ -81,10 +82,10 @@ class _RenderModelFused(torch.autograd.Function):
         K = 1 + f_rest.shape[1]
         # the camera's tensors are inputs of the op: when they are functions of trainable pose / FoV residuals
         # (src/scene/cameras.py:85-151) the backward pass returns their gradients (_camera_grads)
-        cam_in = (view, proj, campos, tanfov)
+        cam_in = (view, proj, campos, fovx, fovy)
         view, proj = view.detach().float().contiguous(), proj.detach().float().contiguous()
         campos, bg = campos.detach().float().contiguous(), cfg["bg"].float().contiguous()
-        tanfov = tanfov.detach().float().reshape(-1).contiguous() if tanfov is not None else None
+        fov = (fovx.detach().float().contiguous(), fovy.detach().float().contiguous()) if fovx is not None else None
         ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in cam_in]
         with torch.cuda.device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
@@ -94,7 +95,7 @@ class _RenderModelFused(torch.autograd.Function):
             lease = _ImgLease(dev, ibytes, W, H) if RECYCLE_IMG_WS else None
             img = lease.buf if lease is not None else torch.empty((ibytes,), dtype=torch.uint8, device=dev)
             m = _model_args(P, W, H, cfg["sh_degree"], K, params, view, proj, campos, bg, cfg["scale_modifier"],
-                            cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"], tanfov)
+                            cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"], fov)
             m.img_ws_recycled = int(lease is not None and lease.recycled)
             pinned = _pinned(dev)
             _lib.check(L.ghr_model_forward_stage1(_stream(), ctypes.byref(m), _ptr(geom), _ptr(img), _ptr(radii),
@@ -131,7 +132,7 @@ class _RenderModelFused(torch.autograd.Function):
         ctx.leaves = (xyz, log_scales, rotations, opacity_logit, label_logit, orient_conf_log, f_dc, f_rest)
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
-        ctx.tanfov = tanfov
+        ctx.fov = fov
         ctx.save_for_backward(*params, view, proj, campos, bg, radii, geom, img, binb)
         return color, radii
 
@@ -175,9 +176,14 @@ class _RenderModelFused(torch.autograd.Function):
             dL = grad_color.float().contiguous()
             m = _model_args(P, cfg["W"], cfg["H"], cfg["sh_degree"], K, params, view, proj, campos, bg,
                             cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"], cfg["conic_eps"], cfg["debug"],
-                            ctx.tanfov)
-            want_cam = any(ctx.needs_input_grad[9:13])
+                            ctx.fov)
+            want_cam = any(ctx.needs_input_grad[9:14])
             cam_partial = _camera_partials(m, [P], dev) if want_cam and P > 0 else None
+            dens = cfg.get("densify_stats")
+            if dens is not None and P > 0:
+                # the stage-1 loop's per-iteration statistics (train_gaussians.py:161-165) ride along in k_project_bwd
+                m.dens_grad_accum, m.dens_denom, m.dens_max_radii2D = [_ptr(t) for t in dens]
+                m.dens_img_ws = _ptr(img)  # (a view whose capacity guess overflowed leaves the statistics alone: it is redone)
             # the step's first gradients into a buffer that is known to hold zeros are assigned, not added (optim.py)
             acc = 1
             if P > 0 and direct and sink.take_known_zero():
@@ -201,7 +207,7 @@ class _RenderModelFused(torch.autograd.Function):
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
                                                 _ptr(d_fdc), _ptr(d_frest), acc if direct else 0,
                                                 sink.nan_flag_ptr() if direct else None, prezeroed))
-            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[9:13], dev) if want_cam else (None,) * 4
+            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[9:14], dev, ctx.fov) if want_cam else (None,) * 5
         if direct:
             sink.note_direct_backward()
             return (None, None, None, None, None, None, None, None, d_m2d) + d_cam + (None,)
@@ -220,25 +226,34 @@ def _camera_partials(m, seg_sizes, dev):
     return table, total, starts
 
 
-def _camera_grads(cam_partial, meta, needs, dev):
-    """Fold the partial table into dL/d(world_view_transform, full_proj_transform, camera_center, tan(FoV / 2)) -- what
-    autograd hands those tensors in the reference's render() -- shaped like the op's inputs."""
+def _camera_grads(cam_partial, meta, needs, dev, fov):
+    """Fold the partial table into dL/d(world_view_transform, full_proj_transform, camera_center, FoVx, FoVy) -- what autograd
+    hands those tensors in the reference's render() -- shaped like the op's inputs.  One launch; the five results are views of
+    one 37-float buffer."""
     d_cam = torch.empty((_lib.CAM_GRADS,), dtype=torch.float32, device=dev)
     if cam_partial is None:
         d_cam.zero_()
     else:
         table, total, _ = cam_partial
-        _lib.check(_lib.lib().ghr_camera_grad_fold(_stream(), _ptr(table), total, _ptr(d_cam)))
-    parts = (d_cam[0:16], d_cam[16:32], d_cam[32:35], d_cam[35:37])
+        _lib.check(_lib.lib().ghr_camera_grad_fold(_stream(), _ptr(table), total, _ptr(d_cam),
+                                                   _ptr(fov[0]) if fov is not None else None,
+                                                   _ptr(fov[1]) if fov is not None else None))
+    parts = (d_cam[0:16], d_cam[16:32], d_cam[32:35], d_cam[35:36], d_cam[36:37])
     out = []
     for g, mt, need in zip(parts, meta, needs):
-        out.append(g.reshape(mt[0]).to(mt[1]) if (need and mt is not None) else None)
+        if not need or mt is None:
+            out.append(None)
+            continue
+        g = g.reshape(mt[0])
+        out.append(g if mt[1] == torch.float32 else g.to(mt[1]))
     return tuple(out)
 
 
-def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False):
+def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False, densify_stats=False):
     """Returns (renders[10,H,W], radii[P], screenspace_points[P,3] leaf whose .grad receives dL/d(NDC mean),
-    num_rendered: int, or a PendingCount with ``defer_count``)."""
+    num_rendered: int, or a PendingCount with ``defer_count``).  ``densify_stats``: the backward pass of this view also
+    updates the model's ``xyz_gradient_accum`` / ``denom`` / ``max_radii2D`` (the reference's per-iteration bookkeeping,
+    train_gaussians.py:161-165), inside k_project_bwd."""
     import math
     xyz = pc.get_xyz
     P = xyz.shape[0]
@@ -246,7 +261,7 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
     # here it also carries the NDC means as values, like the reference's get_mean_2d() output.
     # k_project writes all P rows (culled Gaussians included), so no zero-fill is needed
     screenspace_points = torch.empty((P, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
-    view, proj, campos, tanfov, tfx, tfy = camera_inputs(cam)
+    view, proj, campos, fovx, fovy, tfx, tfy = camera_inputs(cam)
     cfg = dict(W=int(cam.image_width), H=int(cam.image_height), bg=bg_color,
                sh_degree=int(pc.active_sh_degree), scale_modifier=float(scaling_modifier), tanfovx=tfx, tanfovy=tfy,
                conic_eps=float(getattr(pc, "conic_eps", 1e-12)), debug=bool(debug), defer_count=bool(defer_count),
@@ -255,17 +270,25 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
     opt = getattr(pc, "optimizer", None)
     if isinstance(opt, FusedAdam) and opt.direct_grads:
         cfg["grad_sink"] = opt
+    if densify_stats and torch.is_grad_enabled():
+        stats = (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
+        if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and
+                   t.numel() == P for t in stats):
+            raise RuntimeError("densify_stats: xyz_gradient_accum / denom / max_radii2D must be contiguous fp32 device tensors "
+                               "of P elements (GaussianModel.training_setup creates them)")
+        cfg["densify_stats"] = stats
     renders, radii = _RenderModelFused.apply(xyz, pc._scaling, pc._rotation, pc._opacity, pc._label, pc._orient_conf,
                                              pc._features_dc, pc._features_rest, screenspace_points, view, proj, campos,
-                                             tanfov, cfg)
+                                             fovx, fovy, cfg)
     return renders, radii, screenspace_points, cfg.get("count")
 
 
 def camera_inputs(cam):
-    """(world_view_transform, full_proj_transform, camera_center, tanfov tensor | None, tan_fovx, tan_fovy) of a camera, each
+    """(world_view_transform, full_proj_transform, camera_center, FoVx | None, FoVy | None, tan_fovx, tan_fovy) of a camera, each
     property read ONCE (the reference's trainable Camera rebuilds its matrices on every access, src/scene/cameras.py:113-151).
-    A FoV that is part of the autograd graph (trainable intrinsics, :93-105) goes to the kernels as a DEVICE tensor
-    {tan(FoVx / 2), tan(FoVy / 2)} -- differentiable, and never read back by the host; a constant FoV as two host floats."""
+    A FoV that is part of the autograd graph (trainable intrinsics, :93-105) goes to the kernels as two DEVICE scalars -- they
+    take tan(FoV / 2) themselves, its gradient comes back through the op, and the host never reads the value; a constant FoV as
+    two host floats."""
     if hasattr(cam, "tensors"):  # (scene.cameras.TrainableCamera: all five from one evaluation of the camera's graph)
         view, proj, campos, fx, fy = cam.tensors()[:5]
     else:
@@ -274,9 +297,10 @@ def camera_inputs(cam):
     live = torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (fx, fy))
     if live:
         dev = view.device
-        both = torch.stack([torch.as_tensor(fx, device=dev).reshape(()).float(), torch.as_tensor(fy, device=dev).reshape(()).float()])
-        return view, proj, campos, torch.tan(both * 0.5), 1.0, 1.0  # (the floats are ignored: tanfov_dev overrides them)
-    return view, proj, campos, None, _tan_half(fx), _tan_half(fy)
+        fx, fy = [t if isinstance(t, torch.Tensor) and t.device == dev else torch.as_tensor(t, dtype=torch.float32, device=dev)
+                  for t in (fx, fy)]
+        return view, proj, campos, fx, fy, 1.0, 1.0  # (the floats are ignored: fovx_dev / fovy_dev override them)
+    return view, proj, campos, None, None, _tan_half(fx), _tan_half(fy)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -297,7 +321,8 @@ def _seg_args(P, row0, W, H, sh_degree, K, t, cam_t, cfg, eps, consts):
     m.viewmatrix, m.projmatrix, m.campos, m.background = [_ptr(x) for x in cam_t[:4]]
     m.scale_modifier, m.tan_fovx, m.tan_fovy = cfg["scale_modifier"], cfg["tanfovx"], cfg["tanfovy"]
     m.conic_eps = eps
-    m.tanfov_dev = _ptr(cam_t[4]) if len(cam_t) > 4 and cam_t[4] is not None else None
+    if len(cam_t) > 4 and cam_t[4] is not None:
+        m.fovx_dev, m.fovy_dev = _ptr(cam_t[4][0]), _ptr(cam_t[4][1])
     m.debug = int(bool(cfg["debug"]))
     m.mode, m.row0 = 1, int(row0)
     m.const_opacity, m.const_label, m.const_conf = consts
@@ -306,7 +331,7 @@ def _seg_args(P, row0, W, H, sh_degree, K, t, cam_t, cfg, eps, consts):
 
 class _RenderHairFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, scaling, rotation, dirs, conf, f_dc, f_rest, screenspace_points, view, proj, campos, tanfov,
+    def forward(ctx, xyz, scaling, rotation, dirs, conf, f_dc, f_rest, screenspace_points, view, proj, campos, fovx, fovy,
                 head, cfg):
         L = _lib.lib()
         if not xyz.is_cuda:
@@ -320,9 +345,9 @@ class _RenderHairFused(torch.autograd.Function):
         row0 = (n_head + 255) // 256 * 256
         rows = row0 + n_hair
         K = 1 + f_rest.shape[1]
-        ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in (view, proj, campos, tanfov)]
+        ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in (view, proj, campos, fovx, fovy)]
         cam_t = [t.detach().float().contiguous() for t in (view, proj, campos, cfg["bg"])]
-        cam_t.append(tanfov.detach().float().reshape(-1).contiguous() if tanfov is not None else None)
+        cam_t.append((fovx.detach().float().contiguous(), fovy.detach().float().contiguous()) if fovx is not None else None)
         with torch.cuda.device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii_ws = torch.empty((rows,), dtype=torch.int32, device=dev)
@@ -364,7 +389,7 @@ class _RenderHairFused(torch.autograd.Function):
         ctx.scratch_clean = ctx.scratch is not None
         ctx.mark_non_differentiable(radii)
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
-        ctx.tanfov = cam_t[4]
+        ctx.fov = cam_t[4]
         ctx.head = head  # (the frozen head contributes to the camera's gradients)
         ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t[:4],
                               radii_ws, geom, img, binb)
@@ -394,9 +419,9 @@ class _RenderHairFused(torch.autograd.Function):
             ctx.scratch_clean = False
             dL = grad_color.float().contiguous()
             hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
-            cam_t = [view, proj, campos, bg, ctx.tanfov]
+            cam_t = [view, proj, campos, bg, ctx.fov]
             m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, cam_t, cfg, cfg["eps_hair"], (1.0, 1.0, 0.0))
-            want_cam = any(ctx.needs_input_grad[8:12])
+            want_cam = any(ctx.needs_input_grad[8:13])
             cam_partial = None
             if want_cam and rows > 0:
                 # the camera's gradients are sums over BOTH segments: the head is frozen but seen through the same camera
@@ -418,7 +443,7 @@ class _RenderHairFused(torch.autograd.Function):
                                                         _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
                                                         _ptr(d_dir), 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
-            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:12], dev) if want_cam else (None,) * 4
+            d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:13], dev, ctx.fov) if want_cam else (None,) * 5
         return (d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d) + d_cam + (None, None)
 
 
@@ -446,12 +471,12 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
     xyz = pc_hair.get_xyz
     n = head["xyz"].shape[0] + xyz.shape[0]
     screenspace_points = torch.empty((n, 3), dtype=torch.float32, device=xyz.device).requires_grad_(True)
-    view, proj, campos, tanfov, tfx, tfy = camera_inputs(cam)
+    view, proj, campos, fovx, fovy, tfx, tfy = camera_inputs(cam)
     cfg = dict(W=int(cam.image_width), H=int(cam.image_height), bg=bg_color,
                sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier), tanfovx=tfx, tanfovy=tfy,
                eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
                debug=bool(debug), grad_enabled=torch.is_grad_enabled())
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
                                             pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
-                                            screenspace_points, view, proj, campos, tanfov, head, cfg)
+                                            screenspace_points, view, proj, campos, fovx, fovy, head, cfg)
     return renders, radii, screenspace_points

@@ -111,6 +111,7 @@ def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams
                     pkg = render(cam, gaussians, pipe, background)
                     loss = view_loss(pkg, cam, opt, scale=1.0 / V)
                     loss.backward(gradient=_one_like(loss))
+                    _generic_densify_stats(gaussians, pkg, pipe)
                     ld = loss.detach()
                     ld.record_stream(main)
                     losses.append(ld)
@@ -124,14 +125,25 @@ def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams
             pkg = render(cam, gaussians, pipe, background)
             loss = view_loss(pkg, cam, opt, scale=1.0 / V)
             loss.backward(gradient=_one_like(loss))
+            _generic_densify_stats(gaussians, pkg, pipe)
             losses.append(loss.detach())
             counts.append(getattr(pkg, "count", None))
     return losses, counts
 
 
+@torch.no_grad()
+def _generic_densify_stats(gaussians, pkg, pipe):
+    """pipe.densify_stats on a view whose backward pass did not keep the statistics itself (generic path): the reference's
+    PyTorch form (train_gaussians.py:161-165)."""
+    if getattr(pipe, "densify_stats", False) and not getattr(pkg, "densify_stats_done", False):
+        vis = pkg["visibility_filter"]
+        gaussians.update_max_radii(pkg["radii"], vis)
+        gaussians.add_densification_stats(pkg["viewspace_points"], vis)
+
+
 def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
                   global_views: Optional[int] = None, pipe=PIPE, streams: Optional[int] = None,
-                  defer_counts: Optional[bool] = None):
+                  defer_counts: Optional[bool] = None, densify_stats: bool = False):
     """One global gradient step over this rank's views.  Returns the (detached) summed local loss.
 
     ``streams`` (default 2 with the fused path and more than one view): the views of the step are independent given
@@ -143,7 +155,12 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     ``defer_counts`` (default on with the fused path): no view waits for its ``num_rendered`` -- the forward runs with
     the capacity guessed from the previous frame and the counts are checked once, after everything is queued (the host
     never blocks inside the step: 3.10 -> 2.92 ms).  If a count exceeded its capacity the accumulated gradients are
-    dropped and the step is recomputed view by view with exact capacities, so the result never depends on the guess."""
+    dropped and the step is recomputed view by view with exact capacities, so the result never depends on the guess.
+
+    ``densify_stats``: every view's backward pass also keeps the per-iteration densification statistics of the stage-1 loop
+    (``max_radii2D``, ``xyz_gradient_accum``, ``denom``: src/train_gaussians.py:161-165, half of the iterations of a run) --
+    inside ``k_project_bwd`` on the fused path (no extra launch); ``densification_step(..., stats_done=True)`` then only
+    densifies / prunes at its interval.  Views that take the generic path get the PyTorch form."""
     from .optim import FusedAdam
     gaussians.update_learning_rate(iteration)
     # the loss of a view is scaled 1 / V: with more than one rank V defaults to the GLOBAL number of views (the
@@ -172,8 +189,8 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         gaussians.optimizer.resolve_deferred()
     defer = fused_sink and (True if defer_counts is None else bool(defer_counts))
     run_pipe = pipe
-    if defer:
-        run_pipe = SimpleNamespace(**{**vars(pipe), "defer_count": True})
+    if defer or densify_stats:
+        run_pipe = SimpleNamespace(**{**vars(pipe), "defer_count": bool(defer), "densify_stats": bool(densify_stats)})
     losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, run_pipe, n_streams, sink)
     overflow = [c.resolve()[1] for c in counts if hasattr(c, "resolve")]  # resolve every one: they feed the next guess
     if any(overflow):
@@ -183,7 +200,15 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         sink.zero()
         sink.state_dev[1:2].zero_()
         sink._acc_event = None
-        losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, pipe, 0, sink)
+        # (densify_stats: the overflowed views' backward passes left the statistics alone -- k_project_bwd checks the count
+        # on the device -- but the OTHER views of the step have been counted: only those that overflowed are ... all of them are
+        # recomputed below, so the statistics of the views that did not overflow would be counted twice)
+        if densify_stats and len(cams) > 1 and not all(overflow):
+            raise RuntimeError("training_step(densify_stats=True): a capacity guess overflowed in a multi-view step; the "
+                               "statistics of its other views cannot be rolled back -- use defer_counts=False for the first "
+                               "step after the scene has grown")
+        redo_pipe = SimpleNamespace(**{**vars(pipe), "densify_stats": True}) if densify_stats else pipe
+        losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, redo_pipe, 0, sink)
     if not losses:  # a rank without views in this step still takes part in the collectives and the update
         total = torch.zeros((), device=background.device)
     else:
@@ -247,7 +272,7 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
 
 @torch.no_grad()
 def densification_step(gaussians, render_pkg, opt, iteration: int, cameras_extent: float,
-                       white_background: bool = False, generator=None):
+                       white_background: bool = False, generator=None, stats_done: Optional[bool] = None):
     """The densification block of the stage-1 loop (src/train_gaussians.py:158-171), to be called between
     ``loss.backward()`` and the optimizer step of an iteration: image-space radius tracking, gradient statistics,
     densify_and_prune every ``densification_interval`` and the periodic opacity reset.  Under data parallelism every
@@ -255,9 +280,14 @@ def densification_step(gaussians, render_pkg, opt, iteration: int, cameras_exten
     ``generator`` seed so the replicas stay bit-identical."""
     if iteration >= opt.densify_until_iter:
         return False
-    vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
-    gaussians.update_max_radii(radii, vis)
-    gaussians.add_densification_stats(render_pkg["viewspace_points"], vis)
+    # ``stats_done`` (default: what the package says): this iteration's statistics were kept by the fused backward pass
+    # (pipe.densify_stats / training_step(densify_stats=True)); ``render_pkg`` may then be None
+    if stats_done is None:
+        stats_done = bool(getattr(render_pkg, "densify_stats_done", False))
+    if not stats_done:
+        vis, radii = render_pkg["visibility_filter"], render_pkg["radii"]
+        gaussians.update_max_radii(radii, vis)
+        gaussians.add_densification_stats(render_pkg["viewspace_points"], vis)
     changed = False
     if iteration > opt.densify_from_iter and iteration % opt.densification_interval == 0:
         size_threshold = 20 if iteration > opt.opacity_reset_interval else None

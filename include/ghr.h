@@ -179,9 +179,9 @@ typedef struct ghr_model_args {
      * (src/scene/gaussian_model.py:258-266,279-294,332-335; src/gaussian_renderer/__init__.py:59), whose tensors are functions
      * of trainable pose / FoV residuals (src/scene/cameras.py:85-151) stepped by an optimizer of their own
      * (src/train_gaussians.py:45-60,183-196; on by default: src/arguments/__init__.py:61-62).
-     * tanfov_dev: [2] DEVICE floats {tan(FoVx / 2), tan(FoVy / 2)} or NULL.  Non-NULL: forward and backward kernels read the
-     * half-angle tangents from there (and derive focal = dim / (2 tan) themselves) instead of tan_fovx / tan_fovy above, so a FoV
-     * that changes every step never costs a device-to-host read.
+     * fovx_dev, fovy_dev (both or neither): DEVICE scalars FoVx, FoVy in radians.  Non-NULL: forward and backward kernels take
+     * tan(FoV / 2) from there (and derive focal = dim / (2 tan) themselves) instead of tan_fovx / tan_fovy above, so a FoV that
+     * changes every step never costs a device-to-host read; ghr_camera_grad_fold can then return dL/dFoV directly.
      * cam_partial (backward calls only; NULL = no camera gradients): table of GHR_CAM_PARTIALS rows of cam_slots floats.  The
      * segment's backward writes one column per 64 Gaussians -- columns cam_slot0 .. cam_slot0 + ghr_camera_slots(P) - 1, every
      * row of them -- and ghr_camera_grad_fold adds the columns up.  Several segments of one view share a table.
@@ -189,11 +189,24 @@ typedef struct ghr_model_args {
      * parameter-gradient and d_means2D pointers may be NULL).
      * detach_means2D != 0: the segment's NDC means are constants of the graph (render_hair() detaches the head's,
      * src/gaussian_renderer/__init__.py:136): no gradient flows through projmatrix for it. */
-    const float* tanfov_dev;
+    const float* fovx_dev;
+    const float* fovy_dev;
     float* cam_partial;
     int32_t cam_slot0, cam_slots;
     int32_t cam_only;
     int32_t detach_means2D;
+    /* Per-iteration densification statistics of the stage-1 loop (src/train_gaussians.py:161-165,
+     * src/scene/gaussian_model.py:739-741), folded into the backward call (all three non-NULL, or all NULL): for every Gaussian
+     * of the segment the view sees (radii > 0)   xyz_gradient_accum += |d_means2D.xy|,   denom += 1,
+     * max_radii2D = max(max_radii2D, radii).  All [P] floats (the reference's [P,1], [P,1], [P]).  Read-modify-write: calls that
+     * share the arrays must be ordered (they are wherever they share the flat gradient buffer). */
+    float* dens_grad_accum;
+    float* dens_denom;
+    float* dens_max_radii2D;
+    /* optional with the three above: the view's image workspace.  The update then only happens if the instance count stage 1 left
+     * there is within the capacity R the backward call is given -- a view rasterized speculatively with too small a capacity
+     * (ghr_forward_stage2) has invalid gradients and is recomputed by the caller: its statistics must not be counted twice. */
+    const void* dens_img_ws;
 } ghr_model_args;
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
@@ -237,8 +250,10 @@ int32_t ghr_camera_slots(int32_t P);
 /* Adds the cam_slots columns of a partial table up (fixed order, double accumulation) into d_cam[GHR_CAM_GRADS]:
  * dL/d world_view_transform [4,4] (column 3 zero: never read) | dL/d full_proj_transform [4,4] (column 2 zero: the NDC z carries
  * no gradient) | dL/d camera_center [3] | dL/d {tan(FoVx / 2), tan(FoVy / 2)} -- the gradients autograd hands the camera tensors
- * in the reference's render() (torch.clamp's tensor bounds 1.3 tan included). */
-int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam);
+ * in the reference's render() (torch.clamp's tensor bounds 1.3 tan included).  fovx_dev / fovy_dev (both or neither; the
+ * pointers of ghr_model_args): the last two entries are dL/dFoVx, dL/dFoVy instead (x (1 + tan^2(FoV / 2)) / 2). */
+int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam, const float* fovx_dev,
+                         const float* fovy_dev);
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,

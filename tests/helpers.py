@@ -216,7 +216,7 @@ class ModelArgsC(ctypes.Structure):
                [(n, ctypes.c_void_p) for n in ("features_dc", "features_rest", "view", "proj", "campos")] + \
                [(n, ctypes.c_float) for n in ("scale_modifier", "tan_fovx", "tan_fovy", "focal_x", "focal_y",
                                               "conic_eps")] + \
-               [("tanfov", ctypes.c_void_p)] + \
+               [("fovx", ctypes.c_void_p), ("fovy", ctypes.c_void_p)] + \
                [(n, ctypes.c_void_p) for n in ("rec", "depths", "rects", "radii", "means2D", "tile_count", "pos", "slot_blk")]
 
 

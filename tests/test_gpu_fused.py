@@ -786,3 +786,67 @@ def test_empty_model_pass_never_pools_its_image_workspace():
     with torch.no_grad():
         pkg = render(cam, model, dbg, syn.background(dev))
     assert torch.equal(pkg["render"], ref_img) and torch.equal(pkg["radii"], ref_radii)
+
+
+def test_densification_statistics_inside_the_projection_backward_are_bit_identical_to_the_torch_form():
+    """the stage-1 loop's per-iteration bookkeeping (src/train_gaussians.py:161-165,
+    src/scene/gaussian_model.py:739-741: max_radii2D, xyz_gradient_accum += |viewspace grad.xy|, denom += 1 over the visible
+    Gaussians) folded into k_project_bwd (pipe.densify_stats).  Three views in a row (accumulation), against
+    densification_step's PyTorch form on the same gradients: bit for bit.  A view whose capacity guess overflowed leaves the
+    statistics alone."""
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, view_loss
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    cams = ring_cameras(3, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, cams, bg)
+    a, b = syn.make_model(spec, dev), syn.make_model(spec, dev)
+    for m in (a, b):
+        m.training_setup(opt)
+    stats_pipe = SimpleNamespace(debug=False, fused_projection=True, densify_stats=True)
+    _lib.lib().ghr_set_deterministic(1)  # the two models' viewspace gradients must be the same bits
+    try:
+        for cam in cams:
+            pa = render(cam, a, stats_pipe, bg)
+            assert pa.densify_stats_done
+            view_loss(pa, cam, opt).backward()
+            pb = render(cam, b, FUSED, bg)
+            assert not pb.densify_stats_done
+            view_loss(pb, cam, opt).backward()
+            assert torch.equal(pa["viewspace_points"].grad, pb["viewspace_points"].grad)
+            with torch.no_grad():
+                vis = pb["visibility_filter"]
+                b.update_max_radii(pb["radii"], vis)
+                b.add_densification_stats(pb["viewspace_points"], vis)
+            a.optimizer.zero_grad()
+            b.optimizer.zero_grad()
+        torch.cuda.synchronize()
+        assert float(b.denom.max()) == 3.0 and float(b.xyz_gradient_accum.abs().max()) > 0
+        assert torch.equal(a.denom, b.denom) and torch.equal(a.max_radii2D, b.max_radii2D)
+        assert torch.equal(a.xyz_gradient_accum, b.xyz_gradient_accum), \
+            float((a.xyz_gradient_accum - b.xyz_gradient_accum).abs().max())
+        # an overflowed view: a capacity far below the instance count -> the kernel skips the update
+        before = [t.clone() for t in (a.xyz_gradient_accum, a.denom, a.max_radii2D)]
+        saved = dict(dgr._R_HINT), {k: list(v) for k, v in dgr._R_RECENT.items()}
+        dgr._R_RECENT.clear()
+        dgr._R_HINT[dev.index] = 4096
+        pipe = SimpleNamespace(debug=False, fused_projection=True, densify_stats=True, defer_count=True)
+        pa = render(cams[0], a, pipe, bg)
+        view_loss(pa, cams[0], opt).backward()
+        assert pa.count.resolve()[1], "the guess was meant to overflow"
+        torch.cuda.synchronize()
+        for t0, t1 in zip(before, (a.xyz_gradient_accum, a.denom, a.max_radii2D)):
+            assert torch.equal(t0, t1)
+    finally:
+        _lib.lib().ghr_set_deterministic(0)
+        dgr._R_HINT.pop(dev.index, None)
+        dgr._R_RECENT.clear()

@@ -252,7 +252,7 @@ def cam_vector_to_tensors(cam32):
     dv, dp = np.zeros(16), np.zeros(16)
     dv[CAM_LAYOUT["view"]] = cam32[0:12]
     dp[CAM_LAYOUT["proj"]] = cam32[12:24]
-    return dv.reshape(4, 4), dp.reshape(4, 4), cam32[24:27].copy(), cam32[27:29].copy()
+    return dv.reshape(4, 4), dp.reshape(4, 4), cam32[26:29].copy(), cam32[24:26].copy()
 
 
 class LeafCamera:
