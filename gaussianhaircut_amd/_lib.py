@@ -100,7 +100,15 @@ class ModelArgs(ctypes.Structure):
                [("fovx_dev", ctypes.c_void_p), ("fovy_dev", ctypes.c_void_p), ("cam_partial", ctypes.c_void_p), ("cam_slot0", ctypes.c_int32),
                 ("cam_slots", ctypes.c_int32), ("cam_only", ctypes.c_int32), ("detach_means2D", ctypes.c_int32),
                 ("dens_grad_accum", ctypes.c_void_p), ("dens_denom", ctypes.c_void_p), ("dens_max_radii2D", ctypes.c_void_p),
-                ("dens_img_ws", ctypes.c_void_p)]
+                ("dens_img_ws", ctypes.c_void_p), ("overflow_raises_flag", ctypes.c_int32), ("adam_fuse", ctypes.c_void_p)]
+
+
+class AdamFuse(ctypes.Structure):
+    """``ghr_adam_fuse`` (include/ghr.h): the optimizer update fused into the step's last projection backward."""
+    _fields_ = [("n", ctypes.c_int64)] + \
+               [(n, ctypes.c_void_p) for n in ("p_in", "m_in", "v_in", "p_out", "m_out", "v_out", "state", "flag", "flag_next")] + \
+               [("n_groups", ctypes.c_int32), ("group_end_host", ctypes.c_void_p), ("lr_host", ctypes.c_void_p),
+                ("beta1", ctypes.c_double), ("beta2", ctypes.c_double), ("eps", ctypes.c_float)]
 
 
 class LossArgs(ctypes.Structure):

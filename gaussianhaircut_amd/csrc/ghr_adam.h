@@ -148,6 +148,56 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
     }
 }
 
+// ---- Adam fused into the projection backward (round 6; ghr_project.h k_project_bwd<.., ADAM>) ---------------------------------
+// The LAST view's projection backward of a single-rank step holds every parameter gradient of the step in registers (its own
+// terms plus what the earlier views left in the flat gradient buffer) and the raw parameters as well: it applies the update
+// there instead of writing 244 B of gradient per Gaussian for k_adam_v4 to read back.  The skip-on-non-finite decision of
+// src/train_gaussians.py:174-181 is global, so the update goes to a SECOND set of buffers: p, m, v are read from `in`, the
+// updated values written to `out`; the host swaps the roles of the two sets after every fused step, and k_adam_fused_finish
+// copies in -> out when the step's flag says that the update must not have happened (a rare event: 732 B per Gaussian then).
+#define GHR_ADAM_FUSE_ARRAYS 8  // xyz, log_scales, rotations, opacity, label, orient_conf, features_dc, features_rest
+struct AdamFuse {
+    const float* p_base;     // the flat parameter buffer ModelArgs' raw-parameter pointers point into (the `in` set)
+    const float* m_in;       // exp_avg, exp_avg_sq of the `in` set (same offsets as the parameters)
+    const float* v_in;
+    float* p_out;            // the `out` set
+    float* m_out;
+    float* v_out;
+    const int* state;        // GHR_ADAM_STATE ints: [0] step count, [2 + g] steps group g has sat out
+    float lr[GHR_ADAM_FUSE_ARRAYS];   // learning rate of each array's group, in the order above
+    int group[GHR_ADAM_FUSE_ARRAYS];  // ... and its group index
+    double beta1, beta2;
+    float eps;
+    int on;                  // 0: no fusion (everything above ignored)
+};
+
+// One thread per element of [0, n): out := in for p, m, v when *flag != 0 (the fused update of this step must be undone);
+// workgroup 0 also keeps the books of k_adam_finish: the step counter advances unless the step was skipped.  The flag word is
+// not cleared here (other workgroups may still have to read it): fused steps alternate between two flag words and clear the
+// OTHER one (`flag_next`), which nobody reads before the next step's producers run.
+__global__ void __launch_bounds__(256) k_adam_fused_finish(long long n, const float* __restrict__ p_in,
+                                                           const float* __restrict__ m_in, const float* __restrict__ v_in,
+                                                           float* __restrict__ p_out, float* __restrict__ m_out,
+                                                           float* __restrict__ v_out, int* state, const int* flag, int* flag_next)
+{
+    const int bad = *flag;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!bad) state[0] += 1;
+        *flag_next = 0;
+    }
+    if (!bad) return;
+    const long long n4 = n >> 2;
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+        reinterpret_cast<f4*>(p_out)[q] = reinterpret_cast<const f4*>(p_in)[q];
+        reinterpret_cast<f4*>(m_out)[q] = reinterpret_cast<const f4*>(m_in)[q];
+        reinterpret_cast<f4*>(v_out)[q] = reinterpret_cast<const f4*>(v_in)[q];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const long long i = 4 * n4 + threadIdx.x;
+        p_out[i] = p_in[i]; m_out[i] = m_in[i]; v_out[i] = v_in[i];
+    }
+}
+
 // Runs after k_adam on the same stream: advance the step counter unless skipped, note which groups sat the step out,
 // clear the flag.
 __global__ void k_adam_finish(int* state, unsigned skip_mask, int n_groups)

@@ -550,9 +550,53 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
         carve_img(align_base(m->dens_img_ws), (size_t)a.W * a.H, (size_t)a.gx * a.gy, &im);
         mg.dens_count = im.R_dev;
     }
+    mg.overflow_is_bad = 0;
+    mg.adam.on = 0;
+    const ghr_adam_fuse* af = m->adam_fuse;
+    if (af) {
+        if (a.mode != 0 || cam_only) return fail(GHR_E_INVALID, "ghr_adam_fuse: only with mode 0 segments that store gradients");
+        if (af->n <= 0 || !af->p_in || !af->m_in || !af->v_in || !af->p_out || !af->m_out || !af->v_out || !af->state || !af->flag ||
+            !af->flag_next || af->n_groups <= 0 || af->n_groups > GHR_ADAM_MAX_GROUPS || !af->group_end_host || !af->lr_host)
+            return fail(GHR_E_INVALID, "ghr_adam_fuse: NULL buffer / bad group table");
+        if (nan_flag != af->flag) return fail(GHR_E_INVALID, "ghr_adam_fuse: nan_flag of the backward call must be adam_fuse->flag");
+        const float* arrays[GHR_ADAM_FUSE_ARRAYS] = {a.xyz, a.log_scales, a.rotations, a.opacity_logit, a.label_logit,
+                                                     a.orient_conf_log, a.features_dc, a.features_rest};
+        const long long width[GHR_ADAM_FUSE_ARRAYS] = {3, 3, 4, 1, 1, 1, 3, 3LL * (a.sh_coeffs - 1)};
+        long long covered = 0;
+        for (int k = 0; k < GHR_ADAM_FUSE_ARRAYS; k++) {
+            const long long len = width[k] * a.P;
+            if (len == 0) { mg.adam.lr[k] = 0.f; mg.adam.group[k] = 0; continue; }
+            const long long off = arrays[k] - af->p_in;
+            if (off < 0 || off + len > af->n)
+                return fail(GHR_E_INVALID, "ghr_adam_fuse: a raw-parameter array does not lie inside p_in");
+            int gi = 0;
+            while (gi < af->n_groups - 1 && off >= af->group_end_host[gi]) gi++;
+            if (off + len > af->group_end_host[gi])
+                return fail(GHR_E_INVALID, "ghr_adam_fuse: a raw-parameter array straddles two parameter groups");
+            mg.adam.group[k] = gi;
+            mg.adam.lr[k] = af->lr_host[gi];
+            covered += len;
+        }
+        if (covered != af->n) return fail(GHR_E_INVALID, "ghr_adam_fuse: the eight raw-parameter arrays must tile p_in (n floats)");
+        mg.adam.p_base = af->p_in; mg.adam.m_in = af->m_in; mg.adam.v_in = af->v_in;
+        mg.adam.p_out = af->p_out; mg.adam.m_out = af->m_out; mg.adam.v_out = af->v_out;
+        mg.adam.state = af->state; mg.adam.beta1 = af->beta1; mg.adam.beta2 = af->beta2; mg.adam.eps = af->eps;
+        mg.adam.on = 1;
+    }
+    if (m->dens_img_ws && (af || m->overflow_raises_flag)) {
+        // (steps with the fused optimizer update: EVERY view's backward checks its instance count and raises the step's flag)
+        Img im;
+        carve_img(align_base(m->dens_img_ws), (size_t)a.W * a.H, (size_t)a.gx * a.gy, &im);
+        mg.dens_count = im.R_dev; mg.dens_cap = R; mg.overflow_is_bad = 1;
+    }
     const dim3 grid((a.P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), block(GHR_PBW_BLOCK);
-    if (mg.cam_partial) hipLaunchKernelGGL(ghr::k_project_bwd<true>, grid, block, 0, s, a, mg);
-    else hipLaunchKernelGGL(ghr::k_project_bwd<false>, grid, block, 0, s, a, mg);
+    if (af) {
+        if (mg.cam_partial) hipLaunchKernelGGL((ghr::k_project_bwd<true, true>), grid, block, 0, s, a, mg);
+        else hipLaunchKernelGGL((ghr::k_project_bwd<false, true>), grid, block, 0, s, a, mg);
+        hipLaunchKernelGGL(ghr::k_adam_fused_finish, dim3(1024), dim3(256), 0, s, (long long)af->n, af->p_in, af->m_in, af->v_in,
+                           af->p_out, af->m_out, af->v_out, af->state, (const int*)af->flag, af->flag_next);
+    } else if (mg.cam_partial) hipLaunchKernelGGL((ghr::k_project_bwd<true, false>), grid, block, 0, s, a, mg);
+    else hipLaunchKernelGGL((ghr::k_project_bwd<false, false>), grid, block, 0, s, a, mg);
     return finish(s, m->debug);
 }
 

@@ -17,6 +17,7 @@
 // Backward differentiates exactly that pipeline (torch semantics: clamp() passes gradient only inside the range,
 // normalize() is differentiated, clamp_min(sh + 0.5, 0) masks), NOT the dormant CUDA K9/K10.
 #pragma once
+#include "ghr_adam.h"
 #include "ghr_preprocess.h"
 
 namespace ghr {
@@ -96,10 +97,14 @@ struct ModelGrads {
     float* dens_grad_accum;   // [P] (tensor [P,1])
     float* dens_denom;        // [P] (tensor [P,1])
     float* dens_max_radii;    // [P] float, like the reference's
+    AdamFuse adam;               // adam.on != 0 (mode 0, the step's LAST backward on one rank): the optimizer update is applied
+                                 // here, from registers, instead of storing the gradients (ghr_adam.h)
     const uint32_t* dens_count;  // optional: the view's instance count on the device (k_tile_scan's R_dev) ...
-    uint32_t dens_cap;           // ... the update is skipped when it exceeds this capacity: the view was rasterized with a guessed
-                                 // capacity that turned out too small (include/ghr.h, ghr_forward_stage2), its gradients are
-                                 // invalid and the caller recomputes the view -- statistics must not be counted twice
+    uint32_t dens_cap;           // ... the statistics update is skipped when it exceeds this capacity: the view was rasterized with
+                                 // a guessed capacity that turned out too small (include/ghr.h, ghr_forward_stage2), its gradients
+                                 // are invalid and the caller recomputes the view -- statistics must not be counted twice
+    int overflow_is_bad;         // != 0 (steps with the fused optimizer update): such a view also raises nan_flag, so that the
+                                 // update it would poison is undone like one with non-finite gradients
 };
 
 // Camera cotangents a Gaussian contributes (the reference's projection graph is differentiable w.r.t. the camera:
@@ -719,8 +724,19 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
 
 // Writes (or accumulates into) every output element except d_rest, which stays in the caller's staging block.  Returns
 // whether any value stored was non-finite.
+// The per-array step size lr / (1 - beta1^t) and sqrt(1 - beta2^t) of the fused update, t = the group's own step number: the
+// expressions of k_adam (ghr_adam.h), evaluated by the lane whose index is the array's.
+GHR_HD void adam_fuse_coef(const AdamFuse& f, int arr, float& ss, float& b2)
+{
+    const int grp = f.group[arr];
+    const int step = f.state[0] + 1 - f.state[2 + grp];
+    const double bias1 = 1.0 - pow(f.beta1, (double)step);
+    ss = (float)((double)f.lr[arr] / bias1);
+    b2 = (float)sqrt(1.0 - pow(f.beta2, (double)step));
+}
+
 GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, const float* ga, const ProjBwdOut& o,
-                              int radius)
+                              int radius, const RawIn* in = nullptr, const float* ss = nullptr, const float* b2 = nullptr)
 {
     if (g.cam_only) return false;  // a frozen segment: only its camera cotangents are wanted
     const int acc = g.accumulate;
@@ -762,6 +778,49 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
         for (int i = 0; i < n; i++) v[i] += old[i];
     }
     bool bad = false;
+    if (in != nullptr && g.adam.on) {
+        // ---- the optimizer update instead of the gradient stores (mode 0: sixteen values in six arrays + the DC colour).  The
+        // gradient is what the store below would have left in the flat buffer; the parameter is the raw value this thread loaded
+        // at the top of the kernel; m and v come from the `in` set, everything goes to the `out` set (ghr_adam.h).
+        const AdamFuse& f = g.adam;
+        const float w1 = (float)(1.0 - f.beta1), w2 = (float)(1.0 - f.beta2), bt2 = (float)f.beta2;
+        // value index -> (array, parameter pointer, parameter value)
+        const float* q[16];
+        float pv[16], gv[16];
+        int arr[16];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            q[i] = a.xyz + 3 * idx + i;                 pv[i] = in->xyz[i];       gv[i] = v[i];        arr[i] = 0;
+            q[3 + i] = a.log_scales + 3 * idx + i;      pv[3 + i] = in->ls[i];    gv[3 + i] = v[3 + i]; arr[3 + i] = 1;
+            q[13 + i] = a.features_dc + 3 * (size_t)idx + i; pv[13 + i] = in->dc[i]; gv[13 + i] = v[16 + i]; arr[13 + i] = 6;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) { q[6 + i] = a.rotations + 4 * idx + i; pv[6 + i] = in->q[i]; gv[6 + i] = v[6 + i]; arr[6 + i] = 2; }
+        q[10] = a.opacity_logit + idx;   pv[10] = in->op;   gv[10] = v[10]; arr[10] = 3;
+        q[11] = a.label_logit + idx;     pv[11] = in->lab;  gv[11] = v[11]; arr[11] = 4;
+        q[12] = a.orient_conf_log + idx; pv[12] = in->conf; gv[12] = v[12]; arr[12] = 5;
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {  // eight values at a time: sixteen loads in flight, then their updates and stores
+            float mm[8], vv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const ptrdiff_t off = q[h + i] - f.p_base;
+                mm[i] = f.m_in[off];
+                vv[i] = f.v_in[off];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const ptrdiff_t off = q[h + i] - f.p_base;
+                float pp = pv[h + i];
+                bad |= nonfinite(gv[h + i]);
+                adam_update(pp, gv[h + i], mm[i], vv[i], ss[arr[h + i]], w1, bt2, w2, f.eps, b2[arr[h + i]]);
+                f.p_out[off] = pp;
+                f.m_out[off] = mm[i];
+                f.v_out[off] = vv[i];
+            }
+        }
+        return bad;
+    }
 #pragma unroll
     for (int i = 0; i < n; i++)
         if (p[i]) {
@@ -886,6 +945,64 @@ __device__ __forceinline__ bool slab_out(float* dst, const float* src, size_t n_
     }
     return bad;
 }
+// slab_out for the fused optimizer update: the gradient slab in LDS (+ what earlier views left in the flat gradient buffer
+// when `accumulate`) meets p, m, v of the `in` set, 16 B at a time, and the updated values go to the `out` set.  `dst_grad` /
+// `param`: the block's pieces of d_features_rest / features_rest.  Returns whether a gradient value was non-finite.
+template <int BLK>
+__device__ __forceinline__ bool slab_out_adam(const float* dst_grad, const float* param, const float* src, size_t n_floats,
+                                              int tid, int accumulate, const AdamFuse& f, float ss, float b2)
+{
+    const uint32_t n4 = (uint32_t)(n_floats / 4);
+    const f4* s4 = reinterpret_cast<const f4*>(src);
+    const f4* g4 = reinterpret_cast<const f4*>(dst_grad);
+    const ptrdiff_t off0 = param - f.p_base;
+    const f4 *p4 = reinterpret_cast<const f4*>(param), *m4 = reinterpret_cast<const f4*>(f.m_in + off0),
+             *v4 = reinterpret_cast<const f4*>(f.v_in + off0);
+    f4 *po = reinterpret_cast<f4*>(f.p_out + off0), *mo = reinterpret_cast<f4*>(f.m_out + off0),
+       *vo = reinterpret_cast<f4*>(f.v_out + off0);
+    const float w1 = (float)(1.0 - f.beta1), w2 = (float)(1.0 - f.beta2), bt2 = (float)f.beta2;
+    bool bad = false;
+    constexpr int HALF = GHR_SLAB_IT / 2;
+#pragma unroll
+    for (int h = 0; h < GHR_SLAB_IT; h += HALF) {  // six pieces at a time: 18 (24) 16-B loads in flight
+        f4 P[HALF], M[HALF], V[HALF], O[HALF];
+#pragma unroll
+        for (int it = 0; it < HALF; it++) {
+            const uint32_t i = tid + BLK * (h + it);
+            const uint32_t ic = i < n4 ? i : 0u;
+            P[it] = __builtin_nontemporal_load(p4 + ic);
+            M[it] = __builtin_nontemporal_load(m4 + ic);
+            V[it] = __builtin_nontemporal_load(v4 + ic);
+            if (accumulate) O[it] = g4[ic];
+        }
+#pragma unroll
+        for (int it = 0; it < HALF; it++) {
+            const uint32_t i = tid + BLK * (h + it);
+            if (i < n4) {
+                f4 G = s4[i];
+                if (accumulate) G += O[it];
+                bad |= nonfinite(G.x) | nonfinite(G.y) | nonfinite(G.z) | nonfinite(G.w);
+                float pp[4] = {P[it].x, P[it].y, P[it].z, P[it].w}, mm[4] = {M[it].x, M[it].y, M[it].z, M[it].w},
+                      vv[4] = {V[it].x, V[it].y, V[it].z, V[it].w};
+                const float gg[4] = {G.x, G.y, G.z, G.w};
+#pragma unroll
+                for (int e = 0; e < 4; e++) adam_update(pp[e], gg[e], mm[e], vv[e], ss, w1, bt2, w2, f.eps, b2);
+                __builtin_nontemporal_store(f4{pp[0], pp[1], pp[2], pp[3]}, po + i);
+                __builtin_nontemporal_store(f4{mm[0], mm[1], mm[2], mm[3]}, mo + i);
+                __builtin_nontemporal_store(f4{vv[0], vv[1], vv[2], vv[3]}, vo + i);
+            }
+        }
+    }
+    for (size_t i = 4 * (size_t)n4 + tid; i < n_floats; i += BLK) {  // (the scalar tail of a partial last block)
+        float G = src[i];
+        if (accumulate) G += dst_grad[i];
+        bad |= nonfinite(G);
+        float pp = param[i], mm = f.m_in[off0 + i], vv = f.v_in[off0 + i];
+        adam_update(pp, G, mm, vv, ss, w1, bt2, w2, f.eps, b2);
+        f.p_out[off0 + i] = pp; f.m_out[off0 + i] = mm; f.v_out[off0 + i] = vv;
+    }
+    return bad;
+}
 #endif
 
 // REST: the model has SH coefficients beyond the DC term (a template parameter, not a test of sh_coeffs: see load_raw)
@@ -1003,7 +1120,7 @@ __device__ __forceinline__ int cam_butterfly_component(int lane)
 
 // CAM: the camera cotangents as well (ModelGrads::cam_partial); the default instantiation carries none of it.
 #if defined(__HIP_DEVICE_COMPILE__)
-template <bool CAM>
+template <bool CAM, bool ADAM>
 __device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const ModelGrads& g)
 {
     constexpr int BLK = GHR_PBW_BLOCK;
@@ -1027,6 +1144,14 @@ __device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const Model
     load_raw(a, idc, in);
     const int radius = a.radii[rowc];
     if (idx >= a.P) r = make_rect4(0, 0, 0, 0, 0u);
+    // ADAM: the per-array coefficients of the fused update, one array per lane, under the first round trip of the loads above
+    float ss[GHR_ADAM_FUSE_ARRAYS], b2[GHR_ADAM_FUSE_ARRAYS];
+    if constexpr (ADAM) {
+        float ss_l = 0.f, b2_l = 0.f;
+        if ((threadIdx.x & 63) < GHR_ADAM_FUSE_ARRAYS) adam_fuse_coef(g.adam, threadIdx.x & 63, ss_l, b2_l);
+#pragma unroll
+        for (int k = 0; k < GHR_ADAM_FUSE_ARRAYS; k++) { ss[k] = __shfl(ss_l, k); b2[k] = __shfl(b2_l, k); }
+    }
     float ga[16];
     gather_inst_grads_wave(g.ginst, g.inst_line, r, q0, q1, 0.5f * a.W, 0.5f * a.H, ga, g.ginst_rows);
     // (LDS-DMA, not registers: with the slab's 48 registers on top this kernel needs 180 VGPRs -- two waves per SIMD -- or
@@ -1058,11 +1183,18 @@ __device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const Model
     if (CAM) cam[CAM ? 26 : 0] = cam[CAM ? 27 : 0] = cam[CAM ? 28 : 0] = 0.f;   // (lanes past the end of the segment)
     if (idx < a.P) {
         project_bwd_sh<CAM>(a, in, radius, ga, s_rest + threadIdx.x * row, s_rest + threadIdx.x * row, o, cam);
-        bad = project_bwd_store(a, g, idx, ga, o, radius);
+        if constexpr (ADAM) bad = project_bwd_store(a, g, idx, ga, o, radius, &in, ss, b2);
+        else bad = project_bwd_store(a, g, idx, ga, o, radius);
     }
     __syncthreads();
-    if (row > 0 && !g.cam_only)
+    if constexpr (ADAM) {
+        if (row > 0)
+            bad |= slab_out_adam<BLK>(g.d_features_rest + (size_t)base * row, a.features_rest + (size_t)base * row, s_rest,
+                                      (size_t)nb * row, threadIdx.x, g.accumulate, g.adam, ss[7], b2[7]);
+    } else if (row > 0 && !g.cam_only)
         bad |= slab_out<BLK>(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
+    if (g.overflow_is_bad && g.dens_count != nullptr && *reinterpret_cast<const volatile uint32_t*>(g.dens_count) > g.dens_cap)
+        bad = true;
     if (g.nan_flag != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & 63) == 0) atomicOr(g.nan_flag, 1);
     if constexpr (CAM) {
         const int lane = threadIdx.x & 63;
@@ -1081,23 +1213,40 @@ __device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const Model
 }
 #endif
 
-template <bool CAM>
+// ADAM: the optimizer update instead of the gradient stores (ModelGrads::adam; mode 0 only)
+template <bool CAM, bool ADAM>
 __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd(ModelArgs a, ModelGrads g);
 template <>
-__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd<false>(ModelArgs a, ModelGrads g)
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_project_bwd<false, false>(ModelArgs a, ModelGrads g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    project_bwd_body<false>(a, g);
+    project_bwd_body<false, false>(a, g);
 #endif
 }
 // (the LDS footprint allows three waves per SIMD either way: told so, the compiler takes the 168 registers that go with them
-// instead of holding this instantiation to the default one's 134 and spilling the camera cotangents)
+// instead of holding these instantiations to the default one's 134 and spilling)
 template <>
 __global__ void __launch_bounds__(GHR_PBW_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
-k_project_bwd<true>(ModelArgs a, ModelGrads g)
+k_project_bwd<true, false>(ModelArgs a, ModelGrads g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    project_bwd_body<true>(a, g);
+    project_bwd_body<true, false>(a, g);
+#endif
+}
+template <>
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_project_bwd<false, true>(ModelArgs a, ModelGrads g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    project_bwd_body<false, true>(a, g);
+#endif
+}
+template <>
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) __attribute__((amdgpu_waves_per_eu(3, 3)))
+k_project_bwd<true, true>(ModelArgs a, ModelGrads g)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    project_bwd_body<true, true>(a, g);
 #endif
 }
 

@@ -185,7 +185,8 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
         dens = bool(getattr(pipe, "densify_stats", False)) and torch.is_grad_enabled()
         renders, radii, screenspace_points, count = render_model_fused(
             viewpoint_camera, pc, bg_color, scaling_modifier, getattr(pipe, "debug", False),
-            defer_count=getattr(pipe, "defer_count", False) and not getattr(pipe, "debug", False), densify_stats=dens)
+            defer_count=getattr(pipe, "defer_count", False) and not getattr(pipe, "debug", False), densify_stats=dens,
+            fuse_adam=bool(getattr(pipe, "fuse_adam", False)))
         pkg = _package(renders, screenspace_points, radii)
         pkg.count = count
         pkg.densify_stats_done = dens

@@ -184,6 +184,13 @@ class _RenderModelFused(torch.autograd.Function):
                 # the stage-1 loop's per-iteration statistics (train_gaussians.py:161-165) ride along in k_project_bwd
                 m.dens_grad_accum, m.dens_denom, m.dens_max_radii2D = [_ptr(t) for t in dens]
                 m.dens_img_ws = _ptr(img)  # (a view whose capacity guess overflowed leaves the statistics alone: it is redone)
+            fuse = direct and P > 0 and getattr(sink, "_fuse_step", None) is not None
+            if fuse:
+                # a step whose LAST backward carries the optimizer update (optim.FusedAdam.begin_fused_step): every view checks
+                # its instance count on the device (an overflowed speculative pass must raise the step's flag) ...
+                m.dens_img_ws, m.overflow_raises_flag = _ptr(img), 1
+                if cfg.get("fuse_adam"):  # ... and this one IS the last
+                    m.adam_fuse = ctypes.addressof(sink._fuse_step["args"])
             # the step's first gradients into a buffer that is known to hold zeros are assigned, not added (optim.py)
             acc = 1
             if P > 0 and direct and sink.take_known_zero():
@@ -210,6 +217,8 @@ class _RenderModelFused(torch.autograd.Function):
             d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[9:14], dev, ctx.fov) if want_cam else (None,) * 5
         if direct:
             sink.note_direct_backward()
+            if fuse and cfg.get("fuse_adam"):
+                sink.note_fused_update()
             return (None, None, None, None, None, None, None, None, d_m2d) + d_cam + (None,)
         return (d_xyz, d_ls, d_rot, d_op, d_label, d_conf, d_fdc, d_frest, d_m2d) + d_cam + (None,)
 
@@ -249,7 +258,7 @@ def _camera_grads(cam_partial, meta, needs, dev, fov):
     return tuple(out)
 
 
-def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False, densify_stats=False):
+def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=False, densify_stats=False, fuse_adam=False):
     """Returns (renders[10,H,W], radii[P], screenspace_points[P,3] leaf whose .grad receives dL/d(NDC mean),
     num_rendered: int, or a PendingCount with ``defer_count``).  ``densify_stats``: the backward pass of this view also
     updates the model's ``xyz_gradient_accum`` / ``denom`` / ``max_radii2D`` (the reference's per-iteration bookkeeping,
@@ -270,6 +279,8 @@ def render_model_fused(cam, pc, bg_color, scaling_modifier, debug, defer_count=F
     opt = getattr(pc, "optimizer", None)
     if isinstance(opt, FusedAdam) and opt.direct_grads:
         cfg["grad_sink"] = opt
+    if fuse_adam and "grad_sink" in cfg:
+        cfg["fuse_adam"] = True
     if densify_stats and torch.is_grad_enabled():
         stats = (pc.xyz_gradient_accum, pc.denom, pc.max_radii2D)
         if not all(isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and

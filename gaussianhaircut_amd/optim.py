@@ -203,6 +203,7 @@ class FusedAdam:
             off += k
             ends.append(off)
         self.flat_param, self.exp_avg, self.exp_avg_sq = flat_p, flat_m, flat_v
+        self._fuse = None  # (the second buffer set of the fused update is re-made at the new size when next needed)
         self._ends = (ctypes.c_int64 * len(ends))(*ends)
         self.params = params
         self._mark_zero()
@@ -255,6 +256,8 @@ class FusedAdam:
 
     # ---- direct-gradient sink used by gaussian_renderer.fused
     def nan_flag_ptr(self):
+        if self._fuse_step is not None:  # a step whose last backward carries the update: its own flag word (see below)
+            return self.fused_flag_ptr()
         return ctypes.c_void_p(self.state_dev.data_ptr() + 4)
 
     def note_direct_backward(self):
@@ -275,6 +278,83 @@ class FusedAdam:
             ev.record(stream)
             self._acc_event = ev
 
+    # ---- the update fused into the step's last projection backward (include/ghr.h, ghr_adam_fuse; round 6) ----------------
+    # One rank, every view through the fused renderer's direct backward, no group sitting the step out: the LAST view's
+    # k_project_bwd holds the step's whole gradient in registers and applies the update itself -- p, m, v read from the current
+    # buffers, written to a second set whose role is swapped with the first after the step -- so that 244 B of gradient per
+    # Gaussian are neither written nor read back and k_adam_v4 does not run.  The skip-on-non-finite rule stays exact: the
+    # kernel that follows undoes the update (copies the old values over the new) when the step's flag is up; a view whose
+    # speculative forward pass overflowed its capacity raises the same flag, so the trainer's recovery finds the parameters
+    # untouched.  The gradient buffer is left as it was (contents undefined, as with zero_grad="defer").
+    _fuse = None           # {"p", "m", "v": the second set; "flags": two int32 words; "parity"; "clean"}
+    _fuse_step = None      # while a fused step is in progress: its ghr_adam_fuse + what keeps the pointers alive
+    fused_steps = 0
+
+    def can_fuse_step(self) -> bool:
+        return (self.nan_guard and self.direct_grads and self._skip_next == 0 and self._moment_shards is None and
+                not collectives_on() and len(self.param_groups) <= 16 and
+                all(len(g["params"]) == 1 for g in self.param_groups))
+
+    def begin_fused_step(self):
+        """Called by the trainer before the views of a step whose last backward will carry the update.  From here until
+        ``end_fused_step`` every view's backward raises THIS step's flag word (``nan_flag_ptr``)."""
+        n, dev = self.flat_param.numel(), self.flat_param.device
+        f = self._fuse
+        if f is None or f["p"].numel() != n:
+            f = self._fuse = dict(p=torch.empty(n, dtype=torch.float32, device=dev), m=torch.empty(n, dtype=torch.float32, device=dev),
+                                  v=torch.empty(n, dtype=torch.float32, device=dev),
+                                  flags=torch.zeros(2, dtype=torch.int32, device=dev), parity=0, clean=True)
+        if not f["clean"]:
+            f["flags"].zero_()  # (the previous step was not a fused one: its finish kernel did not clear this step's word)
+            f["clean"] = True
+        lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
+        a = _lib.AdamFuse()
+        a.n = n
+        a.p_in, a.m_in, a.v_in = _ptr(self.flat_param), _ptr(self.exp_avg), _ptr(self.exp_avg_sq)
+        a.p_out, a.m_out, a.v_out = _ptr(f["p"]), _ptr(f["m"]), _ptr(f["v"])
+        a.state = _ptr(self.state_dev)
+        base = f["flags"].data_ptr()
+        a.flag, a.flag_next = base + 4 * f["parity"], base + 4 * (1 - f["parity"])
+        a.n_groups = len(self.param_groups)
+        a.group_end_host = ctypes.cast(self._ends, ctypes.c_void_p)
+        a.lr_host = ctypes.cast(lrs, ctypes.c_void_p)
+        a.beta1, a.beta2, a.eps = float(self.betas[0]), float(self.betas[1]), float(self.eps)
+        self._fuse_step = dict(args=a, lrs=lrs, done=False)
+        return a
+
+    def fused_flag_ptr(self):
+        return ctypes.c_void_p(int(self._fuse_step["args"].flag))
+
+    def note_fused_update(self):
+        """The step's last backward has launched the update (gaussian_renderer.fused)."""
+        self._fuse_step["done"] = True
+
+    def end_fused_step(self) -> bool:
+        """After the views: True when the update was carried by the last backward -- the two buffer sets then swap roles and
+        the parameters are re-pointed (host work only); False: nothing happened, the caller steps the usual way."""
+        st, self._fuse_step = self._fuse_step, None
+        f = self._fuse
+        if st is None or not st["done"]:
+            if f is not None:
+                f["clean"] = False  # views may have raised this step's word
+            return False
+        f["p"], self.flat_param = self.flat_param, f["p"]
+        f["m"], self.exp_avg = self.exp_avg, f["m"]
+        f["v"], self.exp_avg_sq = self.exp_avg_sq, f["v"]
+        f["parity"] = 1 - f["parity"]  # (the finish kernel cleared the other word: clean for the next fused step)
+        off = 0
+        for g in self.param_groups:
+            p = g["params"][0]
+            k = p.numel()
+            p.data = self.flat_param[off:off + k].view(p.shape)
+            off += k
+        self._direct_backwards = 0
+        self._acc_event = None
+        self._skip_next = 0
+        self._after_step(False, True)  # the gradient buffer was neither zeroed nor written: undefined until the next backward
+        self.fused_steps += 1
+        return True
+
     # ---- optimizer interface
     def step(self, zero_grad=True, nan_scan: bool = True):
         """``zero_grad``: True (the pass zeroes the gradients), False (left as they are) or "defer" (left UNDEFINED until
@@ -284,6 +364,8 @@ class FusedAdam:
         self.resolve_deferred()  # (a step without a backward since a deferred one: its gradients are zeros)
         zero_grad, defer = _zero_grad_mode(zero_grad)
         self._sync_before_replicated_update()
+        if self._fuse is not None:
+            self._fuse["clean"] = False
         lrs = (ctypes.c_float * len(self.param_groups))(*[float(g["lr"]) for g in self.param_groups])
         guard = 0 if not self.nan_guard else (1 if nan_scan or self._direct_backwards == 0 else 2)
         self._direct_backwards = 0

@@ -28,6 +28,8 @@ def _one_like(loss):
 
 
 OVERLAP_ALL_REDUCE_WITH_ADAM = os.environ.get("GHR_OVERLAP_AR_ADAM", "1") != "0"
+# One rank, fused path: the step's LAST projection backward applies the optimizer update itself (optim.FusedAdam.begin_fused_step)
+FUSE_ADAM_INTO_BACKWARD = os.environ.get("GHR_FUSE_ADAM", "1") != "0"
 DEFER_GRAD_ZEROING = os.environ.get("GHR_DEFER_GRAD_ZEROING", "1") != "0"
 CACHE_GT_SSIM_STATS = True  # keep the SSIM window moments of every camera's ground truth (2*3*H*W floats per camera)
 
@@ -96,9 +98,13 @@ def _side_streams(device, n):
     return _SIDE_STREAMS[key]
 
 
-def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams, sink):
-    """render + loss + backward of every view; returns (detached losses, instance counts [int | PendingCount])."""
+def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams, sink, last_pipe=None):
+    """render + loss + backward of every view; returns (detached losses, instance counts [int | PendingCount]).
+    ``last_pipe``: the pipe of the step's LAST view (it may carry the fused optimizer update)."""
     losses, counts = [], []
+    pipes = [pipe] * len(cams)
+    if last_pipe is not None and cams:
+        pipes[-1] = last_pipe
     if n_streams > 1:
         main = torch.cuda.current_stream(background.device)
         side = _side_streams(background.device, n_streams)
@@ -108,6 +114,7 @@ def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams
         try:
             for i, cam in enumerate(cams):
                 with torch.cuda.stream(side[i % n_streams]):
+                    pipe = pipes[i]
                     pkg = render(cam, gaussians, pipe, background)
                     loss = view_loss(pkg, cam, opt, scale=1.0 / V)
                     loss.backward(gradient=_one_like(loss))
@@ -121,7 +128,7 @@ def _views_forward_backward(gaussians, cams, background, opt, V, pipe, n_streams
             for s in side:
                 main.wait_stream(s)
     else:
-        for cam in cams:
+        for cam, pipe in zip(cams, pipes):
             pkg = render(cam, gaussians, pipe, background)
             loss = view_loss(pkg, cam, opt, scale=1.0 / V)
             loss.backward(gradient=_one_like(loss))
@@ -143,7 +150,7 @@ def _generic_densify_stats(gaussians, pkg, pipe):
 
 def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
                   global_views: Optional[int] = None, pipe=PIPE, streams: Optional[int] = None,
-                  defer_counts: Optional[bool] = None, densify_stats: bool = False):
+                  defer_counts: Optional[bool] = None, densify_stats: bool = False, fuse_adam: Optional[bool] = None):
     """One global gradient step over this rank's views.  Returns the (detached) summed local loss.
 
     ``streams`` (default 2 with the fused path and more than one view): the views of the step are independent given
@@ -160,7 +167,13 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     ``densify_stats``: every view's backward pass also keeps the per-iteration densification statistics of the stage-1 loop
     (``max_radii2D``, ``xyz_gradient_accum``, ``denom``: src/train_gaussians.py:161-165, half of the iterations of a run) --
     inside ``k_project_bwd`` on the fused path (no extra launch); ``densification_step(..., stats_done=True)`` then only
-    densifies / prunes at its interval.  Views that take the generic path get the PyTorch form."""
+    densifies / prunes at its interval.  Views that take the generic path get the PyTorch form.
+
+    ``fuse_adam`` (default on: one rank, every view on the fused path): the step's last ``k_project_bwd`` applies the Adam
+    update from the gradients it holds in registers (``ghr_adam_fuse``): no 244 B of gradient per Gaussian written and read
+    back, no separate optimizer pass.  Same parameters, bit for bit, as the separate pass; the NaN rule stays exact (the
+    update is undone on the device when the step's flag is up).  After such a step ``p.grad`` still holds what the previous
+    separate pass left there (``zero_grad="defer"`` semantics: undefined) -- pass ``fuse_adam=False`` to log gradient norms."""
     from .optim import FusedAdam
     gaussians.update_learning_rate(iteration)
     # the loss of a view is scaled 1 / V: with more than one rank V defaults to the GLOBAL number of views (the
@@ -191,7 +204,21 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     run_pipe = pipe
     if defer or densify_stats:
         run_pipe = SimpleNamespace(**{**vars(pipe), "defer_count": bool(defer), "densify_stats": bool(densify_stats)})
-    losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, run_pipe, n_streams, sink)
+    from .optim import collectives_on
+    # (the fused update leaves the gradient buffer undefined, like zero_grad="defer": not for callers who switched that off)
+    fuse = (FUSE_ADAM_INTO_BACKWARD and DEFER_GRAD_ZEROING if fuse_adam is None else bool(fuse_adam)) and all_direct and \
+        bool(cams) and not collectives_on() and bucket is None
+    last_pipe = None
+    if fuse:
+        sink.cancel_skip()  # (as below: every backward of this step runs after any earlier surgery)
+        fuse = sink.can_fuse_step()
+    if fuse:
+        sink.begin_fused_step()
+        last_pipe = SimpleNamespace(**{**vars(run_pipe), "fuse_adam": True})
+    try:
+        losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, run_pipe, n_streams, sink, last_pipe)
+    finally:
+        fused_done = sink.end_fused_step() if fuse else False
     overflow = [c.resolve()[1] for c in counts if hasattr(c, "resolve")]  # resolve every one: they feed the next guess
     if any(overflow):
         # a guessed capacity was too small: that view's image, loss and gradients are garbage (memory-safe garbage).
@@ -209,10 +236,15 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                                "step after the scene has grown")
         redo_pipe = SimpleNamespace(**{**vars(pipe), "densify_stats": True}) if densify_stats else pipe
         losses, counts = _views_forward_backward(gaussians, cams, background, opt, V, redo_pipe, 0, sink)
+        if fused_done:  # (the overflowed views raised the step's flag: the fused update was undone on the device)
+            sink.fused_steps -= 1
+            fused_done = False
     if not losses:  # a rank without views in this step still takes part in the collectives and the update
         total = torch.zeros((), device=background.device)
     else:
         total = losses[0] if len(losses) == 1 else torch.stack(losses).sum()
+    if fused_done:
+        return total  # the last view's backward carried the update (k_adam_v4 did not run)
     if isinstance(gaussians.optimizer, FusedAdam):
         # Every backward of this step ran AFTER any earlier optimizer surgery (densification / opacity reset between two
         # calls), so all groups hold fresh gradients: the "parameters replaced since the last backward" marks never apply

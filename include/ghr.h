@@ -140,6 +140,7 @@ int ghr_backward_ex(void* stream, const ghr_view_args* a, uint32_t R, const int3
  *   (:143-228) -- and feeds K1's cull / radius / tile rect directly.  ghr_model_backward runs K8 and then maps the
  *   packed per-Gaussian gradients to raw-parameter gradients (what autograd does for that graph), in one pass.
  * Semantics are the PYTHON pipeline's (torch.clamp / normalize / clamp_min gradients, conic eps), tolerance 1e-4. */
+struct ghr_adam_fuse;
 typedef struct ghr_model_args {
     int32_t P, W, H;
     int32_t sh_degree;            /* active SH degree 0..3 */
@@ -207,7 +208,45 @@ typedef struct ghr_model_args {
      * there is within the capacity R the backward call is given -- a view rasterized speculatively with too small a capacity
      * (ghr_forward_stage2) has invalid gradients and is recomputed by the caller: its statistics must not be counted twice. */
     const void* dens_img_ws;
+    /* != 0 with dens_img_ws (statistics pointers may be NULL): a view whose instance count exceeds the capacity R raises nan_flag
+     * -- what every view of a step whose LAST backward carries adam_fuse must do (see ghr_adam_fuse). */
+    int32_t overflow_raises_flag;
+    /* ---- the optimizer update fused into this backward call (mode 0, the LAST backward of a single-rank gradient step): see
+     * ghr_adam_fuse below.  NULL: gradients are stored / accumulated as documented. */
+    const struct ghr_adam_fuse* adam_fuse;
 } ghr_model_args;
+
+/* Adam fused into the projection backward (src/scene/gaussian_model.py:431-444 stepped at src/train_gaussians.py:174-181).
+ * The last view's backward of a step holds every parameter gradient of the step in registers -- its own terms plus what the
+ * earlier views accumulated in the gradient buffers it is given with accumulate != 0 -- and the raw parameters too: with
+ * adam_fuse set it applies ghr_adam_step's update there and stores NO gradients (the gradient buffers are left as they were:
+ * 244 B per Gaussian neither written nor read back by a separate optimizer pass).
+ * Two sets of flat buffers of n floats each: the raw-parameter pointers of ghr_model_args must point into p_in (all eight
+ * arrays; together they must tile it: the reference's eight parameter groups), m_in / v_in are the moments at the same offsets;
+ * the updated p, m, v go to p_out / m_out / v_out at the same offsets, and the caller swaps the roles of the two sets for the
+ * next step.  The skip-on-non-finite rule is global: nan_flag of the backward call must be `flag`; after the projection kernel
+ * the call launches a second kernel that, when *flag != 0, copies in -> out (the update is undone: 732 B per Gaussian, a rare
+ * event) and otherwise advances state[0]; it clears *flag_next, never *flag -- alternate two words between steps (every view of
+ * a step raises the same word).  With dens_img_ws set, a view whose instance count exceeds the capacity R raises the flag as
+ * well (a speculative forward pass that overflowed must not reach the parameters).
+ * state / n_groups / group_end_host / lr_host / beta1 / beta2 / eps: as ghr_adam_step (no group may be marked to sit out). */
+typedef struct ghr_adam_fuse {
+    int64_t n;
+    const float* p_in;
+    const float* m_in;
+    const float* v_in;
+    float* p_out;
+    float* m_out;
+    float* v_out;
+    int32_t* state;
+    int32_t* flag;
+    int32_t* flag_next;
+    int32_t n_groups;
+    const int64_t* group_end_host;
+    const float* lr_host;
+    double beta1, beta2;
+    float eps;
+} ghr_adam_fuse;
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
  * carries P, W, H, C and background; every other field may be NULL).  means2D_out [P,3] (NDC) may be NULL. */

@@ -275,6 +275,7 @@ void ghrsim_project_backward3(const ghr::ModelArgs* a_in, const int* radii, cons
     g.accumulate = 0; g.nan_flag = nullptr;
     g.cam_partial = nullptr; g.cam_slot0 = 0; g.cam_stride = 0; g.cam_only = 0; g.detach_means2D = detach_means2D;
     g.dens_grad_accum = nullptr; g.dens_denom = nullptr; g.dens_max_radii = nullptr; g.dens_count = nullptr; g.dens_cap = 0;
+    g.overflow_is_bad = 0; g.adam.on = 0;
     const int row = 3 * (a.sh_coeffs - 1);
     for (int i = 0; i < a.P; i++)
         ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row,

@@ -155,7 +155,7 @@ def test_two_ranks_on_one_gpu_through_step_chunked_reduce(sh_degree):
     model, cams, bg, opt = _scene(dev, sh_degree)
     grads = []
     _capture_reduced_gradient(model, grads)
-    training_step(model, cams, bg, opt, 1, global_views=VIEWS)
+    training_step(model, cams, bg, opt, 1, global_views=VIEWS, fuse_adam=False)  # (the capture wraps optimizer.step())
     torch.cuda.synchronize()
     ref = grads[0].cpu().numpy()
     got = res[0]["grad0"]

@@ -160,7 +160,8 @@ def test_multi_stream_views_equal_sequential_views():
             grads.append(o.flat_grad.detach().clone())
             return orig_step(**kw)
         o.step = capture
-        losses = [float(training_step(model, cams, bg, opt, i + 1, streams=n_streams)) for i in range(6)]
+        # (fuse_adam=False: the wrapper around optimizer.step() above is how this test sees the gradients)
+        losses = [float(training_step(model, cams, bg, opt, i + 1, streams=n_streams, fuse_adam=False)) for i in range(6)]
         torch.cuda.synchronize()
         assert not o.concurrent and o._acc_event is None
         assert np.isfinite(losses).all() and losses[-1] < losses[0]
@@ -217,7 +218,7 @@ def test_deferred_counts_recover_from_a_too_small_capacity_guess():
             return orig_step(**kw)
         o.step = capture
         try:
-            loss = float(tr.training_step(model, cams, bg, opt, 1, defer_counts=(mode != "wait")))
+            loss = float(tr.training_step(model, cams, bg, opt, 1, defer_counts=(mode != "wait"), fuse_adam=False))
         finally:
             tr._views_forward_backward = orig
         torch.cuda.synchronize()
@@ -679,7 +680,7 @@ def test_deferred_gradient_zeroing_is_invisible_or_loud():
         # `optimizer.flat`, whose contract is "what the next accumulation starts from", zero-fills first
         model = syn.make_model(spec, dev)
         model.training_setup(opt)
-        training_step(model, cams[:2], bg, opt, 1)
+        training_step(model, cams[:2], bg, opt, 1, fuse_adam=False)  # (a fused update stores no gradients at all)
         o = model.optimizer
         assert o._deferred is not None
         g = model._xyz.grad
@@ -846,6 +847,76 @@ def test_densification_statistics_inside_the_projection_backward_are_bit_identic
         torch.cuda.synchronize()
         for t0, t1 in zip(before, (a.xyz_gradient_accum, a.denom, a.max_radii2D)):
             assert torch.equal(t0, t1)
+    finally:
+        _lib.lib().ghr_set_deterministic(0)
+        dgr._R_HINT.pop(dev.index, None)
+        dgr._R_RECENT.clear()
+
+
+def _same_bits(a, b):
+    return bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
+
+
+def test_adam_fused_into_the_last_projection_backward_is_bit_identical():
+    """on one rank the step's LAST k_project_bwd applies the Adam update itself (ghr_adam_fuse: p, m, v read
+    from one buffer set, written to the other, roles swapped after the step; the gradients of the step never reach HBM).  Same
+    parameters, moments and step count as the separate k_adam_v4 pass, bit for bit, over a sequence with a single-view step, a
+    step whose gradients are NaN (skipped: train_gaussians.py:174-181 -- the update is undone on the device), a two-view step on
+    two streams, and a step whose capacity guess overflows (the overflowed view raises the step's flag; the trainer recomputes)."""
+    import copy
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny_strands"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    cams = ring_cameras(4, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, cams, bg)
+    # step 2 (0-based) runs with a NaN opacity logit: its gradients are NaN, the producer-side flag goes up, the step is skipped
+    plan = [([cams[0]], False), ([cams[1]], False), ([cams[1]], False), ([cams[2], cams[3]], False), ([cams[0]], True),
+            ([cams[3]], False)]
+    _lib.lib().ghr_set_deterministic(1)
+    try:
+        runs = {}
+        for fused in (True, False):
+            model = syn.make_model(spec, dev)
+            model.training_setup(opt)
+            o = model.optimizer
+            trace = []
+            for it, (views, overflow) in enumerate(plan):
+                if overflow:  # a capacity guess far below the instance count
+                    dgr._R_RECENT.clear()
+                    dgr._R_HINT[dev.index] = 4096
+                if it == 2:
+                    with torch.no_grad():
+                        keep = model._opacity[3].clone()
+                        model._opacity[3] = float("nan")
+                training_step(model, views, bg, opt, it + 1, fuse_adam=fused)
+                torch.cuda.synchronize()
+                if it == 2:
+                    with torch.no_grad():
+                        assert bool(torch.isnan(model._opacity[3]).all())  # (the skipped step left it alone)
+                        model._opacity[3] = keep
+                assert model._xyz.data_ptr() == o.flat_param.data_ptr(), "the parameters must alias the CURRENT flat buffer"
+                trace.append((o.flat_param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), int(o.state_dev[0])))
+            runs[fused] = trace
+            # every step but the overflowed one (recomputed the blocking way, with the separate pass) was carried by the backward
+            assert o.fused_steps == (len(plan) - 1 if fused else 0), o.fused_steps
+        for it, (a, b) in enumerate(zip(runs[True], runs[False])):
+            assert a[3] == b[3], (it, a[3], b[3])
+            for x, y in zip(a[:3], b[:3]):
+                assert _same_bits(x, y), (it, float((x - y).abs().max()))
+        steps = [t[3] for t in runs[True]]
+        assert steps == [1, 2, 2, 3, 4, 5], steps   # the NaN step did not count
+        assert _same_bits(runs[True][2][0], runs[True][1][0])  # ... and left the parameters alone
+        assert not _same_bits(runs[True][3][0], runs[True][2][0])
     finally:
         _lib.lib().ghr_set_deterministic(0)
         dgr._R_HINT.pop(dev.index, None)

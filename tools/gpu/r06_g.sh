@@ -1,0 +1,3 @@
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+P=$PWD/gpurun_out/r06g; mkdir -p $P; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+timeout 900 python -m pytest tests/test_gpu_fused.py -m gpu -q -k adam_fused 2>&1 | tail -30 > $P/a.log
