@@ -146,8 +146,92 @@ class DensificationMixin:
                                    self._orient_conf[sel], self._label[sel], self._scaling[sel], self._rotation[sel])
 
     @torch.no_grad()
+    def _densify_and_prune_onepass(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
+        """The same event with ONE re-lay of the optimizer's flat buffers (FusedAdam): the reference's sequence -- clone,
+        postfix, split, postfix, prune the split sources, prune by opacity / size (gaussian_model.py:680-741) -- re-lays every
+        buffer four times and gathers by boolean mask some sixty times (each a device-to-host round trip for the row count).
+        Here the three decisions are taken on per-row scalars, the surviving rows are described by (source row, kind) and every
+        group is gathered once by index: three host round trips in all.  Same rows, same order, same values, same moments, same
+        random numbers (the split samples are drawn with the same shape from the same generator) as the stepwise path --
+        tests/test_gpu_fused.py compares the two bit for bit."""
+        dev = self.get_xyz.device
+        P0 = self.get_xyz.shape[0]
+        grads = self.xyz_gradient_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        scal = self.get_scaling
+        smax = torch.max(scal, dim=1).values
+        limit = self.percent_dense * extent
+        sel_c = torch.logical_and(torch.norm(grads, dim=-1) >= max_grad, smax <= limit)          # densify_and_clone
+        # densify_and_split looks at the model AFTER the clones were appended, with the gradients padded by zeros: a clone
+        # (small by selection) can never be split, so the selection lives on the original rows
+        sel_s = torch.logical_and(grads.squeeze(-1) >= max_grad, smax > limit)
+        idx_c = sel_c.nonzero(as_tuple=True)[0]
+        idx_s = sel_s.nonzero(as_tuple=True)[0]
+        n_c, n_s, N = int(idx_c.numel()), int(idx_s.numel()), 2
+        if max_grad <= 0 and n_c:  # (zero-padded gradients would pass a non-positive threshold: leave that to the stepwise path)
+            return None
+        # the split children (gaussian_model.py:688-697)
+        stds = scal[idx_s].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds, generator=generator)
+        rots = build_rotation(self._rotation[idx_s]).repeat(N, 1, 1)
+        child_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[idx_s].repeat(N, 1)
+        child_scaling = self.scaling_inverse_activation(scal[idx_s].repeat(N, 1) / (0.8 * N))
+        # rows after clone + split, before any pruning: the originals, the clones, the children
+        src = torch.cat([torch.arange(P0, device=dev), idx_c, idx_s.repeat(N)])
+        P2 = P0 + n_c + N * n_s
+        keep = torch.ones(P2, dtype=torch.bool, device=dev)
+        keep[idx_s] = False                                                                       # the split sources go
+        # the final prune looks at the model after all that: opacity and largest scale of every row (the children's from
+        # their new raw scaling, through the activation, exactly as get_scaling would)
+        prune = self.opacity_activation(self._opacity[src]).squeeze(-1) < min_opacity
+        if max_screen_size:
+            row_smax = smax[src]
+            if n_s:
+                row_smax[P0 + n_c:] = torch.max(self.scaling_activation(child_scaling), dim=1).values
+            # (max_radii2D was reset by the densification_postfix calls of the stepwise sequence: `big_points_vs` is empty)
+            prune = torch.logical_or(prune, row_smax > 0.1 * extent)
+        keep &= ~prune
+        rows = keep.nonzero(as_tuple=True)[0]
+        take = src[rows]
+        fresh = rows >= P0                       # clones and children start with zero moments
+        child = rows - (P0 + n_c)                # >= 0 for the children: their place in child_xyz / child_scaling
+        is_child = child >= 0
+        o = self.optimizer
+        o.sync_moments()
+        ps, ms, vs = [], [], []
+        off = 0
+        for g in o.param_groups:
+            p = g["params"][0]
+            k = p.numel()
+            m = o.exp_avg[off:off + k].view(p.shape)
+            v = o.exp_avg_sq[off:off + k].view(p.shape)
+            off += k
+            pn = p.data.index_select(0, take)
+            bshape = (-1,) + (1,) * (p.dim() - 1)
+            if g["name"] in ("xyz", "scaling") and n_s:  # (selects, not masked assignments: those read the row count back)
+                new = (child_xyz if g["name"] == "xyz" else child_scaling).index_select(0, child.clamp_min(0))
+                pn = torch.where(is_child.view(bshape), new, pn)
+            zero = torch.zeros((), dtype=pn.dtype, device=dev)
+            mn = torch.where(fresh.view(bshape), zero, m.index_select(0, take))
+            vn = torch.where(fresh.view(bshape), zero, v.index_select(0, take))
+            ps.append(pn); ms.append(mn); vs.append(vn)
+        t = o._rebuild(ps, ms, vs)
+        self._assign(t)
+        self._orient_conf = t["orient_conf"] if "orient_conf" in t else torch.zeros_like(self._label)
+        P = self.get_xyz.shape[0]
+        self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+        self.denom = torch.zeros((P, 1), device=dev)
+        self.max_radii2D = torch.zeros((P,), device=dev)
+        return P
+
+    ONEPASS_DENSIFY = True
+
+    @torch.no_grad()
     def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size, generator=None):
         """gaussian_model.py:727-741 (the reference calls it under ``torch.no_grad()``, train_gaussians.py:146)."""
+        if self.ONEPASS_DENSIFY and self._is_fused() and all(len(g["params"]) == 1 for g in self.optimizer.param_groups):
+            if self._densify_and_prune_onepass(max_grad, min_opacity, extent, max_screen_size, generator) is not None:
+                return
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
         self.densify_and_clone(grads, max_grad, extent)

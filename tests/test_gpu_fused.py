@@ -921,3 +921,49 @@ def test_adam_fused_into_the_last_projection_backward_is_bit_identical():
         _lib.lib().ghr_set_deterministic(0)
         dgr._R_HINT.pop(dev.index, None)
         dgr._R_RECENT.clear()
+
+
+def test_onepass_densify_and_prune_equals_the_stepwise_sequence_bit_for_bit():
+    """scene/densification.py: with FusedAdam one densification event is ONE re-lay of the flat buffers (decisions on per-row
+    scalars, every group gathered once by index) instead of the reference's clone / split / prune sequence with its ~60
+    boolean-mask gathers (src/scene/gaussian_model.py:680-741, which the stepwise path mirrors and tests/test_reference_golden.py
+    pins to the reference).  Same rows in the same order, parameters, moments, statistics and random samples, bit for bit --
+    with and without a size threshold, and with an empty selection."""
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    cam, bg = syn.make_view(spec, dev), syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, [cam], bg)
+    for thr_q, size in ((0.5, None), (0.7, 20), (2.0, 20)):   # (quantile 2.0 -> a threshold nothing reaches)
+        states = []
+        for onepass in (True, False):
+            m = syn.make_model(spec, dev)
+            m.training_setup(opt)
+            m.ONEPASS_DENSIFY = onepass
+            for it in range(4):
+                training_step(m, [cam], bg, opt, it + 1, densify_stats=True, fuse_adam=False)
+            with torch.no_grad():  # some Gaussians nearly transparent: the opacity prune has work to do
+                m._opacity[::7] = -7.0
+            g = (m.xyz_gradient_accum / m.denom.clamp_min(1)).reshape(-1)
+            thr = float(g[m.denom.reshape(-1) > 0].quantile(min(thr_q, 1.0))) * (10.0 if thr_q > 1 else 1.0)
+            gen = torch.Generator(device=dev).manual_seed(5)
+            P0 = m.get_xyz.shape[0]
+            m.densify_and_prune(thr, 0.005, 2.5, size, generator=gen)
+            torch.cuda.synchronize()
+            o = m.optimizer
+            states.append(dict(P=m.get_xyz.shape[0], p=o.flat_param.clone(), m=o.exp_avg.clone(), v=o.exp_avg_sq.clone(),
+                               skip=o._skip_next, acc=m.xyz_gradient_accum.clone(), den=m.denom.clone(),
+                               rad=m.max_radii2D.clone(), conf=m._orient_conf.detach().clone(), P0=P0))
+            training_step(m, [cam], bg, opt, 10)   # the re-laid model trains on
+        a, b = states
+        assert a["P"] == b["P"] and a["skip"] == b["skip"], (a["P"], b["P"])
+        if thr_q <= 1:
+            assert a["P"] != a["P0"]
+        for k in ("p", "m", "v", "acc", "den", "rad", "conf"):
+            assert torch.equal(a[k], b[k]), (thr_q, size, k)
