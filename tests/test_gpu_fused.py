@@ -940,6 +940,16 @@ def test_onepass_densify_and_prune_equals_the_stepwise_sequence_bit_for_bit():
     with torch.no_grad():
         gt._features_dc.add_(0.3)
     make_ground_truth(gt, [cam], bg)
+    from gaussianhaircut_amd import _lib
+    _lib.lib().ghr_set_deterministic(1)  # (the two models must reach the event with the same bits)
+    try:
+        _onepass_cases(spec, opt, cam, bg, dev)
+    finally:
+        _lib.lib().ghr_set_deterministic(0)
+
+
+def _onepass_cases(spec, opt, cam, bg, dev):
+    from gaussianhaircut_amd.trainer import training_step
     for thr_q, size in ((0.5, None), (0.7, 20), (2.0, 20)):   # (quantile 2.0 -> a threshold nothing reaches)
         states = []
         for onepass in (True, False):
