@@ -145,6 +145,10 @@ def main():
             gt._features_dc.add_((0.05 * torch.randn(gt._features_dc.shape, generator=g)).to(dev))
             make_ground_truth(gt, pool_, bg)
             del gt
+            # ... and what a data loader would hand over with them: the SSIM window moments of every camera's ground truth
+            # (constants of a training view, trainer._gt_stats: 2 x 3 planes per camera, computed once)
+            for c in pool_:
+                _tr._gt_stats(c, c.original_image, c.original_mask, True)
         model_.training_setup(opt)  # FusedAdam on ROCm: flat params / grads / moments
         torch.cuda.synchronize()
         return model_, pool_
@@ -218,7 +222,10 @@ def main():
     model, pool = build_scene(spec, NC)
     K, Wm = args.steps, args.warmup
     L.ghr_set_profile_events(None, None, None, None)
-    elapsed, used = timed_steps(model, pool, V, Wm, K)
+    # settle (setup, untimed, like the ground-truth renders above): every camera of the pool is stepped through once, so that the
+    # allocator's pools, the capacity guess and the clocks are those of a running training loop when the W warm-up steps begin
+    timed_steps(model, pool, V, len(pool), 0)
+    elapsed, used = timed_steps(model, pool, V, Wm, K, it0=len(pool))
     ms_per_step = 1e3 * elapsed / K
 
     N_pix = spec.W * spec.H
@@ -305,7 +312,10 @@ def main():
                     " + gradient sum over %d ranks (backend %s%s)" % (world, backend, " = RCCL" if backend == "nccl" else "")
                     if world > 1 else ""),
                    "views_per_gpu": V, "global_views": global_views, "parallelism": "view-dp%d" % world,
-                   "backend": backend, "cameras_per_gpu": len(pool),
+                   "backend": backend, "cameras_per_gpu": len(pool), "settle_steps_before_warmup": len(pool),
+                   "optimizer": ("Adam applied by the step's last k_project_bwd (ghr_adam_fuse): %d of the %d timed + warm-up steps"
+                                 % (model.optimizer.fused_steps - len(pool), K + Wm)) if getattr(model.optimizer, "fused_steps", 0)
+                   else "separate k_adam_v4 pass",
                    "P_model": P_model, "P_visible_per_camera": P_vis,
                    "num_rendered_per_camera": [per_cam[c][0][1] for c in sorted(per_cam)],
                    "value_is": "sum over the timed steps' views of the Gaussians that pass the cull / elapsed time"},

@@ -101,8 +101,16 @@ _R_RECENT = {}  # device index -> those counts (cameras of a training set differ
                 # overflow every time a wide view follows a narrow one)
 
 
+_R_P = {}       # device index -> the number of Gaussians (rows handed to the op) those counts belong to: a guess learnt on one
+                # model says nothing about another (bench.py alternates a 500k and a 2M model: the 2M model's guess made every
+                # view of the small one allocate, sort and gather for 6.5 M instances -- 2.1 ms per step instead of 0.75)
+
+
 def _note_count(dev_index, R, P):
     import collections
+    if _R_P.get(dev_index) != int(P):
+        _R_RECENT.pop(dev_index, None)
+        _R_P[dev_index] = int(P)
     recent = _R_RECENT.setdefault(dev_index, collections.deque(maxlen=64))
     recent.append(int(R))
     m = max(recent)
@@ -137,7 +145,8 @@ def run_stage2(dev, P, pinned, launch, defer=False):
     ``defer``: do not wait at all -- num_rendered comes back as a ``PendingCount`` the caller resolves later (the
     training step: once per step, after every view is queued)."""
     stream = torch.cuda.current_stream()
-    hint = _R_HINT.get(dev.index) if P > 0 else None
+    # (no guess for a model of another size than the one the guess was learnt on: that frame waits for its count)
+    hint = _R_HINT.get(dev.index) if P > 0 and _R_P.get(dev.index, int(P)) == int(P) else None
     if hint and defer:
         ev = torch.cuda.Event()
         ev.record(stream)
