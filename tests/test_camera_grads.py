@@ -246,3 +246,53 @@ def test_gpu_trainable_fov_is_never_read_back_by_the_host():
     pkg = render(c1, model, pipe, syn.background(dev))
     # tan on the device (fp32) and math.tan on the host (double, rounded) may differ in the last bit: 1e-6 of the image
     assert (pkg.renders_packed.detach() - img0).abs().max() <= 1e-5 * img0.abs().max()
+
+
+@pytest.mark.gpu
+def test_gpu_trainable_camera_inside_a_training_step_with_the_fused_update():
+    """k_project_bwd<CAM, ADAM>: a training step whose camera tensors require grad AND whose last backward carries the optimizer
+    update (trainer.training_step, one rank).  Camera gradients and the updated parameters must equal, bit for bit, those of the
+    same step with the separate optimizer pass (deterministic gradient walk), and the camera gradients must be those of a plain
+    render() + loss + backward without any optimizer."""
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import PIPE, make_ground_truth, training_step, view_loss
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny_strands"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    bg = syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    base = mk.camera_for(spec, "ring5", dev)
+    make_ground_truth(gt, [base], bg)
+
+    def trainable():
+        import copy
+        return mk.leaf_camera(copy.copy(base))
+
+    _lib.lib().ghr_set_deterministic(1)
+    try:
+        outs = {}
+        for fused in (True, False):
+            model = syn.make_model(spec, dev)
+            model.training_setup(opt)
+            cam = trainable()
+            training_step(model, [cam], bg, opt, 1, fuse_adam=fused)
+            torch.cuda.synchronize()
+            assert model.optimizer.fused_steps == (1 if fused else 0)
+            outs[fused] = ({n: getattr(cam, n).grad.detach().clone() for n in mk.CAM_LEAVES},
+                           model.optimizer.flat_param.clone(), model.optimizer.exp_avg.clone())
+        for n in mk.CAM_LEAVES:
+            assert torch.equal(outs[True][0][n], outs[False][0][n]), n
+        assert torch.equal(outs[True][1], outs[False][1]) and torch.equal(outs[True][2], outs[False][2])
+        model = syn.make_model(spec, dev)
+        cam = trainable()
+        pkg = render(cam, model, PIPE, bg)
+        view_loss(pkg, cam, opt).backward()
+        for n in mk.CAM_LEAVES:
+            assert torch.equal(cam.__dict__[n].grad, outs[True][0][n]), n
+        assert float(outs[True][0]["world_view_transform"].abs().max()) > 0
+    finally:
+        _lib.lib().ghr_set_deterministic(0)
