@@ -280,15 +280,25 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         f32 = dict(dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            grad_means2D = torch.empty((P, 3), **f32)
-            grad_colors_precomp = torch.empty((P, NUM_CHANNELS), **f32)
-            grad_opacities = torch.empty((P, 1), **f32)
-            grad_means3D = torch.empty((P, 3), **f32)
-            grad_cov3Ds_precomp = torch.empty((P, 6), **f32)
-            grad_conic = torch.empty((P, 2, 2), **f32)
-            grad_conics_precomp = torch.empty((P, 3), **f32)  # [xx, 2 * xy, yy]: written by the library (ghr_backward_ex)
-            grad_scales = torch.empty((P, 3), **f32)
-            grad_rotations = torch.empty((P, 4), **f32)
+            # the nine gradient tensors as views of ONE allocation (each part 256-B aligned like a tensor of its own): eight
+            # allocator calls less on the host's way to the gradient walk's launch -- on a slow host they are what leaves the GPU
+            # idle between the forward pass's last kernel and the backward pass's first (profiles/r06f)
+            widths = (3, NUM_CHANNELS, 1, 3, 6, 4, 3, 3, 4)
+            offs, tot = [], 0
+            for w_ in widths:
+                offs.append(tot)
+                tot += (P * w_ + 63) // 64 * 64
+            flat = torch.empty((max(tot, 1),), **f32)
+            part = lambda i, shape: flat[offs[i]:offs[i] + P * widths[i]].view(shape)
+            grad_means2D = part(0, (P, 3))
+            grad_colors_precomp = part(1, (P, NUM_CHANNELS))
+            grad_opacities = part(2, (P, 1))
+            grad_means3D = part(3, (P, 3))
+            grad_cov3Ds_precomp = part(4, (P, 6))
+            grad_conic = part(5, (P, 2, 2))
+            grad_conics_precomp = part(6, (P, 3))  # [xx, 2 * xy, yy]: written by the library (ghr_backward_ex)
+            grad_scales = part(7, (P, 3))
+            grad_rotations = part(8, (P, 4))
             scratch = getattr(ctx, "scratch", None)  # one line per instance; zeroed by the forward pass if it made it
             if scratch is None:
                 scratch = torch.empty((max(int(num_rendered), 1), _lib.GRAD_STRIDE), **f32)
