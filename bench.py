@@ -23,6 +23,7 @@ Further blocks of the same line (N = 1 unless noted), each named for what it mea
   config4_shard       : BASELINE configs[3]'s per-GPU shard -- 4 views per GPU per step, same model (every N)
   config5_2M          : BASELINE configs[4]'s model (2M strand Gaussians), one view per step: step time, K8 time and fraction
   dropin_trainable_camera_step : the configs[2] step with camera parameters that require grad (the reference's default run)
+  strand_stage        : one iteration of the strand stage (render_hair, 3.07 M Gaussians), fused vs generic projection
   op_only             : SURVEY 8(d)(i), the rasterizer op ALONE (GaussianRasterizer autograd op, mode A), cfg2
                         (BASELINE configs[1], 100k blobs) and cfg3 (500k strands): Gaussians / (t_fwd + t_bwd), and the
                         whole backward (K8 + per-Gaussian epilogue) against B_bwd = 140 P + 132 R + 48 N + 8 T
@@ -82,6 +83,7 @@ def main():
     ap.add_argument("--no-op-only", action="store_true")
     ap.add_argument("--no-2m", action="store_true", help="skip the config5_2M block (BASELINE configs[4]'s model, N = 1)")
     ap.add_argument("--no-camera-block", action="store_true", help="skip the dropin_trainable_camera_step block (N = 1)")
+    ap.add_argument("--no-strand-block", action="store_true", help="skip the strand_stage block (render_hair at the reference's size, N = 1)")
     args = ap.parse_args()
 
     # `--gpus N` without a launcher: become the launcher (one process per GPU, ranks over RCCL), never a silent 1-rank run
@@ -508,6 +510,60 @@ def main():
                                               "side work outside the hot path (cameras.py is out of scope, DESIGN.md 8)"}
         out["dropin_trainable_camera_step"] = blk
         del mC, poolC
+        torch.cuda.empty_cache()
+
+    # ---- the strand stage (src/train_strands.py:98-160; reference size: 30 000 strands x 99 segments + the frozen head): one
+    # iteration = rebuild the strand Gaussians, render_hair (two fused segments of one rasterizer state), the strand-stage loss,
+    # backward to the strand parameters, Adam -- fused against the generic PyTorch projection path, N = 1
+    if world == 1 and not args.no_strand_block and args.workload == "cfg3":
+        from gaussianhaircut_amd.gaussian_renderer import render_hair
+        from gaussianhaircut_amd.scene.gaussian_model_strands import GaussianModelStrands
+        from gaussianhaircut_amd.trainer import strand_training_step
+        from types import SimpleNamespace
+        torch.cuda.empty_cache()
+        S, n_seg, n_head = 30_000, 99, 100_000
+        head = syn.make_model(spec, dev)
+        with torch.no_grad():
+            head._label[:n_head] = -4.0
+            head._label[n_head:] = 4.0
+        head.precompute_head()
+        g = torch.Generator().manual_seed(9)
+        unit = torch.nn.functional.normalize
+        origins = unit(torch.randn(S, 1, 3, generator=g), dim=-1)
+        dirs = torch.randn(S, n_seg, 3, generator=g) * 0.003 + unit(torch.randn(S, 1, 3, generator=g), dim=-1) * 0.01
+        feats = torch.randn(S * n_seg, 16, 3, generator=g) * 0.1
+        hair = GaussianModelStrands(3).create_from_strands(origins.to(dev), dirs.to(dev), feats.to(dev))
+        hcam = pool[0]
+        sopt = OptimizationParams()
+        sopt.lambda_dorient, sopt.lambda_dmask = 0.1, 0.1  # run.sh:177
+        fusedp, genericp = SimpleNamespace(debug=False, fused_projection=True), SimpleNamespace(debug=False, fused_projection=False)
+        saved_gt = (hcam.original_image, hcam.original_mask, hcam.original_orient_angle, hcam.original_orient_conf)
+        with torch.no_grad():
+            hair.initialize_gaussians_hair()
+            hp_ = render_hair(hcam, head, hair, fusedp, bg)
+            hcam.original_image, hcam.original_mask = hp_["render"].clamp(0, 1).detach(), hp_["mask"].clamp(0, 1).detach()
+            hcam.original_orient_angle = hp_["orient_angle"].detach()
+            hcam.original_orient_conf = torch.ones_like(hp_["orient_conf"]).detach()
+            hair._dirs.mul_(1.02)  # (train towards the unperturbed strands)
+        hair.training_setup(sopt)
+
+        def strand_ms(pipe_, n_warm, n_it):
+            for i in range(n_warm + n_it):
+                if i == n_warm:
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                strand_training_step(head, hair, [hcam], bg, sopt, i + 1, pipe=pipe_)
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / n_it
+        f_ms = strand_ms(fusedp, 4, 12)
+        g_ms = strand_ms(genericp, 1, 3)
+        out["strand_stage"] = {"workload": "train_strands.py iteration shape: %d strands x %d segments + %d frozen head Gaussians = %d "
+                                           "Gaussians, 1 view %dx%d: initialize_gaussians_hair + render_hair + strand-stage loss + "
+                                           "backward + Adam" % (S, n_seg, n_head, S * n_seg + n_head, spec.W, spec.H),
+                               "ms_per_iteration_fused": round(f_ms, 3), "ms_per_iteration_generic_projection": round(g_ms, 2),
+                               "generic_over_fused": round(g_ms / f_ms, 1)}
+        (hcam.original_image, hcam.original_mask, hcam.original_orient_angle, hcam.original_orient_conf) = saved_gt
+        del head, hair
         torch.cuda.empty_cache()
 
     if rank == 0 and world == 1:

@@ -8,7 +8,7 @@ TAG=${1:-r06}
 P=$PWD/gpurun_out/profiles; mkdir -p $P; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 R=$PWD
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > /dev/null 2>&1; timeout 600 python bench.py --steps 20 --warmup 5 > $P/${TAG}_bench.json 2> $P/${TAG}_bench.err; echo "bench rc=$?"
-B="python $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-op-only --no-2m --no-camera-block --streams 1 --shard-views 0"
+B="python $R/bench.py --steps 16 --warmup 16 --no-cpu-baseline --no-op-only --no-2m --no-camera-block --no-strand-block --streams 1 --shard-views 0"
 ( cd /tmp && rm -rf /tmp/prof_kt && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o kt -- $B ) > $P/${TAG}_kt.log 2>&1; echo "kt rc=$?"
 python - <<PY
 import csv, glob
