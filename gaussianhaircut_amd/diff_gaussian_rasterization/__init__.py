@@ -92,7 +92,34 @@ def _view_args(rs, P, means3D, colors, opacities, scales, rotations, cov3D, coni
     return a
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on_device(dev):
+    """``with torch.cuda.device(dev)`` that costs nothing when ``dev`` is the current device already (one process per GPU: always;
+    the guard's set / restore pair was ~10 us of Python per use, four uses per view)."""
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
+
+
 def _stream():
+    """The current HIP stream of the current device as a void*.  Through the raw accessor where this PyTorch has it: the
+    public route builds a Stream object and resolves the device index in Python every time, ~10 us a call, several calls per
+    view (tools/host_profile.py)."""
+    if _RAW_STREAM is not None:
+        return ctypes.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -211,7 +238,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise RuntimeError("colors_precomp must have dimensions (num_points, %d)" % NUM_CHANNELS)
 
         mode_b = conic_c is None or conic_c.numel() == 0
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             gbytes, ibytes = _lib.forward_sizes(P, W, H, mode_b)
@@ -279,7 +306,7 @@ class _RasterizeGaussians(torch.autograd.Function):
                                          dtype=torch.float32, device=means3D.device)
         dev = means3D.device
         f32 = dict(dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             # the nine gradient tensors as views of ONE allocation (each part 256-B aligned like a tensor of its own): eight
             # allocator calls less on the host's way to the gradient walk's launch -- on a slow host they are what leaves the GPU
             # idle between the forward pass's last kernel and the backward pass's first (profiles/r06f)
@@ -384,7 +411,7 @@ class GaussianRasterizer(nn.Module):
                 raise RuntimeError("gaussianhaircut_amd: markVisible needs a tensor on a ROCm device")
             pos = _dev_f32(positions, "positions")
             P = pos.size(0)
-            with torch.cuda.device(pos.device):
+            with _on_device(pos.device):
                 present = torch.zeros((P,), dtype=torch.bool, device=pos.device)
                 if P:
                     _lib.check(_lib.lib().ghr_mark_visible(_stream(), P, _ptr(pos),

@@ -9,7 +9,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .diff_gaussian_rasterization import _ptr, _stream
+from .diff_gaussian_rasterization import _on_device, _ptr, _stream
 
 
 def _off(t: torch.Tensor, plane: int, n: int):
@@ -40,7 +40,7 @@ def gt_ssim_stats(gt_image, gt_mask, mask_colours=True):
     assert gt_image.is_cuda, "fused loss has no CPU path"
     _, H, W = gt_image.shape
     gi, gm = _f32c(gt_image), _f32c(gt_mask)
-    with torch.cuda.device(gi.device):
+    with _on_device(gi.device):
         out = torch.empty((2, 3, H, W), dtype=torch.float32, device=gi.device)
         a = _args(W, H, None, None, None, None, gi, gm, None, None, (0.0, 0.0, 0.0, 0.0), not mask_colours)
         _lib.check(_lib.lib().ghr_loss_gt_stats(_stream(), ctypes.byref(a), _ptr(out)))
@@ -64,7 +64,7 @@ class _Stage1LossPacked(torch.autograd.Function):
         gt_angle_c = _f32c(gt_angle) if orient else None
         gt_oconf_c = _f32c(gt_oconf) if orient else None
         dev = renders.device
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
             sums = torch.empty(_lib.loss_sums_floats(W, H), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -86,7 +86,7 @@ class _Stage1LossPacked(torch.autograd.Function):
         _, H, W = r.shape
         n = H * W
         dev = r.device
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             d = torch.empty_like(r)
             gl = _f32c(grad_loss)
             a = _args(W, H, _off(r, 0, n), _off(r, 3, n), _off(r, 5, n), _off(r, 8, n), gt_image, gt_mask, gt_angle,
@@ -105,7 +105,7 @@ class _PhotometricLoss(torch.autograd.Function):
         image_c, mask_c = _f32c(image), _f32c(mask)
         gt_image_c, gt_mask_c = _f32c(gt_image), _f32c(gt_mask)
         dev = image.device
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             maps = torch.empty((9, H, W), dtype=torch.float32, device=dev)
             sums = torch.empty(_lib.loss_sums_floats(W, H), dtype=torch.float32, device=dev)
             loss = torch.empty((), dtype=torch.float32, device=dev)
@@ -122,7 +122,7 @@ class _PhotometricLoss(torch.autograd.Function):
         image, mask, gt_image, gt_mask, maps, sums = ctx.saved_tensors
         _, H, W = image.shape
         dev = image.device
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             d_image = torch.empty_like(image)
             d_mask = torch.empty_like(mask)
             gl = _f32c(grad_loss)

@@ -14,7 +14,7 @@ import torch
 
 from .. import _lib
 from . import _tan_half
-from ..diff_gaussian_rasterization import LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
+from ..diff_gaussian_rasterization import _on_device, LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
 
 RECYCLE_IMG_WS = os.environ.get("GHR_RECYCLE_IMG_WS", "1") != "0"  # see _ImgLease
 
@@ -87,7 +87,7 @@ class _RenderModelFused(torch.autograd.Function):
         campos, bg = campos.detach().float().contiguous(), cfg["bg"].float().contiguous()
         fov = (fovx.detach().float().contiguous(), fovy.detach().float().contiguous()) if fovx is not None else None
         ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in cam_in]
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             gbytes, ibytes = _lib.forward_sizes(P, W, H, False)
@@ -150,7 +150,7 @@ class _RenderModelFused(torch.autograd.Function):
         direct = sink is not None and P > 0 and all(
             isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous()
             and t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.leaves)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             d_m2d = torch.empty((P, 3), **f32)
             if direct:
                 # accumulate into the optimizer's flat gradient buffer: no per-parameter AccumulateGrad kernels
@@ -359,7 +359,7 @@ class _RenderHairFused(torch.autograd.Function):
         ctx.cam_meta = [(t.shape, t.dtype) if t is not None else None for t in (view, proj, campos, fovx, fovy)]
         cam_t = [t.detach().float().contiguous() for t in (view, proj, campos, cfg["bg"])]
         cam_t.append((fovx.detach().float().contiguous(), fovy.detach().float().contiguous()) if fovx is not None else None)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
             radii_ws = torch.empty((rows,), dtype=torch.int32, device=dev)
             m2d_ws = torch.empty((rows, 3), dtype=torch.float32, device=dev)
@@ -417,7 +417,7 @@ class _RenderHairFused(torch.autograd.Function):
         W, H = cfg["W"], cfg["H"]
         if grad_color is None:
             grad_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             d_m2d_ws = torch.zeros((rows, 3), **f32)   # head rows keep 0: the head is frozen
             d_xyz, d_sc = torch.empty((n_hair, 3), **f32), torch.empty((n_hair, 3), **f32)
             d_rot, d_dir = torch.empty((n_hair, 4), **f32), torch.empty((n_hair, 3), **f32)

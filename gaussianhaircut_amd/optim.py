@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib
-from .diff_gaussian_rasterization import _ptr, _stream
+from .diff_gaussian_rasterization import _on_device, _ptr, _stream
 
 
 def _zero_grad_mode(zero_grad):
@@ -342,12 +342,19 @@ class FusedAdam:
         f["m"], self.exp_avg = self.exp_avg, f["m"]
         f["v"], self.exp_avg_sq = self.exp_avg_sq, f["v"]
         f["parity"] = 1 - f["parity"]  # (the finish kernel cleared the other word: clean for the next fused step)
-        off = 0
-        for g in self.param_groups:
-            p = g["params"][0]
-            k = p.numel()
-            p.data = self.flat_param[off:off + k].view(p.shape)
-            off += k
+        # the parameters' views into the two buffers are made once per pair of buffers, not once per step
+        views = f.setdefault("views", {})
+        mine = views.get(self.flat_param.data_ptr())
+        if mine is None:
+            mine, off = [], 0
+            for g in self.param_groups:
+                p = g["params"][0]
+                k = p.numel()
+                mine.append(self.flat_param[off:off + k].view(p.shape))
+                off += k
+            views[self.flat_param.data_ptr()] = mine
+        for g, v in zip(self.param_groups, mine):
+            g["params"][0].data = v
         self._direct_backwards = 0
         self._acc_event = None
         self._skip_next = 0
@@ -371,7 +378,7 @@ class FusedAdam:
         self._direct_backwards = 0
         self._acc_event = None
         skip, self._skip_next = self._skip_next, 0
-        with torch.cuda.device(self.flat_param.device):
+        with _on_device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_adam_step(_stream(), self.flat_param.numel(), _ptr(self.flat_param),
                                                 _ptr(self.flat_grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq),
                                                 _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
@@ -487,7 +494,7 @@ class FusedAdam:
             flag_work.wait()
         n = self.flat_param.numel()
         gathers = []
-        with torch.cuda.device(self.flat_param.device):
+        with _on_device(self.flat_param.device):
             for i, (a, b, how) in enumerate(plan):
                 if works[i] is not None:
                     w, view, packed = works[i]
