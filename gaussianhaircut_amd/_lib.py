@@ -83,6 +83,7 @@ class ViewArgs(ctypes.Structure):
         ("cov3D_precomp", ctypes.c_void_p), ("conic_precomp", ctypes.c_void_p), ("viewmatrix", ctypes.c_void_p),
         ("projmatrix", ctypes.c_void_p), ("scale_modifier", ctypes.c_float), ("tan_fovx", ctypes.c_float),
         ("tan_fovy", ctypes.c_float), ("prefiltered", ctypes.c_int32), ("debug", ctypes.c_int32),
+        ("img_ws_recycled", ctypes.c_int32),
     ]
 
 

@@ -244,7 +244,15 @@ int ghr_forward_stage1(void* stream, const ghr_view_args* a, void* geom_ws, void
     carve_geom(align_base(geom_ws), (size_t)a->P, mode_b, &g);
     carve_img(align_base(img_ws), (size_t)a->W * a->H, (size_t)T, &im);
 
-    GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
+    // (a recycled workspace -- ghr_view_args.img_ws_recycled -- has its counters at zero already: k_tile_sort left them there)
+    if (!a->img_ws_recycled) GHR_HIP(hipMemsetAsync(im.tile_count, 0, sizeof(uint32_t) * 2 * (size_t)T, s));
+    else if (a->debug) {
+        std::vector<uint32_t> h(2 * (size_t)T);
+        GHR_HIP(hipMemcpyAsync(h.data(), im.tile_count, sizeof(uint32_t) * h.size(), hipMemcpyDeviceToHost, s));
+        GHR_HIP(hipStreamSynchronize(s));
+        for (uint32_t v : h)
+            if (v != 0) return fail(GHR_E_INVALID, "ghr_view_args.img_ws_recycled is set but the workspace's per-tile counters are not zero");
+    }
     ghr::PreArgs pa;
     pa.P = a->P; pa.W = a->W; pa.H = a->H; pa.gx = gx; pa.gy = gy;
     pa.means3D = a->means3D; pa.colors = a->colors; pa.opacities = a->opacities;

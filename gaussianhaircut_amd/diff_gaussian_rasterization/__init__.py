@@ -123,6 +123,44 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _ImgLease:
+    """The image workspace of one fused forward pass, recycled between passes of the same size on the same stream.
+
+    Stage 1 counts instances per tile into the workspace's counters and needs them at zero: for a fresh buffer that is a
+    ~5-us zero-fill launch in front of every view.  A workspace that has been through a whole forward pass has its counters
+    back at zero (``k_tile_scan`` turns the counts into append cursors starting at 0, stage 2's tile sort resets them), so a
+    pass that gets such a buffer says so (``ghr_model_args.img_ws_recycled`` / ``ghr_view_args.img_ws_recycled``) and the launch is dropped.  The lease lives
+    in the autograd node: the buffer goes back to the pool when the graph is freed (after backward, or when the outputs
+    go out of scope; a retained graph keeps it), and only if stage 1 AND stage 2 actually ran their kernels on it (a pass
+    over an empty model launches nothing: its buffer is never pooled).  Pools are per (device, W, H, stream): the next
+    pass on the same stream is ordered behind everything that still reads the buffer."""
+    _pools = {}
+    MAX_POOLED = 4
+
+    def __init__(self, dev, nbytes, W, H):
+        # keyed on the image size, not the byte count: the carve offsets of the counters depend on W x H (two sizes may round
+        # to the same number of bytes), and include/ghr.h only allows recycling between passes of the SAME W x H
+        self.key = (dev.index, int(W), int(H), torch.cuda.current_stream(dev).cuda_stream)
+        pool = _ImgLease._pools.get(self.key)
+        if pool:
+            self.buf, self.recycled = pool.pop(), True
+        else:
+            self.buf, self.recycled = torch.empty((nbytes,), dtype=torch.uint8, device=dev), False
+        self.complete = False  # set once stage 2 has been launched on this buffer
+
+    def __del__(self):
+        try:
+            if self.complete and self.buf is not None:
+                pool = _ImgLease._pools.setdefault(self.key, [])
+                if len(pool) < _ImgLease.MAX_POOLED:
+                    pool.append(self.buf)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+RECYCLE_IMG_WS = os.environ.get("GHR_RECYCLE_IMG_WS", "1") != "0"  # the rasterizer op's own use of _ImgLease
+
+
 _R_HINT = {}    # device index -> binning capacity guess: 1.25 x the largest instance count of the last 64 frames
 _R_RECENT = {}  # device index -> those counts (cameras of a training set differ; a guess from the last frame alone would
                 # overflow every time a wide view follows a narrow one)
@@ -243,9 +281,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             radii = torch.empty((P,), dtype=torch.int32, device=dev)
             gbytes, ibytes = _lib.forward_sizes(P, W, H, mode_b)
             geomBuffer = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
-            imgBuffer = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
+            # (the image workspace of a completed earlier pass of the same size on this stream has its per-tile counters back
+            # at zero: stage 1 then skips its zero-fill launch -- _ImgLease; round 6: the op as well as the fused path)
+            lease = _ImgLease(dev, ibytes, W, H) if (RECYCLE_IMG_WS and P > 0 and not rs.debug) else None
+            imgBuffer = lease.buf if lease is not None else torch.empty((ibytes,), dtype=torch.uint8, device=dev)
             args = _view_args(rs, P, means3D_c, colors_c, opac_c, scales_c, rot_c, cov3D_c, conic_c, bg_c, view_c,
                               proj_c)
+            args.img_ws_recycled = int(lease is not None and lease.recycled)
             cpu_args = None
             if rs.debug:  # __init__.py:88-95: snapshot the inputs before they can be corrupted
                 cpu_args = cpu_deep_copy_tuple((rs.bg, means3D, means2D_precomp, colors_precomp, opacities, scales,
@@ -270,6 +312,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                     return b, sc
 
                 num_rendered, bin_cap, (binningBuffer, ctx.scratch) = run_stage2(dev, P, pinned, launch)
+                if lease is not None:
+                    lease.complete = True   # stage 1 and stage 2 ran their kernels on it: the counters end at zero again
+                    ctx.img_lease = lease   # (back to the pool when the graph is freed: the backward pass reads the workspace)
             except Exception as ex:
                 if cpu_args is not None:
                     torch.save(cpu_args, "snapshot_fw.dump")

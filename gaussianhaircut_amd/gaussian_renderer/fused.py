@@ -14,44 +14,9 @@ import torch
 
 from .. import _lib
 from . import _tan_half
-from ..diff_gaussian_rasterization import _on_device, LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
+from ..diff_gaussian_rasterization import _ImgLease, _on_device, LAST_STATS, NUM_CHANNELS, _pinned, _ptr, _stream, run_stage2
 
 RECYCLE_IMG_WS = os.environ.get("GHR_RECYCLE_IMG_WS", "1") != "0"  # see _ImgLease
-
-
-class _ImgLease:
-    """The image workspace of one fused forward pass, recycled between passes of the same size on the same stream.
-
-    Stage 1 counts instances per tile into the workspace's counters and needs them at zero: for a fresh buffer that is a
-    ~5-us zero-fill launch in front of every view.  A workspace that has been through a whole forward pass has its counters
-    back at zero (``k_tile_scan`` turns the counts into append cursors starting at 0, stage 2's tile sort resets them), so a
-    pass that gets such a buffer says so (``ghr_model_args.img_ws_recycled``) and the launch is dropped.  The lease lives
-    in the autograd node: the buffer goes back to the pool when the graph is freed (after backward, or when the outputs
-    go out of scope; a retained graph keeps it), and only if stage 1 AND stage 2 actually ran their kernels on it (a pass
-    over an empty model launches nothing: its buffer is never pooled).  Pools are per (device, W, H, stream): the next
-    pass on the same stream is ordered behind everything that still reads the buffer."""
-    _pools = {}
-    MAX_POOLED = 4
-
-    def __init__(self, dev, nbytes, W, H):
-        # keyed on the image size, not the byte count: the carve offsets of the counters depend on W x H (two sizes may round
-        # to the same number of bytes), and include/ghr.h only allows recycling between passes of the SAME W x H
-        self.key = (dev.index, int(W), int(H), torch.cuda.current_stream(dev).cuda_stream)
-        pool = _ImgLease._pools.get(self.key)
-        if pool:
-            self.buf, self.recycled = pool.pop(), True
-        else:
-            self.buf, self.recycled = torch.empty((nbytes,), dtype=torch.uint8, device=dev), False
-        self.complete = False  # set once stage 2 has been launched on this buffer
-
-    def __del__(self):
-        try:
-            if self.complete and self.buf is not None:
-                pool = _ImgLease._pools.setdefault(self.key, [])
-                if len(pool) < _ImgLease.MAX_POOLED:
-                    pool.append(self.buf)
-        except Exception:  # interpreter shutdown
-            pass
 
 
 def _model_args(P, W, H, sh_degree, K, tensors, view, proj, campos, bg, scale_modifier, tanfovx, tanfovy, eps, debug,

@@ -70,6 +70,10 @@ typedef struct ghr_view_args {
     float tan_fovx, tan_fovy;
     int32_t prefiltered;        /* accepted for API parity; culling is always silent */
     int32_t debug;              /* != 0: synchronise + check after the call */
+    /* ABI 17 (ghr_forward_stage1 only).  != 0: img_ws is the image workspace of an EARLIER forward pass of the same W x H whose
+     * stage 1 AND stage 2 ran (P > 0), ordered before this call, untouched since: its per-tile counters are back at zero and
+     * stage 1 skips its zero-fill (the promise of ghr_model_args.img_ws_recycled, for the rasterizer op itself).  0: any buffer. */
+    int32_t img_ws_recycled;
 } ghr_view_args;
 
 const char* ghr_last_error(void);

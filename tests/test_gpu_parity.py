@@ -438,3 +438,39 @@ def test_fallback_gradient_walk_vs_oracle(oracle_mod, dev, monkeypatch):
         dL = syn.grad_image(spec, 101).numpy() * (spec.H * spec.W)
         dL[:, st_o.fragile.astype(bool)] = 0.0
         hp.assert_grads_close(run.backward(torch.from_numpy(dL)), hp.oracle_backward(oracle_mod, st_o, ri, dL, mode))
+
+
+@pytest.mark.gpu
+def test_rasterizer_op_recycles_its_image_workspace_and_changes_nothing():
+    """Round 6: the GaussianRasterizer op takes its image workspace from the pool of completed passes of the same size and
+    stream (ghr_view_args.img_ws_recycled: stage 1 then skips the per-tile counters' zero-fill launch).  Three calls in a row
+    with different inputs against the same calls with recycling off: image, radii and instance count bit for bit."""
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["cfg1"]
+    outs = {}
+    for recycle in (False, True):
+        dgr.RECYCLE_IMG_WS = recycle
+        dgr._ImgLease._pools.clear()
+        got, seen = [], []
+        for camname in ("front", "ring5", "ring13roll"):
+            ri = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in syn.raster_inputs(spec, "cpu", cam=camname).items()}
+            rs = dgr.GaussianRasterizationSettings(image_height=spec.H, image_width=spec.W, tanfovx=ri["tanfovx"],
+                                                   tanfovy=ri["tanfovy"], bg=ri["bg"], scale_modifier=1.0,
+                                                   viewmatrix=ri["viewmatrix"], projmatrix=ri["projmatrix"], sh_degree=3,
+                                                   campos=ri["campos"], prefiltered=True, debug=False)
+            leaves = {k: ri[k].clone().requires_grad_(True) for k in ("means3D", "means2D", "colors", "opacities", "conic")}
+            color, radii = dgr.GaussianRasterizer(rs)(means3D=leaves["means3D"], means2D=leaves["means2D"], shs=None,
+                                                      colors_precomp=leaves["colors"], opacities=leaves["opacities"],
+                                                      cov3D_precomp=ri["cov3D"], conic_precomp=leaves["conic"])
+            color.sum().backward()
+            got.append((color.detach().clone(), radii.clone(), dgr.LAST_STATS["num_rendered"]))
+            del color, radii, leaves   # the graph is gone: the lease returns its buffer
+            seen.append(sum(len(v) for v in dgr._ImgLease._pools.values()))
+        outs[recycle] = got
+        # a completed pass's workspace goes back to the pool (and the next pass takes it: never more than one there)
+        assert seen == ([1, 1, 1] if recycle else [0, 0, 0]), seen
+        torch.cuda.synchronize()
+    dgr.RECYCLE_IMG_WS = True
+    for a, b in zip(outs[False], outs[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and a[2] == b[2]
