@@ -144,11 +144,12 @@ def is_free_gaussian_model(pc) -> bool:
     (``src/scene/gaussian_model.py:30-43,107-141``): the eight raw tensors, exp / sigmoid / normalize activations (checked by
     identity: the reference binds ``torch.exp`` etc. in ``setup_functions``), SH degree counters -- this package's own class,
     the reference's, or any class that keeps that interface.  Strand models (their per-Gaussian quantities are DERIVED from
-    strand parameters: ``_dir``, ``initialize_gaussians_hair``) are not."""
+    strand parameters: ``_dirs``, ``initialize_gaussians_hair``) are not."""
     from ..scene.gaussian_model import GaussianModel
     if type(pc) is GaussianModel:
         return True
-    if hasattr(pc, "_dir") or hasattr(pc, "initialize_gaussians_hair"):
+    # (not `_dir`: the reference's free-Gaussian get_direction_2d caches an attribute of that name, gaussian_model.py:389)
+    if hasattr(pc, "initialize_gaussians_hair") or hasattr(pc, "_dirs"):
         return False
     if not all(isinstance(getattr(pc, f, None), torch.Tensor) for f in _RAW_FIELDS):
         return False

@@ -227,9 +227,8 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
         sink.zero()
         sink.state_dev[1:2].zero_()
         sink._acc_event = None
-        # (densify_stats: the overflowed views' backward passes left the statistics alone -- k_project_bwd checks the count
-        # on the device -- but the OTHER views of the step have been counted: only those that overflowed are ... all of them are
-        # recomputed below, so the statistics of the views that did not overflow would be counted twice)
+        # (densify_stats: an overflowed view's backward pass left the statistics alone -- k_project_bwd checks the count on the
+        # device -- but the step's OTHER views have been counted, and ALL views are recomputed below: theirs would be counted twice)
         if densify_stats and len(cams) > 1 and not all(overflow):
             raise RuntimeError("training_step(densify_stats=True): a capacity guess overflowed in a multi-view step; the "
                                "statistics of its other views cannot be rolled back -- use defer_counts=False for the first "
