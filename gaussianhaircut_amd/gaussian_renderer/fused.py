@@ -367,6 +367,9 @@ class _RenderHairFused(torch.autograd.Function):
         ctx.set_materialize_grads(False)  # no zeros_like(radii) fill for the integer output on every backward
         ctx.fov = cam_t[4]
         ctx.head = head  # (the frozen head contributes to the camera's gradients)
+        # the SH feature LEAVES themselves: backward may assign straight into their .grad when those alias an optimizer's flat
+        # gradient buffer that is known to hold zeros (cfg["grad_sink"]) -- 142 of the strand model's 145 floats per Gaussian
+        ctx.sh_leaves = (f_dc, f_rest)
         ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t[:4],
                               radii_ws, geom, img, binb)
         return color, radii
@@ -387,7 +390,18 @@ class _RenderHairFused(torch.autograd.Function):
             d_xyz, d_sc = torch.empty((n_hair, 3), **f32), torch.empty((n_hair, 3), **f32)
             d_rot, d_dir = torch.empty((n_hair, 4), **f32), torch.empty((n_hair, 3), **f32)
             d_conf = torch.empty((n_hair, 1), **f32)
-            d_fdc, d_frest = torch.empty((n_hair, 1, 3), **f32), torch.empty((n_hair, K - 1, 3), **f32)
+            # Direct gradients for the SH features (round 6): as leaves of a FusedAdam whose gradient buffer is known to be zero
+            # (the step's first backward) they are ASSIGNED in place by the kernel -- autograd's AccumulateGrad otherwise reads
+            # the 535 MB of zeros, adds and writes them back (0.43 ms per iteration at the reference's 30 000 strands) -- and the
+            # kernel raises the optimizer's non-finite flag for everything it stores (the scan over 145 floats per Gaussian goes)
+            sink = cfg.get("grad_sink")
+            direct = (sink is not None and n_hair > 0 and all(
+                isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous() and
+                t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.sh_leaves) and sink.take_known_zero())
+            if direct:
+                d_fdc, d_frest = ctx.sh_leaves[0].grad, ctx.sh_leaves[1].grad
+            else:
+                d_fdc, d_frest = torch.empty((n_hair, 1, 3), **f32), torch.empty((n_hair, K - 1, 3), **f32)
             scratch = getattr(ctx, "scratch", None)  # made (and zeroed) by the forward pass when it knew of a backward
             if scratch is None:
                 scratch = torch.empty((max(int(R), 1), _lib.GRAD_STRIDE), **f32)
@@ -417,9 +431,13 @@ class _RenderHairFused(torch.autograd.Function):
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
                                                         _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
-                                                        _ptr(d_dir), 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
+                                                        _ptr(d_dir), 0, sink.nan_flag_ptr() if direct else None,
+                                                        scratch.shape[0], _ptr(binb), ctx.cap))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
             d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:13], dev, ctx.fov) if want_cam else (None,) * 5
+        if direct:
+            sink.note_direct_backward()
+            return (d_xyz, d_sc, d_rot, d_dir, d_conf, None, None, d_m2d) + d_cam + (None, None)
         return (d_xyz, d_sc, d_rot, d_dir, d_conf, d_fdc, d_frest, d_m2d) + d_cam + (None, None)
 
 
@@ -452,6 +470,10 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
                sh_degree=int(pc_hair.active_sh_degree), scale_modifier=float(scaling_modifier), tanfovx=tfx, tanfovy=tfy,
                eps_head=float(getattr(pc, "conic_eps", 1e-12)), eps_hair=float(getattr(pc_hair, "conic_eps", 1e-7)),
                debug=bool(debug), grad_enabled=torch.is_grad_enabled())
+    from ..optim import FusedAdam
+    opt = getattr(pc_hair, "optimizer", None)
+    if isinstance(opt, FusedAdam) and opt.direct_grads and torch.is_grad_enabled():
+        cfg["grad_sink"] = opt
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
                                             pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
                                             screenspace_points, view, proj, campos, fovx, fovy, head, cfg)

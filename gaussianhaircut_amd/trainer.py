@@ -375,7 +375,18 @@ def strand_training_step(gaussians, gaussians_hair, cams: List, background, opt,
             gaussians_hair.initialize_gaussians_hair()  # a fresh graph for the next view
     from .optim import FusedAdam
     if isinstance(gaussians_hair.optimizer, FusedAdam):
-        gaussians_hair.optimizer.step(zero_grad=True)  # device-side NaN guard over every strand parameter
+        o = gaussians_hair.optimizer
+        if o._direct_backwards == V and V > 0:
+            # every view's SH-feature gradients (142 of the 145 floats per Gaussian) were assigned by the fused backward, which
+            # raised the optimizer's flag for any non-finite value it stored; what reached the remaining parameters through
+            # autograd (strand directions, confidence: 3 floats per Gaussian) is checked here -- no scan over everything
+            small = [p.grad for g in o.param_groups if g["name"] not in ("f_dc", "f_rest") for p in g["params"] if p.grad is not None]
+            if small:
+                bad = torch.stack([(~torch.isfinite(t)).any() for t in small]).any()
+                o.state_dev[1:2] |= bad.to(torch.int32)
+            o.step(zero_grad=True, nan_scan=False)
+        else:
+            o.step(zero_grad=True)  # device-side NaN guard: a scan over every strand parameter's gradient
     else:
         ps = [gaussians_hair._dirs, gaussians_hair._features_dc, gaussians_hair._features_rest]
         if any(p.grad is not None and bool(p.grad.isnan().any()) for p in ps):  # train_strands.py:151-155

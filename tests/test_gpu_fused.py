@@ -496,6 +496,67 @@ def test_strand_training_step_learns_on_gpu():
         assert (hair._dirs.detach() - d0).abs().max() > 0
 
 
+def test_strand_stage_direct_sh_gradients_match_autograd_accumulation():
+    """Round 6: the fused render_hair backward ASSIGNS the SH-feature gradients of a strand model whose optimizer is a
+    FusedAdam straight into its (known-zero) gradient buffer and raises the optimizer's non-finite flag itself;
+    strand_training_step then steps without the scan over every parameter.  Same parameters after three iterations as with
+    autograd's accumulation (direct_grads off), a second view of the same step accumulates the classic way, and a NaN that
+    reaches the strand directions only through autograd still skips the update."""
+    from gaussianhaircut_amd.gaussian_renderer import render_hair
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import strand_training_step
+    from tests.test_api_cpu import _hair_scene
+    dev = torch.device("cuda:0")
+    opt = OptimizationParams()
+    opt.lambda_dorient, opt.lambda_dmask = 0.1, 0.1
+    bg = syn.background(dev)
+    from gaussianhaircut_amd import _lib as ghr_lib
+    lib = ghr_lib.lib()
+    lib.ghr_set_deterministic(1)
+    try:
+        res = {}
+        for direct in (True, False):
+            spec, head, hair, cam = _hair_scene(dev)
+            _, _, gt_hair, _ = _hair_scene(dev)
+            with torch.no_grad():
+                gt_hair._features_dc.add_(0.4)
+                gt_hair._dirs.mul_(1.1)
+                gt_hair.initialize_gaussians_hair()
+                pkg = render_hair(cam, head, gt_hair, FUSED, bg)
+                cam.original_image = pkg["render"].clamp(0, 1).detach()
+                cam.original_mask = pkg["mask"].clamp(0, 1).detach()
+                cam.original_orient_angle = pkg["orient_angle"].detach()
+                cam.original_orient_conf = torch.ones_like(pkg["orient_conf"]).detach()
+            hair.training_setup(opt, fused=True)
+            o = hair.optimizer
+            o.direct_grads = direct
+            seen = []
+            step0 = o.step
+            o.step = lambda *a, **k: (seen.append(k.get("nan_scan", True)), step0(*a, **k))[1]
+            for i in range(3):
+                strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=FUSED)
+            import copy
+            strand_training_step(head, hair, [cam, copy.copy(cam)], bg, opt, 4, pipe=FUSED)  # the second view accumulates
+            assert seen == ([False] * 3 + [True] if direct else [True] * 4), seen
+            res[direct] = [p.detach().clone() for p in (hair._dirs, hair._features_dc, hair._features_rest, hair._orient_conf)]
+            if direct:
+                # a NaN that only autograd carries (into the strand directions): flag raised by the small check, update skipped
+                before = [t.clone() for t in res[direct]]
+                h = hair._dirs.register_hook(lambda g: torch.full_like(g, float("nan")))
+                strand_training_step(head, hair, [cam], bg, opt, 5, pipe=FUSED)
+                h.remove()
+                assert seen[-1] is False
+                for a, b in zip(before, (hair._dirs, hair._features_dc, hair._features_rest, hair._orient_conf)):
+                    assert torch.equal(a, b.detach())
+                assert float(o.flat_grad.abs().max()) == 0.0
+                strand_training_step(head, hair, [cam], bg, opt, 6, pipe=FUSED)  # and the next one goes through again
+                assert not torch.equal(before[1], hair._features_dc.detach())
+        for a, b in zip(res[True], res[False]):
+            assert torch.equal(a, b)
+    finally:
+        lib.ghr_set_deterministic(0)
+
+
 def test_first_direct_backward_assigns_only_into_a_buffer_known_to_be_zero():
     """FusedAdam.take_known_zero: the step's first direct backward may assign instead of accumulate (k_project_bwd then
     skips reading the zeros) -- but only while the gradient buffer is KNOWN to be zero; anything PyTorch wrote into a
