@@ -24,8 +24,9 @@ NUM_CHANNELS = 10
 GRAD_STRIDE = 16
 CAM_PARTIALS = 32  # GHR_CAM_PARTIALS: rows of the camera-gradient partial table
 CAM_GRADS = 37     # GHR_CAM_GRADS: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2]
+STRAND_MAX_SEG = 2048  # GHR_STRAND_MAX_SEG: longest strand ghr_strand_build takes
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 17  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 18  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -138,8 +139,8 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
-           "ghr_adam_step_range"]
+           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
+           "ghr_adam_step_range", "ghr_adam_nan_scan"]
 
 _lib = None
 
@@ -191,6 +192,9 @@ def lib() -> ctypes.CDLL:
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_camera_slots.argtypes = [i32]
     L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.ghr_adam_nan_scan.argtypes = [vp, vp, ctypes.c_int64, vp]
+    L.ghr_strand_build.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp, vp]
+    L.ghr_strand_build_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

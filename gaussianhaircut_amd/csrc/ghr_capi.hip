@@ -22,6 +22,7 @@
 #include "ghr_render_bwd2.h"
 #include "ghr_render_bwd3.h"
 #include "ghr_render_fwd.h"
+#include "ghr_strands.h"
 
 namespace {
 
@@ -625,6 +626,40 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
     return finish(s, 0);
 }
 
+static_assert(GHR_STRAND_MAX_SEG * 24 <= 48 * 1024, "one strand's two LDS rows");
+
+int ghr_strand_build(void* stream, int32_t S, int32_t n_seg, const float* origins, const float* dirs, float scale, float* xyz,
+                     float* rotation, float* scaling)
+{
+    if (S < 0 || n_seg < 0 || n_seg > GHR_STRAND_MAX_SEG) return fail(GHR_E_INVALID, "ghr_strand_build: bad strand shape");
+    if (S == 0 || n_seg == 0) return GHR_OK;
+    if ((int64_t)S * n_seg > (int64_t)INT32_MAX / 4) return fail(GHR_E_INVALID, "ghr_strand_build: too many segments");
+    if (!origins || !dirs || !xyz || !rotation || !scaling) return fail(GHR_E_INVALID, "ghr_strand_build: NULL buffer");
+    hipStream_t s = (hipStream_t)stream;
+    ghr::StrandArgs a;
+    a.S = S; a.n_seg = n_seg; a.spb = ghr::strands_per_block(n_seg);
+    a.origins = origins; a.dirs = dirs; a.scale = scale; a.xyz = xyz; a.rot = rotation; a.scaling = scaling;
+    const size_t lds = (size_t)2 * a.spb * n_seg * 3 * sizeof(float);
+    hipLaunchKernelGGL(ghr::k_strand_build, dim3((S + a.spb - 1) / a.spb), dim3(GHR_STRAND_BLOCK), lds, s, a);
+    return finish(s, 0);
+}
+
+int ghr_strand_build_backward(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
+                              const float* d_rotation, const float* d_scaling, float* d_dirs)
+{
+    if (S < 0 || n_seg < 0 || n_seg > GHR_STRAND_MAX_SEG) return fail(GHR_E_INVALID, "ghr_strand_build_backward: bad strand shape");
+    if (S == 0 || n_seg == 0) return GHR_OK;
+    if ((int64_t)S * n_seg > (int64_t)INT32_MAX / 4) return fail(GHR_E_INVALID, "ghr_strand_build_backward: too many segments");
+    if (!dirs || !d_dirs) return fail(GHR_E_INVALID, "ghr_strand_build_backward: NULL buffer");
+    hipStream_t s = (hipStream_t)stream;
+    ghr::StrandBwdArgs a;
+    a.S = S; a.n_seg = n_seg; a.spb = ghr::strands_per_block(n_seg);
+    a.dirs = dirs; a.d_xyz = d_xyz; a.d_rot = d_rotation; a.d_scaling = d_scaling; a.d_dirs = d_dirs;
+    const size_t lds = (size_t)2 * a.spb * n_seg * 3 * sizeof(float);
+    hipLaunchKernelGGL(ghr::k_strand_build_bwd, dim3((S + a.spb - 1) / a.spb), dim3(GHR_STRAND_BLOCK), lds, s, a);
+    return finish(s, 0);
+}
+
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
@@ -841,6 +876,16 @@ int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* 
 {
     return ghr_adam_step_range(stream, n, 0, n, p, g, m, v, state, n_groups, group_end_host, lr_host, beta1, beta2,
                                eps, nan_guard, zero_grad, 1, skip_mask);
+}
+
+int ghr_adam_nan_scan(void* stream, const float* g, int64_t count, int32_t* state)
+{
+    if (count < 0 || !state || (count > 0 && !g)) return fail(GHR_E_INVALID, "ghr_adam_nan_scan: bad args");
+    if (count == 0) return GHR_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)count, state);
+    return finish(s, 0);
 }
 
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

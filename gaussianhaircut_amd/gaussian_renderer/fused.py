@@ -368,7 +368,7 @@ class _RenderHairFused(torch.autograd.Function):
         ctx.fov = cam_t[4]
         ctx.head = head  # (the frozen head contributes to the camera's gradients)
         # the SH feature LEAVES themselves: backward may assign straight into their .grad when those alias an optimizer's flat
-        # gradient buffer that is known to hold zeros (cfg["grad_sink"]) -- 142 of the strand model's 145 floats per Gaussian
+        # gradient buffer that is known to hold zeros (cfg["grad_sink"]) -- 48 of the strand model's 52 floats per Gaussian
         ctx.sh_leaves = (f_dc, f_rest)
         ctx.save_for_backward(*[hair[k] for k in ("xyz", "scaling", "rotation", "dir", "conf", "fdc", "frest")], *cam_t[:4],
                               radii_ws, geom, img, binb)
@@ -392,8 +392,8 @@ class _RenderHairFused(torch.autograd.Function):
             d_conf = torch.empty((n_hair, 1), **f32)
             # Direct gradients for the SH features (round 6): as leaves of a FusedAdam whose gradient buffer is known to be zero
             # (the step's first backward) they are ASSIGNED in place by the kernel -- autograd's AccumulateGrad otherwise reads
-            # the 535 MB of zeros, adds and writes them back (0.43 ms per iteration at the reference's 30 000 strands) -- and the
-            # kernel raises the optimizer's non-finite flag for everything it stores (the scan over 145 floats per Gaussian goes)
+            # the 570 MB of zeros, adds and writes them back (0.43 ms per iteration at the reference's 30 000 strands) -- and the
+            # kernel raises the optimizer's non-finite flag for everything it stores (the scan over 52 floats per Gaussian goes)
             sink = cfg.get("grad_sink")
             direct = (sink is not None and n_hair > 0 and all(
                 isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous() and

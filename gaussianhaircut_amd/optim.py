@@ -260,6 +260,18 @@ class FusedAdam:
             return self.fused_flag_ptr()
         return ctypes.c_void_p(self.state_dev.data_ptr() + 4)
 
+    def scan_groups_for_nan(self, names):
+        """Raise the device NaN flag if a gradient of the named groups holds a NaN (``ghr_adam_nan_scan``): the part of the
+        scanning guard a step needs whose other groups' gradients were stored by the fused backward (which keeps the flag)."""
+        off = 0
+        with _on_device(self.flat_param.device):
+            for g in self.param_groups:
+                k = sum(p.numel() for p in g["params"])
+                if g["name"] in names and k:
+                    _lib.check(_lib.lib().ghr_adam_nan_scan(_stream(), ctypes.c_void_p(self.flat_grad.data_ptr() + 4 * off), k,
+                                                            _ptr(self.state_dev)))
+                off += k
+
     def note_direct_backward(self):
         self._direct_backwards += 1
         self._zero_version = None

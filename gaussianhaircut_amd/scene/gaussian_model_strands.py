@@ -6,12 +6,57 @@ un-vendored NeuralHaircut checkpoints and are out of scope; stra
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .. import _lib
 from ..utils.general_utils import build_scaling_rotation, parallel_transport
 from .gaussian_model import GaussianModel
+
+
+FUSED_STRAND_BUILD = os.environ.get("GHR_FUSED_STRAND_BUILD", "1") != "0"
+
+
+def _strand_build_applies(origins, dirs) -> bool:
+    return (dirs.is_cuda and dirs.dtype == torch.float32 and dirs.dim() == 3 and dirs.shape[-1] == 3 and
+            0 < dirs.shape[1] <= _lib.STRAND_MAX_SEG and dirs.is_contiguous() and origins.dtype == torch.float32 and
+            origins.device == dirs.device and tuple(origins.shape) == (dirs.shape[0], 1, 3) and not origins.requires_grad)
+
+
+class _StrandBuild(torch.autograd.Function):
+    """(origins [S,1,3], dirs [S,n_seg,3]) -> xyz [P,3], rotation [P,4], scaling [P,3] of the P = S n_seg segment Gaussians."""
+
+    @staticmethod
+    def forward(ctx, origins, dirs, scale):
+        from ..diff_gaussian_rasterization import _on_device, _ptr, _stream
+        S, n_seg = int(dirs.shape[0]), int(dirs.shape[1])
+        P = S * n_seg
+        f32 = dict(dtype=torch.float32, device=dirs.device)
+        origins = origins.contiguous()
+        xyz, rot, scaling = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 3), **f32)
+        with _on_device(dirs.device):
+            _lib.check(_lib.lib().ghr_strand_build(_stream(), S, n_seg, _ptr(origins), _ptr(dirs), float(scale), _ptr(xyz),
+                                                   _ptr(rot), _ptr(scaling)))
+        ctx.save_for_backward(dirs)
+        return xyz, rot, scaling
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_xyz, d_rot, d_scaling):
+        from ..diff_gaussian_rasterization import _on_device, _ptr, _stream
+        (dirs,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        S, n_seg = int(dirs.shape[0]), int(dirs.shape[1])
+        cots = [None if g is None else g.contiguous().float() for g in (d_xyz, d_rot, d_scaling)]
+        d_dirs = torch.empty_like(dirs)
+        with _on_device(dirs.device):
+            _lib.check(_lib.lib().ghr_strand_build_backward(_stream(), S, n_seg, _ptr(dirs), *[None if g is None else _ptr(g)
+                                                                                               for g in cots], _ptr(d_dirs)))
+        return None, d_dirs, None
 
 
 class GaussianModelStrands(GaussianModel):
@@ -36,7 +81,28 @@ class GaussianModelStrands(GaussianModel):
         return self
 
     def initialize_gaussians_hair(self):
-        """gaussian_model_strands.py:435-452."""
+        """gaussian_model_strands.py:435-452.  On a ROCm device one HIP kernel each way (``ghr_strand_build``, csrc/ghr_strands.h)
+        instead of ~55 PyTorch kernels per iteration; the polyline points ``_pts`` are then made on first use."""
+        self._dir = self._dirs.reshape(-1, 3)
+        if FUSED_STRAND_BUILD and _strand_build_applies(self.pts_origins, self._dirs):
+            self.__dict__.pop("_pts_value", None)
+            self._xyz, self._rotation, self._scaling = _StrandBuild.apply(self.pts_origins, self._dirs, float(self.scale))
+            return
+        self._initialize_gaussians_hair_torch()
+
+    @property
+    def _pts(self):
+        """[S, n_seg + 1, 3] polyline points (gaussian_model_strands.py:436)."""
+        if "_pts_value" not in self.__dict__:
+            self._pts_value = self.pts_origins + torch.cat([torch.zeros_like(self.pts_origins),
+                                                            torch.cumsum(self._dirs, dim=1)], dim=1)
+        return self._pts_value
+
+    @_pts.setter
+    def _pts(self, value):
+        self._pts_value = value
+
+    def _initialize_gaussians_hair_torch(self):
         pts = self.pts_origins + torch.cat([torch.zeros_like(self.pts_origins), torch.cumsum(self._dirs, dim=1)], dim=1)
         self._pts = pts
         self._dir = self._dirs.reshape(-1, 3)

@@ -377,13 +377,10 @@ def strand_training_step(gaussians, gaussians_hair, cams: List, background, opt,
     if isinstance(gaussians_hair.optimizer, FusedAdam):
         o = gaussians_hair.optimizer
         if o._direct_backwards == V and V > 0:
-            # every view's SH-feature gradients (142 of the 145 floats per Gaussian) were assigned by the fused backward, which
+            # every view's SH-feature gradients (48 of the 52 floats per Gaussian) were assigned by the fused backward, which
             # raised the optimizer's flag for any non-finite value it stored; what reached the remaining parameters through
-            # autograd (strand directions, confidence: 3 floats per Gaussian) is checked here -- no scan over everything
-            small = [p.grad for g in o.param_groups if g["name"] not in ("f_dc", "f_rest") for p in g["params"] if p.grad is not None]
-            if small:
-                bad = torch.stack([(~torch.isfinite(t)).any() for t in small]).any()
-                o.state_dev[1:2] |= bad.to(torch.int32)
+            # autograd (strand directions, confidence: 4 of the 52 floats per Gaussian) is scanned here -- not everything
+            o.scan_groups_for_nan([g["name"] for g in o.param_groups if g["name"] not in ("f_dc", "f_rest")])
             o.step(zero_grad=True, nan_scan=False)
         else:
             o.step(zero_grad=True)  # device-side NaN guard: a scan over every strand parameter's gradient

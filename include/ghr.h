@@ -38,13 +38,14 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 17
+#define GHR_ABI_VERSION 18
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
 #define GHR_GRAD_STRIDE 16  /* floats per Gaussian-tile instance in the gradient scratch of ghr_backward */
 #define GHR_CAM_PARTIALS 32 /* rows of the camera-gradient partial table (ghr_model_args.cam_partial) */
 #define GHR_CAM_GRADS 37    /* floats ghr_camera_grad_fold writes: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2] */
+#define GHR_STRAND_MAX_SEG 2048 /* longest strand (segments) ghr_strand_build takes */
 
 #define GHR_OK 0
 #define GHR_E_INVALID (-1)  /* bad argument (NULL where required, C != GHR_NUM_CHANNELS, ...) */
@@ -298,6 +299,22 @@ int32_t ghr_camera_slots(int32_t P);
 int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam, const float* fovx_dev,
                          const float* fovy_dev);
 
+/* ABI 18.  Strand polylines -> one Gaussian per segment: initialize_gaussians_hair (src/scene/gaussian_model_strands.py:435-452,
+ * the same lines in gaussian_model_latent_strands.py), run at the top of every strand-stage iteration
+ * (src/train_strands.py:98-104).  origins [S,3] strand roots, dirs [S,n_seg,3] segment vectors (n_seg <= GHR_STRAND_MAX_SEG);
+ * outputs, row s n_seg + k = segment k of strand s:
+ *   xyz [S n_seg,3]      mid-points of pts = origins + cat(0, cumsum(dirs)) -- the sum taken in list order: bit-identical to torch
+ *   rotation [S n_seg,4] parallel_transport((1,0,0), dir) = (1 + b.x, 0, -b.z, b.y), b = dir / max(|dir|, 1e-12)
+ *                        (src/utils/general_utils.py:150-160; not normalised)
+ *   scaling [S n_seg,3]  (|dir| / 2, scale, scale)
+ * The direction rows themselves (self._dir) are a view of dirs and need no kernel. */
+int ghr_strand_build(void* stream, int32_t S, int32_t n_seg, const float* origins, const float* dirs, float scale, float* xyz,
+                     float* rotation, float* scaling);
+/* Its backward: cotangents of the three outputs (each may be NULL = zero; of d_scaling only column 0 is read) -> d_dirs
+ * [S,n_seg,3], ASSIGNED.  d xyz_k / d dirs_j = 1 for j < k and 1/2 for j == k (a suffix sum along the strand). */
+int ghr_strand_build_backward(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
+                              const float* d_rotation, const float* d_scaling, float* d_dirs);
+
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
                        float* d_means2D, float* d_xyz, float* d_log_scales, float* d_rotations,
@@ -355,6 +372,11 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, c
  * nan_guard == 1 scans the gradients first, nan_guard == 2 trusts state[1] as maintained by the gradient producer
  * (ghr_model_backward's nan_flag).
  * zero_grad != 0: the gradient buffer is zeroed for the next step. */
+/* ABI 18.  state[1] |= any(isnan(g[0 .. count))): the scan of nan_guard == 1 over a part of the gradients, for a step whose other
+ * gradients came from a producer that keeps the flag itself (the strand stage, src/train_strands.py:151-155: the SH features'
+ * gradients are assigned by the fused render_hair backward, those of the strand directions arrive through autograd); follow
+ * it with ghr_adam_step(nan_guard = 2). */
+int ghr_adam_nan_scan(void* stream, const float* g, int64_t count, int32_t* state);
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,
                   int32_t nan_guard, int32_t zero_grad, uint32_t skip_mask);

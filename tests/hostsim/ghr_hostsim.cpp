@@ -21,6 +21,7 @@
 #include "../../gaussianhaircut_amd/csrc/ghr_project.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_render_bwd.h"
 #include "../../gaussianhaircut_amd/csrc/ghr_render_fwd.h"
+#include "../../gaussianhaircut_amd/csrc/ghr_strands.h"
 
 namespace {
 struct Sim {
@@ -385,6 +386,39 @@ void ghrsim_adam(int n, float* p, const float* g, float* m, float* v, float lr, 
     const float bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step));
     const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2), b2 = (float)beta2;
     for (int i = 0; i < n; i++) ghr::adam_update(p[i], g[i], m[i], v[i], (float)((double)lr / bias1), w1, b2, w2, eps, bias2_sqrt);
+}
+
+// ---- strand polylines -> segment Gaussians (csrc/ghr_strands.h), with k_strand_build's slab / thread decomposition ---------
+void ghrsim_strand_build(int S, int n_seg, const float* origins, const float* dirs, float scale, float* xyz, float* rot,
+                         float* scaling)
+{
+    const int row = 3 * n_seg;
+    for (int s = 0; s < S; s++) {
+        for (int c = 0; c < 3; c++)
+            ghr::strand_scan_fwd(dirs + (size_t)s * row + c, xyz + (size_t)s * row + c, origins[3 * s + c], n_seg);
+        for (int k = 0; k < n_seg; k++) {
+            const size_t i = (size_t)s * n_seg + k;
+            ghr::strand_row_fwd(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], scale, rot + 4 * i, scaling + 3 * i);
+        }
+    }
+}
+
+void ghrsim_strand_build_backward(int S, int n_seg, const float* dirs, const float* d_xyz, const float* d_rot,
+                                  const float* d_scaling, float* d_dirs)
+{
+    const int row = 3 * n_seg;
+    std::vector<float> acc((size_t)row, 0.f);
+    for (int s = 0; s < S; s++) {
+        if (d_xyz != nullptr)
+            for (int c = 0; c < 3; c++) ghr::strand_scan_bwd(d_xyz + (size_t)s * row + c, acc.data() + c, n_seg);
+        for (int k = 0; k < n_seg; k++) {
+            const size_t i = (size_t)s * n_seg + k;
+            float o[3];
+            ghr::strand_row_bwd(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], d_rot != nullptr ? d_rot + 4 * i : nullptr,
+                                d_scaling != nullptr ? d_scaling[3 * i] : 0.f, o);
+            for (int c = 0; c < 3; c++) d_dirs[3 * i + c] = o[c] + (d_xyz != nullptr ? acc[3 * k + c] : 0.f);
+        }
+    }
 }
 
 }  // extern "C"
