@@ -395,6 +395,10 @@ class _RenderHairFused(torch.autograd.Function):
             # the 570 MB of zeros, adds and writes them back (0.43 ms per iteration at the reference's 30 000 strands) -- and the
             # kernel raises the optimizer's non-finite flag for everything it stores (the scan over 52 floats per Gaussian goes)
             sink = cfg.get("grad_sink")
+            if sink is not None:
+                # (a buffer left undefined by step(zero_grad="defer") is only made whole by a backward that assigns EVERY
+                # group; this one assigns two of four: the others would be accumulated into garbage)
+                sink.resolve_deferred()
             direct = (sink is not None and n_hair > 0 and all(
                 isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous() and
                 t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.sh_leaves) and sink.take_known_zero())

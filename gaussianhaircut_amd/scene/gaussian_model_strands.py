@@ -41,6 +41,7 @@ class _StrandBuild(torch.autograd.Function):
             _lib.check(_lib.lib().ghr_strand_build(_stream(), S, n_seg, _ptr(origins), _ptr(dirs), float(scale), _ptr(xyz),
                                                    _ptr(rot), _ptr(scaling)))
         ctx.save_for_backward(dirs)
+        ctx.set_materialize_grads(False)  # an output nobody differentiated arrives as None (the kernel takes NULL), not as zeros
         return xyz, rot, scaling
 
     @staticmethod
@@ -48,7 +49,7 @@ class _StrandBuild(torch.autograd.Function):
     def backward(ctx, d_xyz, d_rot, d_scaling):
         from ..diff_gaussian_rasterization import _on_device, _ptr, _stream
         (dirs,) = ctx.saved_tensors
-        if not ctx.needs_input_grad[1]:
+        if not ctx.needs_input_grad[1] or (d_xyz is None and d_rot is None and d_scaling is None):
             return None, None, None
         S, n_seg = int(dirs.shape[0]), int(dirs.shape[1])
         cots = [None if g is None else g.contiguous().float() for g in (d_xyz, d_rot, d_scaling)]
