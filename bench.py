@@ -417,6 +417,36 @@ def main():
                 L = (b - a) // Gw
                 dist.all_gather_into_tensor(o.flat_param[a:b], o.flat_param[a + rk * L: a + (rk + 1) * L])
         rs_ms, ag_ms = (timed(rs), timed(ag)) if dist.is_initialized() else (None, None)
+        # the headline step's message since ABI 19: SH gradients as per-view dL/d(rgb) tables (all-gather) + the other 13
+        # floats per Gaussian summed; what the step does with V views per rank when V x ranks <= FACTORED_SH_MAX_VIEWS
+        from gaussianhaircut_amd import optim as _optim
+        fact = None
+        if _optim.FACTORED_SH_REDUCE and o.can_factor_views() and V * Gw <= _optim.FACTORED_SH_MAX_VIEWS:
+            def factored_step(shard_):
+                o.begin_factored_views(V)
+                o._views["next"] = V  # (as if V backward passes had filled the slots: zero tables, like the zero gradients)
+                try:
+                    o.step_chunked(chunks=4, zero_grad=True, reduce=True, shard=shard_)
+                finally:
+                    o.end_factored_views()
+            o.begin_factored_views(V)
+            buf = o._views["buf"]
+            o.end_factored_views()
+            gathered = torch.empty((Gw * buf.shape[0], buf.shape[1]), dtype=torch.float32, device=dev)
+            gather_ms = timed(lambda: dist.all_gather_into_tensor(gathered, buf)) if dist.is_initialized() else None
+            o.begin_factored_views(V)
+            rebuild_ms = timed(lambda: o._rebuild_sh_from_views(gathered))
+            plan_f = o._reduce_plan(4)
+            o.end_factored_views()
+            fact = {"views_per_rank": V, "views_gathered": V * Gw,
+                    "all_gather_bytes_per_rank": int(4 * buf.numel()),
+                    "summed_floats_per_gaussian": round(sum(b - a for a, b, how in plan_f if how == "sum") / max(int(model.get_xyz.shape[0]), 1), 2),
+                    "all_gather_ms": round(gather_ms, 4) if gather_ms is not None else None,
+                    "rebuild_ms": round(rebuild_ms, 4),
+                    "step_chunked_replicated_ms": round(timed(lambda: factored_step(False)), 4),
+                    "step_chunked_sharded_ms": round(timed(lambda: factored_step(True)), 4),
+                    "bytes_on_wire_per_gpu_ring": int((Gw - 1) / Gw * Gw * 4 * buf.numel() +
+                                                      2 * (Gw - 1) / Gw * 4 * sum(b - a for a, b, how in plan_f if how == "sum"))}
         o.sync_moments()
         for dst, src in zip((o.flat_param, o.exp_avg, o.exp_avg_sq, o.state_dev), snap):
             dst.copy_(src)
@@ -445,6 +475,7 @@ def main():
                          "allocated in full): each rank updates 1 / N of every reduced range",
             "message_bytes": int(4 * msg), "bytes_on_wire_per_gpu_ring": int(2 * (G - 1) / G * 4 * msg),
             "bus_bandwidth_GBps": round(2 * (G - 1) / G * 4 * msg / (ar_ms * 1e-3) / 1e9, 2) if ar_ms > 0 and G > 1 else None,
+            "factored_sh_message": fact,
             "backend": dist.get_backend() if dist.is_initialized() else None, "replicas_identical": replicas_identical,
             "note": "HIP events on the rank's stream, median of 7, max over ranks; no curve is computed here (the driver "
                     "divides the per-N lines)"}

@@ -26,7 +26,7 @@ CAM_PARTIALS = 32  # GHR_CAM_PARTIALS: rows of the camera-gradient partial table
 CAM_GRADS = 37     # GHR_CAM_GRADS: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2]
 STRAND_MAX_SEG = 2048  # GHR_STRAND_MAX_SEG: longest strand ghr_strand_build takes
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 18  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 19  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -102,7 +102,8 @@ class ModelArgs(ctypes.Structure):
                [("fovx_dev", ctypes.c_void_p), ("fovy_dev", ctypes.c_void_p), ("cam_partial", ctypes.c_void_p), ("cam_slot0", ctypes.c_int32),
                 ("cam_slots", ctypes.c_int32), ("cam_only", ctypes.c_int32), ("detach_means2D", ctypes.c_int32),
                 ("dens_grad_accum", ctypes.c_void_p), ("dens_denom", ctypes.c_void_p), ("dens_max_radii2D", ctypes.c_void_p),
-                ("dens_img_ws", ctypes.c_void_p), ("overflow_raises_flag", ctypes.c_int32), ("adam_fuse", ctypes.c_void_p)]
+                ("dens_img_ws", ctypes.c_void_p), ("overflow_raises_flag", ctypes.c_int32), ("adam_fuse", ctypes.c_void_p),
+                ("d_rgb", ctypes.c_void_p)]
 
 
 class AdamFuse(ctypes.Structure):
@@ -139,7 +140,7 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
+           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_sh_grad_from_views", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range", "ghr_adam_nan_scan"]
 
 _lib = None
@@ -192,6 +193,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_camera_slots.argtypes = [i32]
     L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp, vp, vp]
+    L.ghr_sh_grad_from_views.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, ctypes.c_int64, vp, vp]
     L.ghr_adam_nan_scan.argtypes = [vp, vp, ctypes.c_int64, vp]
     L.ghr_strand_build.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp, vp]
     L.ghr_strand_build_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]

@@ -530,9 +530,13 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: the segment's camera columns exceed cam_slots");
     if (!radii || !geom_ws)
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
-    if (!cam_only && (!d_means2D || !d_xyz || !d_log_scales || !d_rotations || !d_features_dc ||
-        (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) || (a.sh_coeffs > 1 && !d_features_rest)))
+    const bool factored_sh = m->d_rgb != nullptr;  // ABI 19: the SH gradients leave as d_rgb, their own buffers may be NULL
+    if (!cam_only && (!d_means2D || !d_xyz || !d_log_scales || !d_rotations || (!factored_sh && !d_features_dc) ||
+        (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) ||
+        (!factored_sh && a.sh_coeffs > 1 && !d_features_rest)))
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
+    if (factored_sh && (cam_only || m->adam_fuse))
+        return fail(GHR_E_INVALID, "ghr_model_backward_segment: d_rgb with cam_only / adam_fuse");
     Geom g;
     carve_geom(align_base(geom_ws), (size_t)rows_total, false, &g);
     a.radii = const_cast<int*>(radii);
@@ -545,6 +549,7 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     mg.ginst = grad_scratch; mg.ginst_rows = grad_rows ? (grad_rows < R ? grad_rows : R) : R; mg.d_means2D = d_means2D; mg.d_xyz = d_xyz; mg.d_log_scales = d_log_scales;
     mg.d_rotations = d_rotations; mg.d_opacity_logit = d_opacity_logit; mg.d_label_logit = d_label_logit;
     mg.d_orient_conf_log = d_orient_conf_log; mg.d_features_dc = d_features_dc; mg.d_features_rest = d_features_rest;
+    mg.d_rgb = m->d_rgb;
     mg.d_dir3d = a.mode == 1 ? d_dir3d : nullptr;
     mg.accumulate = accumulate; mg.nan_flag = cam_only ? nullptr : nan_flag;
     mg.cam_partial = m->cam_partial; mg.cam_slot0 = (uint32_t)m->cam_slot0; mg.cam_stride = (uint32_t)m->cam_slots;
@@ -623,6 +628,25 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
     }
     hipLaunchKernelGGL(ghr::k_cam_fold, dim3(GHR_CAM_PARTIALS), dim3(GHR_CAM_FOLD_BLOCK), 0, s, cam_partial, (uint32_t)cam_slots,
                        d_cam, fovx_dev, fovy_dev);
+    return finish(s, 0);
+}
+
+int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
+                           const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
+                           float* d_features_rest)
+{
+    if (P < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || view_stride < 0 ||
+        !(sh_coeffs == 1 || sh_coeffs == 4 || sh_coeffs == 9 || sh_coeffs == 16) || (sh_degree + 1) * (sh_degree + 1) > sh_coeffs)
+        return fail(GHR_E_INVALID, "ghr_sh_grad_from_views: bad sizes");
+    if (P == 0) return GHR_OK;
+    if (!xyz || !d_features_dc || (sh_coeffs > 1 && !d_features_rest) || (n_views > 0 && (!campos || !g_views)) ||
+        (n_views > 1 && view_stride < 3 * (int64_t)P))
+        return fail(GHR_E_INVALID, "ghr_sh_grad_from_views: NULL buffer / overlapping views");
+    hipStream_t s = (hipStream_t)stream;
+    ghr::ShViewsArgs a;
+    a.P = P; a.sh_degree = sh_degree; a.sh_coeffs = sh_coeffs; a.n_views = n_views; a.xyz = xyz; a.campos = campos;
+    a.g = g_views; a.view_stride = (size_t)view_stride; a.d_dc = d_features_dc; a.d_rest = d_features_rest;
+    hipLaunchKernelGGL(ghr::k_sh_grad_from_views, dim3((P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), dim3(GHR_PBW_BLOCK), 0, s, a);
     return finish(s, 0);
 }
 

@@ -79,6 +79,8 @@ struct ModelGrads {
     float* d_orient_conf_log; // [P]
     float* d_features_dc;     // [P,1,3]
     float* d_features_rest;   // [P,K-1,3]
+    float* d_rgb;             // [P,3] optional, ASSIGNED: dL/d(rgb) behind the colour clamp -- the view's SH gradients in factored
+                              // form (d sh[k][c] = basis_k(dir) d_rgb[c]: k_sh_grad_from_views); d_features_dc / _rest may then be NULL
     float* d_dir3d;           // [P,3] mode 1 (NULL: not wanted).  In mode 1 d_log_scales / d_opacity_logit / d_label_logit /
                               // d_orient_conf_log receive the gradients of the LINEAR quantities and may be NULL
     int accumulate;           // != 0: parameter gradients are ADDED to the output buffers (d_means2D is always assigned)
@@ -475,6 +477,7 @@ struct ProjBwdOut {
     float dxyz[3], dls[3], dq[4];
     float dlo, dll, dlc;
     float ddc[3], ddir[3];
+    float grgb[3];  // dL/d(rgb) behind the colour clamp: every SH gradient of the view is basis_k x grgb (ModelGrads.d_rgb)
 };
 
 // CAM: also the Gaussian's camera cotangents into cam[GHR_CAM_PARTIALS] (layout above; campos by project_bwd_sh).
@@ -699,6 +702,7 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
                     acc += basis[k] * cf[k];
                 }
                 const float gch = (acc + 0.5f >= 0.0f) ? gc[ch] : 0.f;  // clamp_min backward: grad where x >= min
+                o.grgb[ch] = gch;
                 ddc[ch] = basis[0] * gch;
 #pragma unroll
                 for (int k = 0; k < GHR_SH_MAX; k++) {
@@ -718,6 +722,7 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
         }
     } else {
         for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
+        o.grgb[0] = o.grgb[1] = o.grgb[2] = 0.f;
         if (CAM) cam[26] = cam[27] = cam[28] = 0.f;
     }
 }
@@ -762,7 +767,7 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
         v[i] = o.dxyz[i];          p[i] = g.d_xyz + 3 * idx + i;
         v[3 + i] = o.dls[i];       p[3 + i] = g.d_log_scales + 3 * idx + i;
         v[13 + i] = o.ddir[i];     p[13 + i] = g.d_dir3d ? g.d_dir3d + 3 * idx + i : nullptr;
-        v[16 + i] = o.ddc[i];      p[16 + i] = g.d_features_dc + 3 * (size_t)idx + i;
+        v[16 + i] = o.ddc[i];      p[16 + i] = g.d_features_dc ? g.d_features_dc + 3 * (size_t)idx + i : nullptr;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) { v[6 + i] = o.dq[i]; p[6 + i] = g.d_rotations + 4 * idx + i; }
@@ -827,6 +832,13 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
             *p[i] = v[i];
             bad |= nonfinite(v[i]);
         }
+    if (g.d_rgb != nullptr) {  // the view's SH gradients in factored form (ASSIGNED: one table per view)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            g.d_rgb[3 * (size_t)idx + i] = o.grgb[i];
+            bad |= nonfinite(o.grgb[i]);
+        }
+    }
     return bad;
 }
 
@@ -1191,7 +1203,7 @@ __device__ __forceinline__ void project_bwd_body(const ModelArgs& a, const Model
         if (row > 0)
             bad |= slab_out_adam<BLK>(g.d_features_rest + (size_t)base * row, a.features_rest + (size_t)base * row, s_rest,
                                       (size_t)nb * row, threadIdx.x, g.accumulate, g.adam, ss[7], b2[7]);
-    } else if (row > 0 && !g.cam_only)
+    } else if (row > 0 && !g.cam_only && g.d_features_rest != nullptr)
         bad |= slab_out<BLK>(g.d_features_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, g.accumulate);
     if (g.overflow_is_bad && g.dens_count != nullptr && *reinterpret_cast<const volatile uint32_t*>(g.dens_count) > g.dens_cap)
         bad = true;
@@ -1247,6 +1259,74 @@ k_project_bwd<true, true>(ModelArgs a, ModelGrads g)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     project_bwd_body<true, true>(a, g);
+#endif
+}
+
+// ---- SH gradients from their per-view factors (round 6: the data-parallel gradient message) ------------------------------------
+// A view's gradient of the SH coefficients of Gaussian i is the outer product basis(dir_i) (x) d_rgb_i (project_bwd_sh): 48
+// floats that are determined by 3 -- the view direction is a function of the camera centre and xyz, which every rank holds.
+// Ranks therefore exchange d_rgb per view (12 B per Gaussian and view, all-gather) instead of summing 192 B per Gaussian
+// (all-reduce), and every rank rebuilds  d sh[k][c] = sum_v basis_k(dir_{v,i}) d_rgb_{v,i}[c]  here, views in list order: the
+// products are the ones project_bwd_sh forms and the sum is taken in the order a single rank accumulating the same views takes
+// it, so the result has that run's bits.  A view in which the Gaussian has no gradient (culled: d_rgb = 0) is skipped -- its
+// direction may not even be defined (a Gaussian at the camera centre).
+GHR_HD void sh_grad_from_views_one(int deg, int K, const float* xyz3, int n_views, const float* campos, const float* g,
+                                   size_t view_stride, size_t idx, float* dc, float* rest)
+{
+    float acc[3 * GHR_SH_MAX];
+#pragma unroll
+    for (int i = 0; i < 3 * GHR_SH_MAX; i++) acc[i] = 0.f;
+    const float mx = xyz3[0], my = xyz3[1], mz = xyz3[2];
+    for (int v = 0; v < n_views; v++) {
+        const float* gv = g + (size_t)v * view_stride + 3 * idx;
+        const float g0 = gv[0], g1 = gv[1], g2 = gv[2];
+        if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // (a NaN compares unequal: it is carried through)
+        const float* cpos = campos + 3 * v;
+        const float dxv = mx - cpos[0], dyv = my - cpos[1], dzv = mz - cpos[2];  // as project_bwd_sh
+        const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
+        const float x = dxv * il, y = dyv * il, z = dzv * il;
+        float basis[GHR_SH_MAX];
+        sh_basis(deg, x, y, z, basis);
+        const float gg[3] = {g0, g1, g2};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+#pragma unroll
+            for (int k = 0; k < GHR_SH_MAX; k++)
+                if (k < K) acc[3 * k + ch] = acc[3 * k + ch] + basis[k] * gg[ch];
+    }
+    dc[0] = acc[0]; dc[1] = acc[1]; dc[2] = acc[2];
+#pragma unroll
+    for (int k = 1; k < GHR_SH_MAX; k++)
+        if (k < K) { rest[3 * (k - 1)] = acc[3 * k]; rest[3 * (k - 1) + 1] = acc[3 * k + 1]; rest[3 * (k - 1) + 2] = acc[3 * k + 2]; }
+}
+
+struct ShViewsArgs {
+    int P, sh_degree, sh_coeffs, n_views;
+    const float* xyz;      // [P,3]
+    const float* campos;   // [n_views,3] (device)
+    const float* g;        // view v: [P,3] at g + v * view_stride
+    size_t view_stride;    // floats
+    float* d_dc;           // [P,1,3] assigned
+    float* d_rest;         // [P,K-1,3] assigned
+};
+
+__global__ void __launch_bounds__(GHR_PBW_BLOCK) k_sh_grad_from_views(ShViewsArgs a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int BLK = GHR_PBW_BLOCK;
+    __shared__ __attribute__((aligned(16))) float s_rest[BLK * GHR_REST_MAX];
+    const int row = 3 * (a.sh_coeffs - 1);
+    const int base = blockIdx.x * BLK;
+    const int nb = min(BLK, a.P - base);
+    const int idx = base + threadIdx.x;
+    if (idx < a.P) {
+        float dc[3];
+        sh_grad_from_views_one(a.sh_degree, a.sh_coeffs, a.xyz + 3 * (size_t)idx, a.n_views, a.campos, a.g, a.view_stride,
+                               (size_t)idx, dc, s_rest + threadIdx.x * row);
+        a.d_dc[3 * (size_t)idx] = dc[0]; a.d_dc[3 * (size_t)idx + 1] = dc[1]; a.d_dc[3 * (size_t)idx + 2] = dc[2];
+    }
+    __syncthreads();
+    if (row > 0) slab_out<BLK>(a.d_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, 0);
 #endif
 }
 

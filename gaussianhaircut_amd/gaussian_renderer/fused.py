@@ -160,6 +160,12 @@ class _RenderModelFused(torch.autograd.Function):
             acc = 1
             if P > 0 and direct and sink.take_known_zero():
                 acc = 0
+            p_fdc, p_frest = _ptr(d_fdc), _ptr(d_frest)
+            if P > 0 and direct and getattr(sink, "_views", None) is not None:
+                # a data-parallel step that sends the SH gradients in factored form (optim.FusedAdam.begin_factored_views):
+                # this view's dL/d(rgb) table instead of 192 B per Gaussian added into the flat gradient
+                m.d_rgb = sink.next_view_slot(campos)
+                p_fdc = p_frest = None
             if P > 0 and direct and sink.concurrent:
                 # this view shares the GPU with its neighbours (trainer.training_step): only the kernel that adds into
                 # the shared gradient buffer is ordered after the previous view's
@@ -169,15 +175,15 @@ class _RenderModelFused(torch.autograd.Function):
                 sink.accumulate_begin(stream)
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
-                                                        _ptr(d_op), _ptr(d_label), _ptr(d_conf), _ptr(d_fdc),
-                                                        _ptr(d_frest), None, acc, sink.nan_flag_ptr(), rows,
+                                                        _ptr(d_op), _ptr(d_label), _ptr(d_conf), p_fdc,
+                                                        p_frest, None, acc, sink.nan_flag_ptr(), rows,
                                                         _ptr(binb), ctx.cap))
                 sink.accumulate_end(stream)
             elif P > 0:
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),
-                                                _ptr(d_fdc), _ptr(d_frest), acc if direct else 0,
+                                                p_fdc, p_frest, acc if direct else 0,
                                                 sink.nan_flag_ptr() if direct else None, prezeroed))
             d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[9:14], dev, ctx.fov) if want_cam else (None,) * 5
         if direct:

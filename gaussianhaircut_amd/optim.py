@@ -9,6 +9,7 @@ Every parameter's storage is re-pointed into one contiguous fp32 buffer (``flat_
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, List
 
 import torch
@@ -32,6 +33,11 @@ def _zero_grad_mode(zero_grad):
 # NOT ZeRO-1's memory saving: both moment buffers stay allocated in full on every rank (488 B per Gaussian against 288 GB of
 # HBM; densification re-lays them as whole tensors), only the slices a rank does not own go stale there -- see sync_moments().
 SHARD_ADAM = True
+# Data-parallel steps of up to this many views in all send the SH gradients in factored form (FusedAdam.begin_factored_views):
+# 12 B per Gaussian and VIEW, all-gathered, instead of 192 B per Gaussian, summed -- on the wire of a ring V (G - 1) / G x 12 B
+# against 2 (G - 1) / G x 192 B per GPU, i.e. a gain below V = 32 views, kept to where it is at least 2x.
+FACTORED_SH_REDUCE = os.environ.get("GHR_FACTORED_SH_REDUCE", "1") != "0"
+FACTORED_SH_MAX_VIEWS = 16
 
 
 class StaleMomentsError(RuntimeError):
@@ -150,6 +156,8 @@ class FusedAdam:
     def zero(self):
         self.flat_grad.zero_()
         self._mark_zero()
+        if self._views is not None:
+            self._views["next"] = 0  # (a step that is recomputed: its views fill the slots again)
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat_grad.zero_()  # grads alias the flat buffer: never dropped
@@ -271,6 +279,71 @@ class FusedAdam:
                     _lib.check(_lib.lib().ghr_adam_nan_scan(_stream(), ctypes.c_void_p(self.flat_grad.data_ptr() + 4 * off), k,
                                                             _ptr(self.state_dev)))
                 off += k
+
+    # ---- SH gradients in factored form (data-parallel steps; include/ghr.h ABI 19, csrc/ghr_project.h k_sh_grad_from_views).
+    # A view's gradient of the 48 SH floats of a Gaussian is basis(dir) (x) d_rgb: the fused backward of every view of the step
+    # leaves its d_rgb table [P,3] (+ the camera centre) in a slot here instead of adding 192 B per Gaussian into the flat
+    # gradient; step_chunked all-gathers the slots of all ranks and every rank rebuilds the f_dc / f_rest gradients from them.
+    _views = None
+
+    def _group_range(self, name):
+        off = 0
+        for g in self.param_groups:
+            k = sum(p.numel() for p in g["params"])
+            if g["name"] == name:
+                return off, off + k, g["params"][0]
+            off += k
+        return None
+
+    def can_factor_views(self) -> bool:
+        dc, rest, xyz = self._group_range("f_dc"), self._group_range("f_rest"), self._group_range("xyz")
+        return (dc is not None and rest is not None and xyz is not None and dc[1] == rest[0] and rest[2].dim() == 3 and
+                rest[2].shape[1] in (3, 8, 15) and xyz[2].dim() == 2 and xyz[2].shape[1] == 3 and
+                dc[2].shape[0] == xyz[2].shape[0] == rest[2].shape[0])
+
+    def begin_factored_views(self, n_local: int):
+        """``n_local`` view slots for this rank's backwards of the coming step (the same number on every rank: the all-gather
+        is of equal parts; a rank with fewer views leaves zero tables)."""
+        P = int(self._group_range("xyz")[2].shape[0])
+        stride = -(-(3 * P + 3) // 4) * 4  # [d_rgb P x 3 | camera centre 3 | pad]: 16-B multiples
+        v = getattr(self, "_views_buf", None)
+        if v is None or v["buf"].shape != (n_local, stride) or v["buf"].device != self.flat_param.device:
+            v = dict(buf=torch.zeros((n_local, stride), dtype=torch.float32, device=self.flat_param.device), P=P,
+                     stride=stride, gathered=None)
+            self._views_buf = v
+        v["next"] = 0
+        self._views = v
+
+    def end_factored_views(self):
+        self._views = None
+
+    def next_view_slot(self, campos: torch.Tensor):
+        """Device pointer of the next free d_rgb table of the step; the view's camera centre goes behind it."""
+        v = self._views
+        i = v["next"]
+        if i >= v["buf"].shape[0]:
+            raise RuntimeError("FusedAdam: more backward passes than view slots in this step (%d)" % v["buf"].shape[0])
+        v["next"] = i + 1
+        v["buf"][i, 3 * v["P"]: 3 * v["P"] + 3].copy_(campos.detach().reshape(3).to(torch.float32))
+        return ctypes.c_void_p(v["buf"].data_ptr() + 4 * i * v["stride"])
+
+    def _rebuild_sh_from_views(self, gathered: torch.Tensor):
+        """flat_grad[f_dc | f_rest] := sum over the gathered views (rank-major, then slot order) -- ghr_sh_grad_from_views."""
+        v = self._views
+        P, stride = v["P"], v["stride"]
+        n_views = gathered.numel() // stride
+        rows = gathered.view(n_views, stride)
+        campos = rows[:, 3 * P: 3 * P + 3].contiguous()
+        (a_dc, _, _), (a_rest, _, p_rest), (a_xyz, _, _) = self._group_range("f_dc"), self._group_range("f_rest"), self._group_range("xyz")
+        K = int(p_rest.shape[1]) + 1
+        act = K - 1 if self.active_rest_coeffs is None else int(self.active_rest_coeffs)
+        deg = {0: 0, 3: 1, 8: 2, 15: 3}[act]
+        base_g, base_p = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
+        with _on_device(self.flat_param.device):
+            _lib.check(_lib.lib().ghr_sh_grad_from_views(
+                _stream(), P, deg, K, ctypes.c_void_p(base_p + 4 * a_xyz), n_views, _ptr(campos), _ptr(rows), stride,
+                ctypes.c_void_p(base_g + 4 * a_dc), ctypes.c_void_p(base_g + 4 * a_rest)))
+        self._views_keep = (campos, gathered)  # (alive until the stream has consumed them: replaced by the next step's)
 
     def note_direct_backward(self):
         self._direct_backwards += 1
@@ -433,7 +506,12 @@ class FusedAdam:
         for g in self.param_groups:
             p = g["params"][0]
             k = p.numel()
-            if g.get("name") == "f_rest" and act is not None and p.dim() == 3 and act < p.shape[1]:
+            if getattr(self, "_views", None) is not None and g.get("name") in ("f_dc", "f_rest"):
+                # not reduced: rebuilt on every rank from the gathered per-view factors (begin_factored_views)
+                flush(off)
+                plan.append((off, off + k, "views"))
+                run_a = off + k
+            elif g.get("name") == "f_rest" and act is not None and p.dim() == 3 and act < p.shape[1]:
                 flush(off)
                 plan.append((off, off + k, "none" if act <= 0 else ("rest", p.shape[0], p.shape[1], int(act))))
                 run_a = off + k
@@ -488,6 +566,17 @@ class FusedAdam:
         else:
             self._sync_before_replicated_update()
         works = [None] * len(plan)
+        views_work, gathered = None, None
+        if self._views is not None:
+            v = self._views
+            if v["next"] < v["buf"].shape[0]:
+                v["buf"][v["next"]:].zero_()  # slots no backward of this rank filled: tables without a gradient
+            if comm:
+                # the per-view d_rgb tables of every rank, rank-major: started first, the f_dc / f_rest ranges wait for it
+                gathered = torch.empty((G * v["buf"].shape[0], v["buf"].shape[1]), dtype=torch.float32, device=v["buf"].device)
+                views_work = dist.all_gather_into_tensor(gathered, v["buf"], async_op=True)
+            else:
+                self._rebuild_sh_from_views(v["buf"])
         if comm:
             flag = self.state_dev[1:2]
             flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
@@ -506,13 +595,22 @@ class FusedAdam:
             flag_work.wait()
         n = self.flat_param.numel()
         gathers = []
+        # The ranges rebuilt from the gathered views go FIRST: the rebuild evaluates the SH basis at the positions the forward
+        # passes saw, i.e. before the xyz range of this very step is updated (and, sharded, before other ranks' updated
+        # slices of it arrive); their gather was also issued first, so the sums of the other ranges travel under their update.
+        order = [i for i, x in enumerate(plan) if x[2] == "views"] + [i for i, x in enumerate(plan) if x[2] != "views"]
         with _on_device(self.flat_param.device):
-            for i, (a, b, how) in enumerate(plan):
+            for pos, i in enumerate(order):
+                a, b, how = plan[i]
                 if works[i] is not None:
                     w, view, packed = works[i]
                     w.wait()  # orders the current stream behind this chunk's collective
                     if view is not None:
                         view.copy_(packed)
+                if how == "views" and views_work is not None:
+                    views_work.wait()
+                    views_work = None
+                    self._rebuild_sh_from_views(gathered)  # both ranges (f_dc, f_rest) in one launch
                 lo, hi = a, b
                 if how == "shard":
                     L = (b - a) // G
@@ -520,7 +618,7 @@ class FusedAdam:
                 _lib.check(_lib.lib().ghr_adam_step_range(
                     _stream(), n, lo, hi - lo, _ptr(self.flat_param), _ptr(self.flat_grad), _ptr(self.exp_avg),
                     _ptr(self.exp_avg_sq), _ptr(self.state_dev), len(self.param_groups), self._ends, lrs,
-                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(i == len(plan) - 1), skip))
+                    self.betas[0], self.betas[1], self.eps, guard, int(zero_grad), int(pos == len(order) - 1), skip))
                 if how == "shard":
                     # (issued behind the kernel above on the current stream; in place: the send slice lies in the receive
                     # buffer at rank * count, the layout the backends' in-place all-gather expects)

@@ -150,7 +150,8 @@ def _generic_densify_stats(gaussians, pkg, pipe):
 
 def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
                   global_views: Optional[int] = None, pipe=PIPE, streams: Optional[int] = None,
-                  defer_counts: Optional[bool] = None, densify_stats: bool = False, fuse_adam: Optional[bool] = None):
+                  defer_counts: Optional[bool] = None, densify_stats: bool = False, fuse_adam: Optional[bool] = None,
+                  views_per_rank: Optional[int] = None):
     """One global gradient step over this rank's views.  Returns the (detached) summed local loss.
 
     ``streams`` (default 2 with the fused path and more than one view): the views of the step are independent given
@@ -173,7 +174,13 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     update from the gradients it holds in registers (``ghr_adam_fuse``): no 244 B of gradient per Gaussian written and read
     back, no separate optimizer pass.  Same parameters, bit for bit, as the separate pass; the NaN rule stays exact (the
     update is undone on the device when the step's flag is up).  After such a step ``p.grad`` still holds what the previous
-    separate pass left there (``zero_grad="defer"`` semantics: undefined) -- pass ``fuse_adam=False`` to log gradient norms."""
+    separate pass left there (``zero_grad="defer"`` semantics: undefined) -- pass ``fuse_adam=False`` to log gradient norms.
+
+    ``views_per_rank`` (more than one rank): the LARGEST number of views any rank holds in this step, the same value on every
+    rank; default ceil(global views / ranks), which is what ``parallel.shard_views`` deals.  Steps of up to
+    ``optim.FACTORED_SH_MAX_VIEWS`` view slots in all send the SH gradients as per-view dL/d(rgb) tables (12 B per Gaussian and
+    view, all-gathered; ``FusedAdam.begin_factored_views``) instead of summing 192 B per Gaussian: every rank opens that many
+    slots, and a rank with more views than slots fails loudly before any collective."""
     from .optim import FusedAdam
     gaussians.update_learning_rate(iteration)
     # the loss of a view is scaled 1 / V: with more than one rank V defaults to the GLOBAL number of views (the
@@ -208,6 +215,23 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     # (the fused update leaves the gradient buffer undefined, like zero_grad="defer": not for callers who switched that off)
     fuse = (FUSE_ADAM_INTO_BACKWARD and DEFER_GRAD_ZEROING if fuse_adam is None else bool(fuse_adam)) and all_direct and \
         bool(cams) and not collectives_on() and bucket is None
+    # Data-parallel steps of few views send the SH gradients -- 48 of the 61 floats per Gaussian -- in factored form: every view's
+    # backward leaves its dL/d(rgb) table (12 B per Gaussian) in a slot of the optimizer, the ranks all-gather the slots and each
+    # rebuilds the f_dc / f_rest gradients (optim.FusedAdam.begin_factored_views).  The choice decides the sequence of
+    # collectives: it depends on the configuration and on the GLOBAL number of views only, never on this rank's cameras.
+    from . import optim as _optim
+    if sink is not None:
+        sink.end_factored_views()  # (a step that died between its backwards and its update)
+    slots = int(views_per_rank) if views_per_rank else -(-V // max(_world_size(), 1))
+    factored = bool(collectives_on() and fused_sink and OVERLAP_ALL_REDUCE_WITH_ADAM and bucket is None and
+                    _optim.FACTORED_SH_REDUCE and 0 < slots * _world_size() <= _optim.FACTORED_SH_MAX_VIEWS and
+                    sink.can_factor_views())
+    if factored:
+        if len(cams) > slots:
+            raise RuntimeError("training_step: %d views on this rank, %d view slots per rank (%d global views on %d ranks): "
+                               "pass views_per_rank = the largest number of views any rank holds, on every rank" %
+                               (len(cams), slots, V, _world_size()))
+        sink.begin_factored_views(slots)
     last_pipe = None
     if fuse:
         sink.cancel_skip()  # (as below: every backward of this step runs after any earlier surgery)
@@ -270,7 +294,10 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                 raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
                                    (gaussians.optimizer._direct_backwards, len(cams)))
             # all-reduce in chunks, each chunk's Adam update as soon as its sum is there (FusedAdam.step_chunked)
-            gaussians.optimizer.step_chunked(chunks=4, zero_grad=zg, reduce=True)
+            try:
+                gaussians.optimizer.step_chunked(chunks=4, zero_grad=zg, reduce=True)
+            finally:
+                gaussians.optimizer.end_factored_views()
             return total
         gaussians.optimizer.all_reduce()
         gaussians.optimizer.step(zero_grad=zg, nan_scan=not (direct_local and not collectives_on()))

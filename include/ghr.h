@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 18
+#define GHR_ABI_VERSION 19
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -219,6 +219,12 @@ typedef struct ghr_model_args {
     /* ---- the optimizer update fused into this backward call (mode 0, the LAST backward of a single-rank gradient step): see
      * ghr_adam_fuse below.  NULL: gradients are stored / accumulated as documented. */
     const struct ghr_adam_fuse* adam_fuse;
+    /* ---- ABI 19 (backward calls, mode 0 or 1; NULL = off): d_rgb [P,3], ASSIGNED: dL/d(rgb) of every Gaussian behind the colour
+     * clamp (sh_utils.py:57-112 + clamp_min(.. + 0.5, 0), src/gaussian_renderer/__init__.py:58-63).  This view's gradient of the
+     * SH coefficients is the outer product basis_k(dir) x d_rgb[c] -- 48 floats determined by 3 and by the view direction, which
+     * any holder of xyz and the camera centre can recompute: ghr_sh_grad_from_views.  With d_rgb set, d_features_dc and
+     * d_features_rest of the call may be NULL (nothing is stored for them); non-finite d_rgb raises nan_flag. */
+    float* d_rgb;
 } ghr_model_args;
 
 /* Adam fused into the projection backward (src/scene/gaussian_model.py:431-444 stepped at src/train_gaussians.py:174-181).
@@ -298,6 +304,18 @@ int32_t ghr_camera_slots(int32_t P);
  * pointers of ghr_model_args): the last two entries are dL/dFoVx, dL/dFoVy instead (x (1 + tan^2(FoV / 2)) / 2). */
 int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slots, float* d_cam, const float* fovx_dev,
                          const float* fovy_dev);
+
+/* ABI 19.  SH-coefficient gradients from per-view factors: the data-parallel step's gradient message (an all-reduce
+ * of 244 B per Gaussian over xGMI) is 79 % SH gradients, and those are rank-1 per view.  Ranks all-gather d_rgb (12 B per Gaussian
+ * and view, ghr_model_args.d_rgb) and their camera centres instead, and every rank calls this:
+ *   d_features_dc[i][c]      = sum_v basis_0 d_rgb[v][i][c]
+ *   d_features_rest[i][k][c] = sum_v basis_{k+1}(normalize(xyz_i - campos_v)) d_rgb[v][i][c]      (both ASSIGNED)
+ * views in list order, the products and the order of the sum being those of one rank accumulating the same views
+ * (ghr_model_backward with accumulate != 0): that run's bits.  campos [n_views,3] and g_views are DEVICE arrays; view v's [P,3]
+ * table starts at g_views + v * view_stride (floats).  sh_degree = the active degree (bands above it get zeros), sh_coeffs = K. */
+int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
+                           const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
+                           float* d_features_rest);
 
 /* ABI 18.  Strand polylines -> one Gaussian per segment: initialize_gaussians_hair (src/scene/gaussian_model_strands.py:435-452,
  * the same lines in gaussian_model_latent_strands.py), run at the top of every strand-stage iteration

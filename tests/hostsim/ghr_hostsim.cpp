@@ -37,6 +37,8 @@ struct Sim {
 };
 }  // namespace
 
+static float* g_sim_d_rgb = nullptr;
+
 extern "C" {
 
 void* ghrsim_forward(const ghr_view_args* a, int32_t* radii_out, float* out_color)
@@ -272,7 +274,7 @@ void ghrsim_project_backward3(const ghr::ModelArgs* a_in, const int* radii, cons
     ghr::ModelGrads g;
     g.ginst = nullptr; g.d_means2D = d_means2D; g.d_xyz = d_xyz; g.d_log_scales = d_ls; g.d_rotations = d_rot;
     g.d_opacity_logit = d_op; g.d_label_logit = d_label; g.d_orient_conf_log = d_conf; g.d_features_dc = d_fdc;
-    g.d_features_rest = d_frest; g.d_dir3d = d_dir;
+    g.d_features_rest = d_frest; g.d_dir3d = d_dir; g.d_rgb = g_sim_d_rgb;
     g.accumulate = 0; g.nan_flag = nullptr;
     g.cam_partial = nullptr; g.cam_slot0 = 0; g.cam_stride = 0; g.cam_only = 0; g.detach_means2D = detach_means2D;
     g.dens_grad_accum = nullptr; g.dens_denom = nullptr; g.dens_max_radii = nullptr; g.dens_count = nullptr; g.dens_cap = 0;
@@ -281,6 +283,21 @@ void ghrsim_project_backward3(const ghr::ModelArgs* a_in, const int* radii, cons
     for (int i = 0; i < a.P; i++)
         ghr::project_bwd_one(a, g, i, gacc + 16 * (size_t)i, a.features_rest + (size_t)i * row, d_frest + (size_t)i * row,
                              cam ? cam + (size_t)GHR_CAM_PARTIALS * i : nullptr);
+}
+
+// (set before a ghrsim_project_backward* call: that call also leaves d_rgb [P,3]; NULL = off)
+void ghrsim_set_d_rgb(float* p) { g_sim_d_rgb = p; }
+
+void ghrsim_sh_grad_from_views(int P, int deg, int K, const float* xyz, int n_views, const float* campos, const float* g,
+                               long long view_stride, float* d_dc, float* d_rest)
+{
+    const int row = 3 * (K - 1);
+    std::vector<float> tmp((size_t)(row > 0 ? row : 1));
+    for (int i = 0; i < P; i++) {
+        ghr::sh_grad_from_views_one(deg, K, xyz + 3 * (size_t)i, n_views, campos, g, (size_t)view_stride, (size_t)i,
+                                    d_dc + 3 * (size_t)i, tmp.data());
+        for (int k = 0; k < row; k++) d_rest[(size_t)i * row + k] = tmp[k];
+    }
 }
 
 int ghrsim_sizeof_model_args(void) { return (int)sizeof(ghr::ModelArgs); }

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ghr_abi_version() == _lib.ABI_VERSION == 18
+    assert L.ghr_abi_version() == _lib.ABI_VERSION == 19
 
 
 def test_workspace_sizes_and_error_codes():
@@ -300,6 +300,13 @@ def test_adam_reduce_plan_covers_the_buffer_and_skips_inactive_sh_bands(deg):
         assert len(special) == 1 and special[0][:2] == (rest_a, rest_b)
         assert special[0][2] == ("none" if deg == 0 else ("rest", P, 15, act))
         assert sent == n - 45 * P + 3 * P * act
+    # SH gradients as per-view factors (ABI 19): neither f_dc nor f_rest is reduced, whatever the active degree
+    fake._views = dict(buf=None)
+    plan = FusedAdam._reduce_plan(fake, 4)
+    assert plan[0][0] == 0 and plan[-1][1] == n and all(x[1] == y[0] for x, y in zip(plan, plan[1:]))
+    assert [x[:2] for x in plan if x[2] == "views"] == [(3 * P, 6 * P), (6 * P, 51 * P)]
+    assert all(how == "sum" for a, b, how in plan if not (3 * P <= a < 51 * P))
+    assert sum(b - a for a, b, how in plan if how == "sum") == 13 * P
 
 
 def test_camera_requires_grad_detects_every_trainable_camera_tensor():

@@ -66,7 +66,7 @@ def _capture_reduced_gradient(model, store):
     o.step_chunked, o.step = chunked, step
 
 
-def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None):
+def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None, factored=True):
     import torch.distributed as dist
     from gaussianhaircut_amd.parallel import param_checksum, shard_views
     from gaussianhaircut_amd.trainer import training_step
@@ -76,6 +76,11 @@ def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model, cams, bg, opt = _scene(dev, sh_degree)
     mine = shard_views(cams, rank, world)
+    from gaussianhaircut_amd import optim as _optim
+    _optim.FACTORED_SH_REDUCE = bool(factored)  # SH gradients as per-view factors (all-gather) or as sums (all-reduce)
+    rebuilds = []
+    _orig_rebuild = model.optimizer._rebuild_sh_from_views
+    model.optimizer._rebuild_sh_from_views = lambda g: (rebuilds.append(tuple(g.shape)), _orig_rebuild(g))[1]
     grads = []
     if shard is None:
         _capture_reduced_gradient(model, grads)
@@ -93,7 +98,7 @@ def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None):
     torch.cuda.synchronize()
     out = dict(rank=rank, checksum=param_checksum(model.leaf_parameters()),
                grad0=grads[0].cpu().numpy() if grads else None,
-               step=int(model.optimizer.state_dev[0]), chunked=model.optimizer.flat_param.numel())
+               step=int(model.optimizer.state_dev[0]), chunked=model.optimizer.flat_param.numel(), rebuilds=rebuilds)
     if shard is not None:
         o = model.optimizer
         out["stale"] = o._moment_shards is not None
@@ -126,27 +131,50 @@ def _worker(rank, world, port, q, sh_degree, poison_rank, shard=None):
     dist.destroy_process_group()
 
 
-def _run_two_ranks(sh_degree, poison_rank=None, shard=None):
+def _run_two_ranks(sh_degree, poison_rank=None, shard=None, factored=True):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sh_degree, poison_rank, shard)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, sh_degree, poison_rank, shard, factored)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=900) for _ in range(2)], key=lambda d: d["rank"])
+    res = _collect(q, procs, 2)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
     return res
 
 
+def _collect(q, procs, n, timeout=900):
+    """The workers' results; fails as soon as one of them has died (its peers would wait in a collective until the timeout)."""
+    import queue
+    import time
+    out, t0 = [], time.time()
+    while len(out) < n:
+        try:
+            out.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() - t0 > timeout:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError("worker exit codes %s after %.0f s" % ([p.exitcode for p in procs], time.time() - t0))
+    return sorted(out, key=lambda d: d["rank"])
+
+
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("sh_degree", [3, 1])
-def test_two_ranks_on_one_gpu_through_step_chunked_reduce(sh_degree):
+@pytest.mark.parametrize("sh_degree,factored", [(3, True), (1, True), (3, False), (1, False)])
+def test_two_ranks_on_one_gpu_through_step_chunked_reduce(sh_degree, factored):
+    """``factored``: the SH gradients travel as per-view dL/d(rgb) tables (all-gather, 12 B per Gaussian and view) and are
+    rebuilt on every rank (ABI 19, optim.FusedAdam.begin_factored_views) instead of being summed by the all-reduce."""
     from gaussianhaircut_amd.trainer import training_step
-    res = _run_two_ranks(sh_degree, poison_rank=1 if sh_degree == 3 else None)
+    res = _run_two_ranks(sh_degree, poison_rank=1 if sh_degree == 3 else None, factored=factored)
     assert res[0]["checksum"] == res[1]["checksum"], "replicas diverged"
     assert res[0]["step"] == res[1]["step"] == STEPS
+    for r in res:  # 8 views on 2 ranks: four slots per rank, gathered rank-major, one rebuild per step (the poisoned one too)
+        n = STEPS + (1 if sh_degree == 3 else 0)
+        assert len(r["rebuilds"]) == (n if factored else 0) and all(s[0] == 8 for s in r["rebuilds"]), r["rebuilds"]
     np.testing.assert_array_equal(res[0]["grad0"], res[1]["grad0"])
     if sh_degree == 3:
         assert res[0]["skipped"] and res[1]["skipped"], "a non-finite gradient on one rank must skip the step on both"
@@ -269,10 +297,10 @@ def _empty_rank_worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     model, cams, bg, opt = _scene(dev, 3)
     mine = cams[:4] if rank == 0 else []
-    training_step(model, mine, bg, opt, 1, global_views=4)
+    training_step(model, mine, bg, opt, 1, global_views=4, views_per_rank=4)  # (rank 0 holds all four: say so)
     model.reset_opacity()
     before = model.optimizer.flat_param.detach().clone()
-    training_step(model, mine, bg, opt, 2, global_views=4)
+    training_step(model, mine, bg, opt, 2, global_views=4, views_per_rank=4)
     torch.cuda.synchronize()
     o = model.optimizer
     q.put(dict(rank=rank, checksum=param_checksum(model.leaf_parameters()), step=int(o.state_dev[0]),
@@ -292,7 +320,7 @@ def test_a_rank_without_views_stays_a_bit_identical_replica_across_optimizer_sur
     procs = [ctx.Process(target=_empty_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=800) for _ in range(2)], key=lambda d: d["rank"])
+    res = _collect(q, procs, 2, timeout=800)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

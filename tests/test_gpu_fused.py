@@ -595,6 +595,65 @@ def test_first_direct_backward_assigns_only_into_a_buffer_known_to_be_zero():
     assert opt._zero_version is not None and float(opt.flat_grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("cfg,deg", [("tiny_strands", 3), ("tiny", 1)])
+def test_sh_gradients_rebuilt_from_per_view_factors_equal_the_accumulated_ones(cfg, deg):
+    """ABI 19 (the data-parallel gradient message): with view slots open (FusedAdam.begin_factored_views) the fused backward of
+    every view leaves dL/d(rgb) [P,3] + its camera centre instead of adding 192 B per Gaussian of SH gradients, and the update
+    rebuilds them (ghr_sh_grad_from_views).  One process, three views (one slot stays empty): the whole flat gradient and the
+    parameters after the update are the BITS of the plain accumulation."""
+    from gaussianhaircut_amd import _lib
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS[cfg]
+    bg = syn.background(dev)
+    cams = ring_cameras(3, spec.W, spec.H, device=dev)
+    w = torch.randn(6, spec.H, spec.W, generator=torch.Generator().manual_seed(2)).to(dev)
+    _lib.lib().ghr_set_deterministic(1)
+    try:
+        res = {}
+        for factored in (False, True):
+            model = syn.make_model(spec, dev)
+            model.active_sh_degree = deg
+            model.training_setup(OptimizationParams())
+            o = model.optimizer
+            assert o.can_factor_views()
+            if factored:
+                o.begin_factored_views(4)
+            for cam in cams:
+                pkg = render(cam, model, FUSED, bg)
+                (torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0) * w).sum().backward()
+            assert o._direct_backwards == 3
+            o.active_rest_coeffs = (deg + 1) ** 2 - 1
+            P = model.get_xyz.shape[0]
+            if factored:
+                assert o._views["next"] == 3
+                before = o.flat_grad[3 * P: 51 * P].detach().clone()   # the SH ranges: untouched by the three backwards
+                assert float(before.abs().max()) == 0.0
+            o.step_chunked(chunks=4, zero_grad=False)
+            o.end_factored_views()
+            torch.cuda.synchronize()
+            res[factored] = (o.flat_grad.detach().clone(), o.flat_param.detach().clone(), int(o.state_dev[0]))
+        (g0, p0, s0), (g1, p1, s1) = res[False], res[True]
+        assert s0 == s1 == 1 and float(g0[3 * P: 51 * P].abs().max()) > 0
+        assert torch.equal(g0, g1) and torch.equal(p0, p1)
+        # a non-finite cotangent of the red channel: the view's dL/d(rgb) table is non-finite and the optimizer's flag goes up
+        model = syn.make_model(spec, dev)
+        model.training_setup(OptimizationParams())
+        o = model.optimizer
+        o.begin_factored_views(1)
+        w_bad = w[:3].clone()
+        w_bad[0] = float("inf")
+        pkg = render(cams[0], model, FUSED, bg)
+        (pkg["render"] * w_bad).sum().backward()
+        torch.cuda.synchronize()
+        assert not bool(torch.isfinite(o._views["buf"][0, : 3 * P]).all())
+        o.end_factored_views()
+        assert int(o.state_dev[1]) == 1
+    finally:
+        _lib.lib().ghr_set_deterministic(0)
+
+
 def _trainable_camera(spec, dev):
     """A camera whose pose and FoV are being optimised, like the reference's (src/scene/cameras.py:83-151): the view
     matrix is a leaf, the full projection / centre are functions of it, the FoV tensors are leaves."""
