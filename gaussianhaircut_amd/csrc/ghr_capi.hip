@@ -633,7 +633,7 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
 
 int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
                            const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
-                           float* d_features_rest)
+                           float* d_features_rest, int32_t accumulate)
 {
     if (P < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || view_stride < 0 ||
         !(sh_coeffs == 1 || sh_coeffs == 4 || sh_coeffs == 9 || sh_coeffs == 16) || (sh_degree + 1) * (sh_degree + 1) > sh_coeffs)
@@ -646,6 +646,7 @@ int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t s
     ghr::ShViewsArgs a;
     a.P = P; a.sh_degree = sh_degree; a.sh_coeffs = sh_coeffs; a.n_views = n_views; a.xyz = xyz; a.campos = campos;
     a.g = g_views; a.view_stride = (size_t)view_stride; a.d_dc = d_features_dc; a.d_rest = d_features_rest;
+    a.accumulate = accumulate != 0;
     hipLaunchKernelGGL(ghr::k_sh_grad_from_views, dim3((P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), dim3(GHR_PBW_BLOCK), 0, s, a);
     return finish(s, 0);
 }

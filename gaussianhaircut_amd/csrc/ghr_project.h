@@ -1306,8 +1306,9 @@ struct ShViewsArgs {
     const float* campos;   // [n_views,3] (device)
     const float* g;        // view v: [P,3] at g + v * view_stride
     size_t view_stride;    // floats
-    float* d_dc;           // [P,1,3] assigned
-    float* d_rest;         // [P,K-1,3] assigned
+    float* d_dc;           // [P,1,3]
+    float* d_rest;         // [P,K-1,3]
+    int accumulate;        // != 0: added to what the two arrays hold; 0: assigned
 };
 
 __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_sh_grad_from_views(ShViewsArgs a)
@@ -1323,10 +1324,12 @@ __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_sh_grad_from_views(ShViewsArg
         float dc[3];
         sh_grad_from_views_one(a.sh_degree, a.sh_coeffs, a.xyz + 3 * (size_t)idx, a.n_views, a.campos, a.g, a.view_stride,
                                (size_t)idx, dc, s_rest + threadIdx.x * row);
-        a.d_dc[3 * (size_t)idx] = dc[0]; a.d_dc[3 * (size_t)idx + 1] = dc[1]; a.d_dc[3 * (size_t)idx + 2] = dc[2];
+        float* o = a.d_dc + 3 * (size_t)idx;
+        if (a.accumulate) { dc[0] += o[0]; dc[1] += o[1]; dc[2] += o[2]; }
+        o[0] = dc[0]; o[1] = dc[1]; o[2] = dc[2];
     }
     __syncthreads();
-    if (row > 0) slab_out<BLK>(a.d_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, 0);
+    if (row > 0) slab_out<BLK>(a.d_rest + (size_t)base * row, s_rest, (size_t)nb * row, threadIdx.x, a.accumulate);
 #endif
 }
 

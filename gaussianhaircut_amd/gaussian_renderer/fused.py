@@ -161,11 +161,17 @@ class _RenderModelFused(torch.autograd.Function):
             if P > 0 and direct and sink.take_known_zero():
                 acc = 0
             p_fdc, p_frest = _ptr(d_fdc), _ptr(d_frest)
+            fold_first = False
             if P > 0 and direct and getattr(sink, "_views", None) is not None:
-                # a data-parallel step that sends the SH gradients in factored form (optim.FusedAdam.begin_factored_views):
-                # this view's dL/d(rgb) table instead of 192 B per Gaussian added into the flat gradient
-                m.d_rgb = sink.next_view_slot(campos)
-                p_fdc = p_frest = None
+                if fuse and cfg.get("fuse_adam"):
+                    # the view that carries the optimizer update needs the step's whole SH gradient in the flat buffer: the
+                    # earlier views' tables are folded into it first (one launch), this view's terms are added by the kernel
+                    fold_first = True
+                else:
+                    # the SH gradients of this view in factored form (optim.FusedAdam.begin_factored_views): its dL/d(rgb)
+                    # table instead of 192 B per Gaussian read, added and written back in the flat gradient
+                    m.d_rgb = sink.next_view_slot(campos)
+                    p_fdc = p_frest = None
             if P > 0 and direct and sink.concurrent:
                 # this view shares the GPU with its neighbours (trainer.training_step): only the kernel that adds into
                 # the shared gradient buffer is ordered after the previous view's
@@ -173,6 +179,8 @@ class _RenderModelFused(torch.autograd.Function):
                 _lib.check(L.ghr_render_backward(_stream(), P, cfg["W"], cfg["H"], ctx.cap, _ptr(bg), _ptr(geom),
                                                  _ptr(img), _ptr(binb), _ptr(dL), _ptr(scratch), prezeroed))
                 sink.accumulate_begin(stream)
+                if fold_first:
+                    sink.fold_own_views()
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m), P, _ptr(radii), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz), _ptr(d_ls), _ptr(d_rot),
                                                         _ptr(d_op), _ptr(d_label), _ptr(d_conf), p_fdc,
@@ -180,6 +188,8 @@ class _RenderModelFused(torch.autograd.Function):
                                                         _ptr(binb), ctx.cap))
                 sink.accumulate_end(stream)
             elif P > 0:
+                if fold_first:
+                    sink.fold_own_views()
                 _lib.check(L.ghr_model_backward(_stream(), ctypes.byref(m), ctx.cap, _ptr(radii), _ptr(geom), _ptr(img),
                                                 _ptr(binb), _ptr(dL), _ptr(scratch), _ptr(d_m2d), _ptr(d_xyz),
                                                 _ptr(d_ls), _ptr(d_rot), _ptr(d_op), _ptr(d_label), _ptr(d_conf),

@@ -301,9 +301,12 @@ class FusedAdam:
                 rest[2].shape[1] in (3, 8, 15) and xyz[2].dim() == 2 and xyz[2].shape[1] == 3 and
                 dc[2].shape[0] == xyz[2].shape[0] == rest[2].shape[0])
 
-    def begin_factored_views(self, n_local: int):
-        """``n_local`` view slots for this rank's backwards of the coming step (the same number on every rank: the all-gather
-        is of equal parts; a rank with fewer views leaves zero tables)."""
+    def begin_factored_views(self, n_local: int, gather: bool = True):
+        """``n_local`` view slots for this rank's backwards of the coming step.  ``gather`` (the same on every rank, and then
+        ``n_local`` too: the all-gather is of equal parts; a rank with fewer views leaves zero tables): the slots of all ranks
+        are gathered and the f_dc / f_rest ranges are NOT reduced.  ``gather=False`` (a rank's own business: the collectives do
+        not change): only this rank's views are folded, before the usual sums -- what is saved is the read-modify-write of
+        192 B per Gaussian in every view's backward (a rank with at least two views: 12 B per view + one 192-B store)."""
         P = int(self._group_range("xyz")[2].shape[0])
         stride = -(-(3 * P + 3) // 4) * 4  # [d_rgb P x 3 | camera centre 3 | pad]: 16-B multiples
         v = getattr(self, "_views_buf", None)
@@ -312,6 +315,13 @@ class FusedAdam:
                      stride=stride, gathered=None)
             self._views_buf = v
         v["next"] = 0
+        v["gather"] = bool(gather)
+        # whether the SH ranges of the gradient buffer hold nothing yet (zeros, or undefined after a deferred step): the fold then
+        # ASSIGNS; otherwise (somebody else's gradients are in there) it adds -- the question take_known_zero() answers for the
+        # step's first backward, asked here without consuming the answer
+        v["assign"] = bool(getattr(self, "_deferred", None) is not None or
+                           (self._zero_version is not None and self.flat_grad._version == self._zero_version and
+                            self._direct_backwards == 0))
         self._views = v
 
     def end_factored_views(self):
@@ -327,8 +337,16 @@ class FusedAdam:
         v["buf"][i, 3 * v["P"]: 3 * v["P"] + 3].copy_(campos.detach().reshape(3).to(torch.float32))
         return ctypes.c_void_p(v["buf"].data_ptr() + 4 * i * v["stride"])
 
+    def fold_own_views(self):
+        """``gather=False``: this rank's filled slots folded into the SH ranges of the gradient buffer (no-op without any)."""
+        v = self._views
+        if v is None or v["gather"] or v["next"] == 0:
+            return
+        self._rebuild_sh_from_views(v["buf"][: v["next"]])
+        v["next"] = 0
+
     def _rebuild_sh_from_views(self, gathered: torch.Tensor):
-        """flat_grad[f_dc | f_rest] := sum over the gathered views (rank-major, then slot order) -- ghr_sh_grad_from_views."""
+        """flat_grad[f_dc | f_rest] (+)= sum over the gathered views (rank-major, then slot order) -- ghr_sh_grad_from_views."""
         v = self._views
         P, stride = v["P"], v["stride"]
         n_views = gathered.numel() // stride
@@ -342,7 +360,8 @@ class FusedAdam:
         with _on_device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_sh_grad_from_views(
                 _stream(), P, deg, K, ctypes.c_void_p(base_p + 4 * a_xyz), n_views, _ptr(campos), _ptr(rows), stride,
-                ctypes.c_void_p(base_g + 4 * a_dc), ctypes.c_void_p(base_g + 4 * a_rest)))
+                ctypes.c_void_p(base_g + 4 * a_dc), ctypes.c_void_p(base_g + 4 * a_rest), 0 if v["assign"] else 1))
+        v["assign"] = False  # (anything folded later in the same step comes on top)
         self._views_keep = (campos, gathered)  # (alive until the stream has consumed them: replaced by the next step's)
 
     def note_direct_backward(self):
@@ -453,6 +472,9 @@ class FusedAdam:
         the next fused backward assigns them; see ``resolve_deferred``).  ``nan_scan=False``: every gradient of this step was produced by the fused renderer's backward on THIS rank
         (which maintains the NaN flag), so the guard needs no pass over the gradients.  Must stay True after an
         all-reduce (another rank's NaN arrives through the sum) or when other losses touched ``.grad``."""
+        if self._views is not None and self._views["gather"]:
+            raise RuntimeError("FusedAdam.step: view slots opened for a gathered exchange need step_chunked(reduce=True)")
+        self.fold_own_views()  # (before resolve_deferred: the fold defines the SH ranges of a deferred buffer)
         self.resolve_deferred()  # (a step without a backward since a deferred one: its gradients are zeros)
         zero_grad, defer = _zero_grad_mode(zero_grad)
         self._sync_before_replicated_update()
@@ -506,7 +528,7 @@ class FusedAdam:
         for g in self.param_groups:
             p = g["params"][0]
             k = p.numel()
-            if getattr(self, "_views", None) is not None and g.get("name") in ("f_dc", "f_rest"):
+            if (getattr(self, "_views", None) or {}).get("gather") and g.get("name") in ("f_dc", "f_rest"):
                 # not reduced: rebuilt on every rank from the gathered per-view factors (begin_factored_views)
                 flush(off)
                 plan.append((off, off + k, "views"))
@@ -569,14 +591,18 @@ class FusedAdam:
         views_work, gathered = None, None
         if self._views is not None:
             v = self._views
-            if v["next"] < v["buf"].shape[0]:
-                v["buf"][v["next"]:].zero_()  # slots no backward of this rank filled: tables without a gradient
-            if comm:
-                # the per-view d_rgb tables of every rank, rank-major: started first, the f_dc / f_rest ranges wait for it
-                gathered = torch.empty((G * v["buf"].shape[0], v["buf"].shape[1]), dtype=torch.float32, device=v["buf"].device)
-                views_work = dist.all_gather_into_tensor(gathered, v["buf"], async_op=True)
+            if not v["gather"]:
+                self.fold_own_views()  # this rank's views folded; the ranges are summed like the others
             else:
-                self._rebuild_sh_from_views(v["buf"])
+                if v["next"] < v["buf"].shape[0]:
+                    v["buf"][v["next"]:].zero_()  # slots no backward of this rank filled: tables without a gradient
+                if comm:
+                    # the per-view d_rgb tables of every rank, rank-major: started first, the f_dc / f_rest ranges wait for it
+                    gathered = torch.empty((G * v["buf"].shape[0], v["buf"].shape[1]), dtype=torch.float32,
+                                           device=v["buf"].device)
+                    views_work = dist.all_gather_into_tensor(gathered, v["buf"], async_op=True)
+                else:
+                    self._rebuild_sh_from_views(v["buf"])
         if comm:
             flag = self.state_dev[1:2]
             flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)

@@ -148,7 +148,17 @@ def _generic_densify_stats(gaussians, pkg, pipe):
         gaussians.add_densification_stats(pkg["viewspace_points"], vis)
 
 
-def training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
+def training_step(gaussians, cams: List, background, opt, iteration: int, *args, **kwargs):
+    # (this wrapper only makes sure the optimizer's view slots never outlive the step)
+    try:
+        return _training_step(gaussians, cams, background, opt, iteration, *args, **kwargs)
+    finally:
+        o = getattr(gaussians, "optimizer", None)
+        if hasattr(o, "end_factored_views"):
+            o.end_factored_views()
+
+
+def _training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
                   global_views: Optional[int] = None, pipe=PIPE, streams: Optional[int] = None,
                   defer_counts: Optional[bool] = None, densify_stats: bool = False, fuse_adam: Optional[bool] = None,
                   views_per_rank: Optional[int] = None):
@@ -232,6 +242,13 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                                "pass views_per_rank = the largest number of views any rank holds, on every rank" %
                                (len(cams), slots, V, _world_size()))
         sink.begin_factored_views(slots)
+    elif (all_direct and bucket is None and _optim.FACTORED_SH_REDUCE and sink.can_factor_views() and
+          len(cams) >= (3 if fuse else 2) and (not collectives_on() or OVERLAP_ALL_REDUCE_WITH_ADAM)):
+        # one rank, or too many views in all for the gathered form: the rank folds ITS views' tables into the flat gradient
+        # once (before the sums / the update; before the last view's backward when that one carries the update) and every other
+        # view's backward skips the read-modify-write of 192 B of SH gradients per Gaussian (4 views per rank through the
+        # collective branch: 2.74 -> 2.45 ms, profiles/r06k).  A rank's own choice: the sequence of collectives is the plain one.
+        sink.begin_factored_views(len(cams), gather=False)
     last_pipe = None
     if fuse:
         sink.cancel_skip()  # (as below: every backward of this step runs after any earlier surgery)
@@ -294,10 +311,7 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
                 raise RuntimeError("training_step: %d of %d views went through the fused backward on this rank" %
                                    (gaussians.optimizer._direct_backwards, len(cams)))
             # all-reduce in chunks, each chunk's Adam update as soon as its sum is there (FusedAdam.step_chunked)
-            try:
-                gaussians.optimizer.step_chunked(chunks=4, zero_grad=zg, reduce=True)
-            finally:
-                gaussians.optimizer.end_factored_views()
+            gaussians.optimizer.step_chunked(chunks=4, zero_grad=zg, reduce=True)
             return total
         gaussians.optimizer.all_reduce()
         gaussians.optimizer.step(zero_grad=zg, nan_scan=not (direct_local and not collectives_on()))
@@ -326,6 +340,9 @@ def training_step(gaussians, cams: List, background, opt, iteration: int, bucket
     else:
         gaussians.optimizer.zero_grad(set_to_none=True)
     return total
+
+
+training_step.__doc__ = _training_step.__doc__  # (the arguments are documented there)
 
 
 @torch.no_grad()

@@ -309,13 +309,13 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
  * of 244 B per Gaussian over xGMI) is 79 % SH gradients, and those are rank-1 per view.  Ranks all-gather d_rgb (12 B per Gaussian
  * and view, ghr_model_args.d_rgb) and their camera centres instead, and every rank calls this:
  *   d_features_dc[i][c]      = sum_v basis_0 d_rgb[v][i][c]
- *   d_features_rest[i][k][c] = sum_v basis_{k+1}(normalize(xyz_i - campos_v)) d_rgb[v][i][c]      (both ASSIGNED)
- * views in list order, the products and the order of the sum being those of one rank accumulating the same views
+ *   d_features_rest[i][k][c] = sum_v basis_{k+1}(normalize(xyz_i - campos_v)) d_rgb[v][i][c]
+ * (both ASSIGNED, or added to what the arrays hold with accumulate != 0), views in list order, the products and the order of the sum being those of one rank accumulating the same views
  * (ghr_model_backward with accumulate != 0): that run's bits.  campos [n_views,3] and g_views are DEVICE arrays; view v's [P,3]
  * table starts at g_views + v * view_stride (floats).  sh_degree = the active degree (bands above it get zeros), sh_coeffs = K. */
 int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
                            const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
-                           float* d_features_rest);
+                           float* d_features_rest, int32_t accumulate);
 
 /* ABI 18.  Strand polylines -> one Gaussian per segment: initialize_gaussians_hair (src/scene/gaussian_model_strands.py:435-452,
  * the same lines in gaussian_model_latent_strands.py), run at the top of every strand-stage iteration

@@ -301,12 +301,14 @@ def test_adam_reduce_plan_covers_the_buffer_and_skips_inactive_sh_bands(deg):
         assert special[0][2] == ("none" if deg == 0 else ("rest", P, 15, act))
         assert sent == n - 45 * P + 3 * P * act
     # SH gradients as per-view factors (ABI 19): neither f_dc nor f_rest is reduced, whatever the active degree
-    fake._views = dict(buf=None)
+    fake._views = dict(buf=None, gather=True)
     plan = FusedAdam._reduce_plan(fake, 4)
     assert plan[0][0] == 0 and plan[-1][1] == n and all(x[1] == y[0] for x, y in zip(plan, plan[1:]))
     assert [x[:2] for x in plan if x[2] == "views"] == [(3 * P, 6 * P), (6 * P, 51 * P)]
     assert all(how == "sum" for a, b, how in plan if not (3 * P <= a < 51 * P))
     assert sum(b - a for a, b, how in plan if how == "sum") == 13 * P
+    fake._views = dict(buf=None, gather=False)  # a rank folding only its own views: the plan is the usual one
+    assert all(how == "sum" for _, _, how in FusedAdam._reduce_plan(SimpleNamespace(**{**vars(fake), "active_rest_coeffs": None}), 4))
 
 
 def test_camera_requires_grad_detects_every_trainable_camera_tensor():

@@ -234,19 +234,29 @@ def _nccl_worker(port, q):
     from gaussianhaircut_amd import _lib
     _lib.lib().ghr_set_deterministic(1)  # two RUNS are compared bit for bit: the gradient walk's atomics must be ordered
     out = {}
+    from gaussianhaircut_amd import optim as _optim
     for deg in (3, 1):
         runs = []
+        # degree 3: the four views' dL/d(rgb) tables are GATHERED (one rank: the gather is the identity) and the SH ranges are
+        # not reduced; degree 1: the threshold is set to 0, so the rank only FOLDS its own four tables before the usual sums
+        _optim.FACTORED_SH_MAX_VIEWS = 16 if deg == 3 else 0
         for force in ("1", "0"):
             os.environ["GHR_FORCE_COLLECTIVES"] = force
             model, cams, bg, opt = _scene(dev, deg)
             calls = []
             orig = model.optimizer.step_chunked
             model.optimizer.step_chunked = lambda **kw: (calls.append(kw), orig(**kw))[1]
+            folds = []
+            o_ = model.optimizer
+            orig_fold = o_._rebuild_sh_from_views
+            o_._rebuild_sh_from_views = lambda g, o_=o_, orig_fold=orig_fold, folds=folds: (folds.append(o_._views["gather"]), orig_fold(g))[1]
             for it in range(STEPS):
                 training_step(model, cams[:4], bg, opt, it + 1, global_views=4)
             torch.cuda.synchronize()
             runs.append((model.optimizer.flat_param.detach().clone(), model.optimizer.exp_avg_sq.detach().clone(),
                          int(model.optimizer.state_dev[0]), len(calls), [c.get("reduce") for c in calls]))
+            if force == "1":
+                out["folds_%d" % deg] = list(folds)
             if force == "1" and deg == 3:  # a non-finite gradient skips the step through the collective branch too
                 before = model.optimizer.flat_param.detach().clone()
                 cams[0].original_image = cams[0].original_image.clone()
@@ -282,6 +292,8 @@ def test_one_rank_on_rccl_through_the_collective_branch_is_bit_identical_to_the_
         assert r["chunked_calls"][1] == 0, r                                     # ... and the local one otherwise
         assert r["params_equal"] and r["v_equal"] and r["steps"] == (STEPS, STEPS) and r["finite"], r
         assert r["moved"] > 0
+        # every step of the collective branch rebuilt the SH gradients from the views' tables: gathered (3) / folded locally (1)
+        assert res["folds_%d" % deg] == [deg == 3] * STEPS, res["folds_%d" % deg]
     assert res["skipped"]
 
 

@@ -1043,6 +1043,95 @@ def test_adam_fused_into_the_last_projection_backward_is_bit_identical():
         dgr._R_RECENT.clear()
 
 
+def test_multi_view_steps_fold_their_sh_gradients_from_per_view_tables_bit_for_bit():
+    """Round 6: in a step of several views on one rank every view but the one that carries the update leaves its dL/d(rgb) table
+    (12 B per Gaussian) instead of read-modify-writing 192 B of SH gradients, and the tables are folded into the flat gradient
+    once (optim.FusedAdam.begin_factored_views(gather=False)).  Same parameters, moments and step count as with the in-place
+    accumulation, bit for bit: four-view and three-view steps with the update in the last backward, the same with the separate
+    pass, a two-view step (separate pass only), a step whose capacity guess overflows, a NaN step; and a gradient somebody else
+    left in ``.grad`` before the step survives the fold."""
+    import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+    from gaussianhaircut_amd import _lib, optim
+    from gaussianhaircut_amd.scene.cameras import ring_cameras
+    from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
+    from gaussianhaircut_amd.trainer import make_ground_truth, training_step
+    dev = torch.device("cuda:0")
+    spec = syn.CONFIGS["tiny_strands"]
+    opt = OptimizationParams()
+    opt.lambda_dorient = 0.1
+    cams = ring_cameras(6, spec.W, spec.H, device=dev)
+    bg = syn.background(dev)
+    gt = syn.make_model(spec, dev)
+    with torch.no_grad():
+        gt._features_dc.add_(0.3)
+    make_ground_truth(gt, cams, bg)
+    plan = [(cams[:4], False, False), (cams[1:4], False, False), (cams[2:4], False, False), (cams[:4], True, False),
+            (cams[2:6], False, True), (cams[:5], False, False)]
+    _lib.lib().ghr_set_deterministic(1)
+    saved = optim.FACTORED_SH_REDUCE
+    try:
+        for fused in (True, False):
+            runs = {}
+            for factored in (True, False):
+                optim.FACTORED_SH_REDUCE = factored
+                model = syn.make_model(spec, dev)
+                model.training_setup(opt)
+                o = model.optimizer
+                folds = []
+                orig = o._rebuild_sh_from_views
+                o._rebuild_sh_from_views = lambda g, folds=folds, orig=orig: (folds.append(int(g.shape[0])), orig(g))[1]
+                trace = []
+                for it, (views, overflow, nan) in enumerate(plan):
+                    if overflow:
+                        dgr._R_RECENT.clear()
+                        dgr._R_HINT[dev.index] = 4096
+                    if nan:
+                        with torch.no_grad():
+                            keep = model._opacity[3].clone()
+                            model._opacity[3] = float("nan")
+                    training_step(model, list(views), bg, opt, it + 1, fuse_adam=fused)
+                    torch.cuda.synchronize()
+                    if nan:
+                        with torch.no_grad():
+                            model._opacity[3] = keep
+                    assert o._views is None
+                    trace.append((o.flat_param.clone(), o.exp_avg.clone(), o.exp_avg_sq.clone(), int(o.state_dev[0])))
+                runs[factored] = (trace, folds)
+            (ta, fa), (tb, fb) = runs[True], runs[False]
+            assert fb == [] and len(fa) >= 5, (fa, fb)
+            # tables folded: all but the updating view's (fused) / all (separate pass); two views fold only with the separate pass
+            assert fa[0] == (3 if fused else 4) and fa[1] == (2 if fused else 3), fa
+            for it, (a, b) in enumerate(zip(ta, tb)):
+                assert a[3] == b[3], (fused, it, a[3], b[3])
+                for x, y in zip(a[:3], b[:3]):
+                    assert _same_bits(x, y), (fused, it, float((x - y).abs().max()))
+            assert [t[3] for t in ta] == [1, 2, 3, 4, 4, 5]
+        # somebody else's gradient in .grad before the step: the fold adds to it
+        res = []
+        for factored in (True, False):
+            optim.FACTORED_SH_REDUCE = factored
+            model = syn.make_model(spec, dev)
+            model.training_setup(opt)
+            o = model.optimizer
+            model._features_rest.grad.add_(0.5)
+            model._features_dc.grad.add_(0.25)
+            grads = []
+            orig_step = o.step
+            o.step = lambda *a, **k: (grads.append(o.flat_grad.detach().clone()) if o._views is None else
+                                      (o.fold_own_views(), grads.append(o.flat_grad.detach().clone())), orig_step(*a, **k))[-1]
+            training_step(model, list(cams[:3]), bg, opt, 1, fuse_adam=False)
+            torch.cuda.synchronize()
+            res.append(grads[0])
+        P = model.get_xyz.shape[0]
+        assert torch.allclose(res[0], res[1], rtol=1e-5, atol=1e-7)
+        assert float((res[0][3 * P: 51 * P] - 0.25).abs().min()) >= 0.0 and float(res[0][6 * P: 51 * P].mean()) > 0.4
+    finally:
+        optim.FACTORED_SH_REDUCE = saved
+        _lib.lib().ghr_set_deterministic(0)
+        dgr._R_HINT.pop(dev.index, None)
+        dgr._R_RECENT.clear()
+
+
 def test_onepass_densify_and_prune_equals_the_stepwise_sequence_bit_for_bit():
     """scene/densification.py: with FusedAdam one densification event is ONE re-lay of the flat buffers (decisions on per-row
     scalars, every group gathered once by index) instead of the reference's clone / split / prune sequence with its ~60
