@@ -193,7 +193,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_model_backward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32] + [vp] * 13 + [i32, vp, u32, vp, u32]
     L.ghr_camera_slots.argtypes = [i32]
     L.ghr_camera_grad_fold.argtypes = [vp, vp, i32, vp, vp, vp]
-    L.ghr_sh_grad_from_views.argtypes = [vp, i32, i32, i32, vp, i32, vp, vp, ctypes.c_int64, vp, vp, i32]
+    L.ghr_sh_grad_from_views.argtypes = [vp, i32, i32, i32, vp, i32, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, i32, vp,
+                                         ctypes.c_int64]
     L.ghr_adam_nan_scan.argtypes = [vp, vp, ctypes.c_int64, vp]
     L.ghr_strand_build.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp, vp]
     L.ghr_strand_build_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]

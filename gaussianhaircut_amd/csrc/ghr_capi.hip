@@ -632,10 +632,12 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
 }
 
 int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
-                           const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
-                           float* d_features_rest, int32_t accumulate)
+                           const float* campos, int64_t campos_stride, const float* g_views, int64_t view_stride,
+                           float* d_features_dc, float* d_features_rest, int32_t accumulate, int32_t* nan_flag,
+                           int64_t flag_offset)
 {
-    if (P < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || view_stride < 0 ||
+    if (P < 0 || n_views < 0 || sh_degree < 0 || sh_degree > 3 || view_stride < 0 || campos_stride < 0 ||
+        (nan_flag != nullptr && (flag_offset < 0 || (n_views > 1 && flag_offset >= view_stride))) ||
         !(sh_coeffs == 1 || sh_coeffs == 4 || sh_coeffs == 9 || sh_coeffs == 16) || (sh_degree + 1) * (sh_degree + 1) > sh_coeffs)
         return fail(GHR_E_INVALID, "ghr_sh_grad_from_views: bad sizes");
     if (P == 0) return GHR_OK;
@@ -645,6 +647,7 @@ int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t s
     hipStream_t s = (hipStream_t)stream;
     ghr::ShViewsArgs a;
     a.P = P; a.sh_degree = sh_degree; a.sh_coeffs = sh_coeffs; a.n_views = n_views; a.xyz = xyz; a.campos = campos;
+    a.campos_stride = (size_t)campos_stride; a.nan_flag = nan_flag; a.flag_offset = flag_offset;
     a.g = g_views; a.view_stride = (size_t)view_stride; a.d_dc = d_features_dc; a.d_rest = d_features_rest;
     a.accumulate = accumulate != 0;
     hipLaunchKernelGGL(ghr::k_sh_grad_from_views, dim3((P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK), dim3(GHR_PBW_BLOCK), 0, s, a);

@@ -1270,8 +1270,8 @@ k_project_bwd<true, true>(ModelArgs a, ModelGrads g)
 // products are the ones project_bwd_sh forms and the sum is taken in the order a single rank accumulating the same views takes
 // it, so the result has that run's bits.  A view in which the Gaussian has no gradient (culled: d_rgb = 0) is skipped -- its
 // direction may not even be defined (a Gaussian at the camera centre).
-GHR_HD void sh_grad_from_views_one(int deg, int K, const float* xyz3, int n_views, const float* campos, const float* g,
-                                   size_t view_stride, size_t idx, float* dc, float* rest)
+GHR_HD void sh_grad_from_views_one(int deg, int K, const float* xyz3, int n_views, const float* campos, size_t campos_stride,
+                                   const float* g, size_t view_stride, size_t idx, float* dc, float* rest)
 {
     float acc[3 * GHR_SH_MAX];
 #pragma unroll
@@ -1281,7 +1281,7 @@ GHR_HD void sh_grad_from_views_one(int deg, int K, const float* xyz3, int n_view
         const float* gv = g + (size_t)v * view_stride + 3 * idx;
         const float g0 = gv[0], g1 = gv[1], g2 = gv[2];
         if (g0 == 0.f && g1 == 0.f && g2 == 0.f) continue;  // (a NaN compares unequal: it is carried through)
-        const float* cpos = campos + 3 * v;
+        const float* cpos = campos + campos_stride * v;
         const float dxv = mx - cpos[0], dyv = my - cpos[1], dzv = mz - cpos[2];  // as project_bwd_sh
         const float len = sqrtf(dxv * dxv + dyv * dyv + dzv * dzv), il = 1.0f / len;
         const float x = dxv * il, y = dyv * il, z = dzv * il;
@@ -1303,9 +1303,12 @@ GHR_HD void sh_grad_from_views_one(int deg, int K, const float* xyz3, int n_view
 struct ShViewsArgs {
     int P, sh_degree, sh_coeffs, n_views;
     const float* xyz;      // [P,3]
-    const float* campos;   // [n_views,3] (device)
+    const float* campos;   // view v: 3 floats at campos + v * campos_stride (device)
+    size_t campos_stride;  // floats
     const float* g;        // view v: [P,3] at g + v * view_stride
     size_t view_stride;    // floats
+    int* nan_flag;         // optional: raised when the float at g + v * view_stride + flag_offset of any view is not zero --
+    long long flag_offset; // the ranks' own non-finite flags, carried by the gathered rows (saves a 4-byte all-reduce)
     float* d_dc;           // [P,1,3]
     float* d_rest;         // [P,K-1,3]
     int accumulate;        // != 0: added to what the two arrays hold; 0: assigned
@@ -1320,10 +1323,13 @@ __global__ void __launch_bounds__(GHR_PBW_BLOCK) k_sh_grad_from_views(ShViewsArg
     const int base = blockIdx.x * BLK;
     const int nb = min(BLK, a.P - base);
     const int idx = base + threadIdx.x;
+    if (a.nan_flag != nullptr && blockIdx.x == 0)
+        for (int v = threadIdx.x; v < a.n_views; v += BLK)
+            if (a.g[(size_t)v * a.view_stride + (size_t)a.flag_offset] != 0.f) atomicOr(a.nan_flag, 1);
     if (idx < a.P) {
         float dc[3];
-        sh_grad_from_views_one(a.sh_degree, a.sh_coeffs, a.xyz + 3 * (size_t)idx, a.n_views, a.campos, a.g, a.view_stride,
-                               (size_t)idx, dc, s_rest + threadIdx.x * row);
+        sh_grad_from_views_one(a.sh_degree, a.sh_coeffs, a.xyz + 3 * (size_t)idx, a.n_views, a.campos, a.campos_stride, a.g,
+                               a.view_stride, (size_t)idx, dc, s_rest + threadIdx.x * row);
         float* o = a.d_dc + 3 * (size_t)idx;
         if (a.accumulate) { dc[0] += o[0]; dc[1] += o[1]; dc[2] += o[2]; }
         o[0] = dc[0]; o[1] = dc[1]; o[2] = dc[2];

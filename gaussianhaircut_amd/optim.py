@@ -38,6 +38,7 @@ SHARD_ADAM = True
 # against 2 (G - 1) / G x 192 B per GPU, i.e. a gain below V = 32 views, kept to where it is at least 2x.
 FACTORED_SH_REDUCE = os.environ.get("GHR_FACTORED_SH_REDUCE", "1") != "0"
 FACTORED_SH_MAX_VIEWS = 16
+SHARD_WITH_GATHERED_VIEWS = os.environ.get("GHR_SHARD_WITH_GATHERED_VIEWS", "0") == "1"
 
 
 class StaleMomentsError(RuntimeError):
@@ -301,14 +302,14 @@ class FusedAdam:
                 rest[2].shape[1] in (3, 8, 15) and xyz[2].dim() == 2 and xyz[2].shape[1] == 3 and
                 dc[2].shape[0] == xyz[2].shape[0] == rest[2].shape[0])
 
-    def begin_factored_views(self, n_local: int, gather: bool = True):
+    def begin_factored_views(self, n_local: int, gather: bool = True, sh_degree=None):
         """``n_local`` view slots for this rank's backwards of the coming step.  ``gather`` (the same on every rank, and then
         ``n_local`` too: the all-gather is of equal parts; a rank with fewer views leaves zero tables): the slots of all ranks
         are gathered and the f_dc / f_rest ranges are NOT reduced.  ``gather=False`` (a rank's own business: the collectives do
         not change): only this rank's views are folded, before the usual sums -- what is saved is the read-modify-write of
         192 B per Gaussian in every view's backward (a rank with at least two views: 12 B per view + one 192-B store)."""
         P = int(self._group_range("xyz")[2].shape[0])
-        stride = -(-(3 * P + 3) // 4) * 4  # [d_rgb P x 3 | camera centre 3 | pad]: 16-B multiples
+        stride = -(-(3 * P + 4) // 4) * 4  # [d_rgb P x 3 | camera centre 3 | the rank's non-finite mark | pad]: 16-B multiples
         v = getattr(self, "_views_buf", None)
         if v is None or v["buf"].shape != (n_local, stride) or v["buf"].device != self.flat_param.device:
             v = dict(buf=torch.zeros((n_local, stride), dtype=torch.float32, device=self.flat_param.device), P=P,
@@ -316,6 +317,7 @@ class FusedAdam:
             self._views_buf = v
         v["next"] = 0
         v["gather"] = bool(gather)
+        v["deg"] = None if sh_degree is None else int(sh_degree)  # the active SH degree of the step's backwards
         # whether the SH ranges of the gradient buffer hold nothing yet (zeros, or undefined after a deferred step): the fold then
         # ASSIGNS; otherwise (somebody else's gradients are in there) it adds -- the question take_known_zero() answers for the
         # step's first backward, asked here without consuming the answer
@@ -345,24 +347,26 @@ class FusedAdam:
         self._rebuild_sh_from_views(v["buf"][: v["next"]])
         v["next"] = 0
 
-    def _rebuild_sh_from_views(self, gathered: torch.Tensor):
-        """flat_grad[f_dc | f_rest] (+)= sum over the gathered views (rank-major, then slot order) -- ghr_sh_grad_from_views."""
+    def _rebuild_sh_from_views(self, gathered: torch.Tensor, flags: bool = False):
+        """flat_grad[f_dc | f_rest] (+)= sum over the gathered views (rank-major, then slot order) -- ghr_sh_grad_from_views.
+        ``flags``: the rows also carry their owners' non-finite marks (float 3 P + 3 of a row): OR-ed into this rank's flag."""
         v = self._views
         P, stride = v["P"], v["stride"]
         n_views = gathered.numel() // stride
         rows = gathered.view(n_views, stride)
-        campos = rows[:, 3 * P: 3 * P + 3].contiguous()
         (a_dc, _, _), (a_rest, _, p_rest), (a_xyz, _, _) = self._group_range("f_dc"), self._group_range("f_rest"), self._group_range("xyz")
         K = int(p_rest.shape[1]) + 1
         act = K - 1 if self.active_rest_coeffs is None else int(self.active_rest_coeffs)
-        deg = {0: 0, 3: 1, 8: 2, 15: 3}[act]
+        deg = v["deg"] if v.get("deg") is not None else {0: 0, 3: 1, 8: 2, 15: 3}[act]
         base_g, base_p = self.flat_grad.data_ptr(), self.flat_param.data_ptr()
         with _on_device(self.flat_param.device):
             _lib.check(_lib.lib().ghr_sh_grad_from_views(
-                _stream(), P, deg, K, ctypes.c_void_p(base_p + 4 * a_xyz), n_views, _ptr(campos), _ptr(rows), stride,
-                ctypes.c_void_p(base_g + 4 * a_dc), ctypes.c_void_p(base_g + 4 * a_rest), 0 if v["assign"] else 1))
+                _stream(), P, deg, K, ctypes.c_void_p(base_p + 4 * a_xyz), n_views,
+                ctypes.c_void_p(rows.data_ptr() + 4 * 3 * P), stride, _ptr(rows), stride,
+                ctypes.c_void_p(base_g + 4 * a_dc), ctypes.c_void_p(base_g + 4 * a_rest), 0 if v["assign"] else 1,
+                ctypes.c_void_p(self.state_dev.data_ptr() + 4) if flags else None, 3 * P + 3))
         v["assign"] = False  # (anything folded later in the same step comes on top)
-        self._views_keep = (campos, gathered)  # (alive until the stream has consumed them: replaced by the next step's)
+        self._views_keep = gathered  # (alive until the stream has consumed them: replaced by the next step's)
 
     def note_direct_backward(self):
         self._direct_backwards += 1
@@ -575,8 +579,12 @@ class FusedAdam:
             # gradients / send-buffer remains: a caller that keeps the gradients (zero_grad=False) would read a mix
             raise ValueError("FusedAdam.step_chunked: shard=True needs zero_grad=True or 'defer' (the sharded update does "
                              "not leave the summed gradient on every rank); use shard=False to keep the gradients")
-        # (default: shard only when the gradients are not kept -- the same on every rank, it only depends on the arguments)
-        shard = comm and (SHARD_ADAM and (zero_grad or defer) if shard is None else bool(shard))
+        # (default: shard only when the gradients are not kept -- the same on every rank, it only depends on the arguments;
+        # and not when the SH ranges travel as gathered view tables: what is left to sum is 13 floats per Gaussian in two
+        # ranges -- two all-reduces and 29 us of replicated update instead of reduce-scatter + all-gather pairs and their tails)
+        gather_mode = self._views is not None and self._views["gather"]
+        shard = comm and (SHARD_ADAM and (zero_grad or defer) and not (gather_mode and not SHARD_WITH_GATHERED_VIEWS)
+                          if shard is None else bool(shard))
         G, r = (dist.get_world_size(), dist.get_rank()) if comm else (1, 0)
         plan = self._reduce_plan(chunks) if comm else [(a, b, "local") for a, b in self._chunk_ranges(chunks)]
         if shard:
@@ -597,15 +605,20 @@ class FusedAdam:
                 if v["next"] < v["buf"].shape[0]:
                     v["buf"][v["next"]:].zero_()  # slots no backward of this rank filled: tables without a gradient
                 if comm:
-                    # the per-view d_rgb tables of every rank, rank-major: started first, the f_dc / f_rest ranges wait for it
+                    # the per-view d_rgb tables of every rank, rank-major: started first, the f_dc / f_rest ranges wait for it.
+                    # The rank's skip-the-step flag rides in its first row (the pad float behind the camera centre): the
+                    # rebuild kernel ORs the gathered marks into the flag before any range is updated -- no 4-byte all-reduce
+                    v["buf"][0, 3 * v["P"] + 3: 3 * v["P"] + 4].copy_(self.state_dev[1:2])
                     gathered = torch.empty((G * v["buf"].shape[0], v["buf"].shape[1]), dtype=torch.float32,
                                            device=v["buf"].device)
                     views_work = dist.all_gather_into_tensor(gathered, v["buf"], async_op=True)
                 else:
                     self._rebuild_sh_from_views(v["buf"])
         if comm:
-            flag = self.state_dev[1:2]
-            flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
+            flag_work = None
+            if views_work is None:
+                flag = self.state_dev[1:2]
+                flag_work = dist.all_reduce(flag, op=dist.ReduceOp.MAX, async_op=True)
             for i, (a, b, how) in enumerate(plan):
                 if how == "sum":
                     works[i] = (dist.all_reduce(self.flat_grad[a:b], op=dist.ReduceOp.SUM, async_op=True), None, None)
@@ -618,7 +631,8 @@ class FusedAdam:
                     view = self.flat_grad[a:b].view(P, K1, 3)[:, :act]
                     packed = view.contiguous()
                     works[i] = (dist.all_reduce(packed, op=dist.ReduceOp.SUM, async_op=True), view, packed)
-            flag_work.wait()
+            if flag_work is not None:
+                flag_work.wait()
         n = self.flat_param.numel()
         gathers = []
         # The ranges rebuilt from the gathered views go FIRST: the rebuild evaluates the SH basis at the positions the forward
@@ -636,7 +650,7 @@ class FusedAdam:
                 if how == "views" and views_work is not None:
                     views_work.wait()
                     views_work = None
-                    self._rebuild_sh_from_views(gathered)  # both ranges (f_dc, f_rest) in one launch
+                    self._rebuild_sh_from_views(gathered, flags=True)  # both ranges (f_dc, f_rest) in one launch
                 lo, hi = a, b
                 if how == "shard":
                     L = (b - a) // G

@@ -241,14 +241,14 @@ def _training_step(gaussians, cams: List, background, opt, iteration: int, bucke
             raise RuntimeError("training_step: %d views on this rank, %d view slots per rank (%d global views on %d ranks): "
                                "pass views_per_rank = the largest number of views any rank holds, on every rank" %
                                (len(cams), slots, V, _world_size()))
-        sink.begin_factored_views(slots)
+        sink.begin_factored_views(slots, sh_degree=int(gaussians.active_sh_degree))
     elif (all_direct and bucket is None and _optim.FACTORED_SH_REDUCE and sink.can_factor_views() and
           len(cams) >= (3 if fuse else 2) and (not collectives_on() or OVERLAP_ALL_REDUCE_WITH_ADAM)):
         # one rank, or too many views in all for the gathered form: the rank folds ITS views' tables into the flat gradient
         # once (before the sums / the update; before the last view's backward when that one carries the update) and every other
         # view's backward skips the read-modify-write of 192 B of SH gradients per Gaussian (4 views per rank through the
         # collective branch: 2.74 -> 2.45 ms, profiles/r06k).  A rank's own choice: the sequence of collectives is the plain one.
-        sink.begin_factored_views(len(cams), gather=False)
+        sink.begin_factored_views(len(cams), gather=False, sh_degree=int(gaussians.active_sh_degree))
     last_pipe = None
     if fuse:
         sink.cancel_skip()  # (as below: every backward of this step runs after any earlier surgery)

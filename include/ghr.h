@@ -311,11 +311,16 @@ int ghr_camera_grad_fold(void* stream, const float* cam_partial, int32_t cam_slo
  *   d_features_dc[i][c]      = sum_v basis_0 d_rgb[v][i][c]
  *   d_features_rest[i][k][c] = sum_v basis_{k+1}(normalize(xyz_i - campos_v)) d_rgb[v][i][c]
  * (both ASSIGNED, or added to what the arrays hold with accumulate != 0), views in list order, the products and the order of the sum being those of one rank accumulating the same views
- * (ghr_model_backward with accumulate != 0): that run's bits.  campos [n_views,3] and g_views are DEVICE arrays; view v's [P,3]
- * table starts at g_views + v * view_stride (floats).  sh_degree = the active degree (bands above it get zeros), sh_coeffs = K. */
+ * (ghr_model_backward with accumulate != 0): that run's bits.  campos and g_views are DEVICE arrays: view v's camera centre is
+ * the 3 floats at campos + v * campos_stride, its [P,3] table starts at g_views + v * view_stride (strides in floats; both may
+ * point into the same gathered rows).  sh_degree = the active degree (bands above it get zeros), sh_coeffs = K.
+ * nan_flag (optional) with flag_offset: the float at g_views + v * view_stride + flag_offset of every view is that view's
+ * owner's "my gradients are not finite" mark (non-zero = raised); any raised mark raises *nan_flag -- the ranks' skip-the-step
+ * flags (ghr_adam_step, nan_guard = 2) travel inside the gathered rows instead of through a collective of their own. */
 int ghr_sh_grad_from_views(void* stream, int32_t P, int32_t sh_degree, int32_t sh_coeffs, const float* xyz, int32_t n_views,
-                           const float* campos, const float* g_views, int64_t view_stride, float* d_features_dc,
-                           float* d_features_rest, int32_t accumulate);
+                           const float* campos, int64_t campos_stride, const float* g_views, int64_t view_stride,
+                           float* d_features_dc, float* d_features_rest, int32_t accumulate, int32_t* nan_flag,
+                           int64_t flag_offset);
 
 /* ABI 18.  Strand polylines -> one Gaussian per segment: initialize_gaussians_hair (src/scene/gaussian_model_strands.py:435-452,
  * the same lines in gaussian_model_latent_strands.py), run at the top of every strand-stage iteration

@@ -294,7 +294,7 @@ void ghrsim_sh_grad_from_views(int P, int deg, int K, const float* xyz, int n_vi
     const int row = 3 * (K - 1);
     std::vector<float> tmp((size_t)(row > 0 ? row : 1));
     for (int i = 0; i < P; i++) {
-        ghr::sh_grad_from_views_one(deg, K, xyz + 3 * (size_t)i, n_views, campos, g, (size_t)view_stride, (size_t)i,
+        ghr::sh_grad_from_views_one(deg, K, xyz + 3 * (size_t)i, n_views, campos, 3, g, (size_t)view_stride, (size_t)i,
                                     d_dc + 3 * (size_t)i, tmp.data());
         for (int k = 0; k < row; k++) d_rest[(size_t)i * row + k] = tmp[k];
     }

@@ -1067,6 +1067,7 @@ def test_multi_view_steps_fold_their_sh_gradients_from_per_view_tables_bit_for_b
     make_ground_truth(gt, cams, bg)
     plan = [(cams[:4], False, False), (cams[1:4], False, False), (cams[2:4], False, False), (cams[:4], True, False),
             (cams[2:6], False, True), (cams[:5], False, False)]
+    degrees = [1, 1, 2, 2, 3, 3]  # the active SH degree of each step (the fold must use the step's, bands above it get zeros)
     _lib.lib().ghr_set_deterministic(1)
     saved = optim.FACTORED_SH_REDUCE
     try:
@@ -1079,9 +1080,10 @@ def test_multi_view_steps_fold_their_sh_gradients_from_per_view_tables_bit_for_b
                 o = model.optimizer
                 folds = []
                 orig = o._rebuild_sh_from_views
-                o._rebuild_sh_from_views = lambda g, folds=folds, orig=orig: (folds.append(int(g.shape[0])), orig(g))[1]
+                o._rebuild_sh_from_views = lambda g, folds=folds, orig=orig, **k: (folds.append(int(g.shape[0])), orig(g, **k))[1]
                 trace = []
                 for it, (views, overflow, nan) in enumerate(plan):
+                    model.active_sh_degree = degrees[it]
                     if overflow:
                         dgr._R_RECENT.clear()
                         dgr._R_HINT[dev.index] = 4096

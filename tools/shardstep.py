@@ -41,15 +41,29 @@ def main():
     model.training_setup(opt)
     folds = []
     orig = model.optimizer._rebuild_sh_from_views
-    model.optimizer._rebuild_sh_from_views = lambda g: (folds.append(model.optimizer._views["gather"]), orig(g))[1]
+    model.optimizer._rebuild_sh_from_views = lambda g, **k: (folds.append(model.optimizer._views["gather"]), orig(g, **k))[1]
     for i in range(6):
         training_step(model, [cams[(i * V + j) % 8] for j in range(V)], bg, opt, i + 1, global_views=V)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
         training_step(model, [cams[(i * V + j) % 8] for j in range(V)], bg, opt, 7 + i, global_views=V)
+    t_issue = time.perf_counter()
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / K
+    print("SHARDSTEP host issue %.4f ms per step (the Python side of the step; the step is host-bound when this equals the total)" %
+          (1e3 * (t_issue - t0) / K))
+    if os.environ.get("SHARDSTEP_PROFILE"):
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(K):
+            training_step(model, [cams[(i * V + j) % 8] for j in range(V)], bg, opt, 7 + K + i, global_views=V)
+        torch.cuda.synchronize()
+        pr.disable()
+        st = pstats.Stats(pr)
+        st.sort_stats("cumulative").print_stats(45)
     print("SHARDSTEP views %d  GHR_FACTORED_SH_REDUCE=%s max_views %d  %s: %.4f ms per step" % (
         V, os.environ.get("GHR_FACTORED_SH_REDUCE", "1"), optim.FACTORED_SH_MAX_VIEWS,
         "SH tables %s" % ("gathered" if folds[-1] else "folded on the rank") if folds else "SH gradients accumulated in place", ms))
