@@ -678,6 +678,10 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
                            ProjBwdOut& o, float* cam)
 {
     const int K = a.sh_coeffs;
+    // (the camera-centre cotangents as three SSA values stored ONCE behind the branch: stored into cam[] on both paths the
+    // compiler sank the stores into one with a selected ADDRESS, and the array went to scratch -- 32 B per lane in both CAM
+    // instantiations until round 6)
+    float cpg0 = 0.f, cpg1 = 0.f, cpg2 = 0.f;
     if (radius > 0) {
         const float mx = in.xyz[0], my = in.xyz[1], mz = in.xyz[2];
         const float* gc = ga + 6;  // colours: rgb 0-2
@@ -715,16 +719,14 @@ GHR_HD void project_bwd_sh(const ModelArgs& a, const RawIn& in, int radius, cons
             const float dotp = Ld[0] * x + Ld[1] * y + Ld[2] * z;  // d(normalize)
             const float dd[3] = {(Ld[0] - x * dotp) * il, (Ld[1] - y * dotp) * il, (Ld[2] - z * dotp) * il};
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-                dxyz[m] += dd[m];
-                if (CAM) cam[26 + m] = -dd[m];  // dir = xyz - camera_center (gaussian_renderer/__init__.py:59)
-            }
+            for (int m = 0; m < 3; m++) dxyz[m] += dd[m];
+            cpg0 = -dd[0]; cpg1 = -dd[1]; cpg2 = -dd[2];  // dir = xyz - camera_center (gaussian_renderer/__init__.py:59)
         }
     } else {
         for (int k = 0; k < 3 * (K - 1); k++) d_rest[k] = 0.f;
         o.grgb[0] = o.grgb[1] = o.grgb[2] = 0.f;
-        if (CAM) cam[26] = cam[27] = cam[28] = 0.f;
     }
+    if (CAM) { cam[26] = cpg0; cam[27] = cpg1; cam[28] = cpg2; }
 }
 
 // Writes (or accumulates into) every output element except d_rest, which stays in the caller's staging block.  Returns

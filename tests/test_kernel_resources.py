@@ -69,3 +69,18 @@ def test_marching_loss_and_adam_kernels_stay_within_their_occupancy_steps():
     assert fwd["group_segment_fixed_size"] <= 12288, fwd     # 13 waves per CU
     assert bwd["group_segment_fixed_size"] <= 14336, bwd     # 11
     assert adam["vgpr_count"] <= 64, adam
+
+
+def test_round6_kernels_compile_without_scratch():
+    """k_strand_build / k_strand_build_bwd (dynamic LDS only), k_sh_grad_from_views (48 accumulators + 16 basis values per thread,
+    11.5 KB of LDS) and the four k_project_bwd variants: no scratch, no vector spills."""
+    meta = _descriptors()
+    for sub, vgprs in (("k_strand_build", 128), ("k_strand_build_bwd", 128), ("k_sh_grad_from_views", 168)):
+        ks = [v for k, v in meta.items() if sub in k and (sub != "k_strand_build" or "bwd" not in k)]
+        assert len(ks) == 1, (sub, [k for k in meta if sub in k])
+        k = ks[0]
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= vgprs, (sub, k)
+    pb = [v for k, v in meta.items() if "k_project_bwd" in k]
+    assert len(pb) == 4, [k for k in meta if "k_project_bwd" in k]
+    for k in pb:
+        assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 168, k   # three waves per SIMD
