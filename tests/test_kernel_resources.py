@@ -84,3 +84,14 @@ def test_round6_kernels_compile_without_scratch():
     assert len(pb) == 4, [k for k in meta if "k_project_bwd" in k]
     for k in pb:
         assert k["private_segment_fixed_size"] == 0 and k["vgpr_spill_count"] == 0 and k["vgpr_count"] <= 168, k   # three waves per SIMD
+
+
+def test_no_kernel_of_the_library_uses_scratch():
+    """Every kernel of libghr_hip.so keeps its arrays in registers / LDS: a private segment means an array the compiler could
+    not promote (round 6 found one in both camera-gradient instantiations of k_project_bwd: two stores sunk into one with a
+    selected address) or a vector spill -- on this part a scratch access also counts in vmcnt, which breaks hand-counted waits."""
+    meta = _descriptors()
+    assert len(meta) >= 30
+    bad = {k: v["private_segment_fixed_size"] for k, v in meta.items()
+           if v.get("private_segment_fixed_size", 0) or v.get("vgpr_spill_count", 0)}
+    assert not bad, bad
