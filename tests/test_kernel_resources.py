@@ -16,6 +16,10 @@ import pytest
 from gaussianhaircut_amd import _lib
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=1)
 def _descriptors():
     hipcc = _lib._hipcc()
     if hipcc is None:
