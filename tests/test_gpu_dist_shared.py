@@ -297,7 +297,8 @@ def test_one_rank_on_rccl_through_the_collective_branch_is_bit_identical_to_the_
         assert r["params_equal"] and r["v_equal"] and r["steps"] == (STEPS, STEPS) and r["finite"], "deg %d: %s" % (deg, sorted(r.items()))
         assert r["moved"] > 0
         # every step of the collective branch rebuilt the SH gradients from the views' tables: gathered (3) / folded locally (1)
-        assert res["folds_%d" % deg] == [deg == 3] * STEPS, res["folds_%d" % deg]
+        if os.environ.get("GHR_FACTORED_SH_REDUCE", "1") != "0":
+            assert res["folds_%d" % deg] == [deg == 3] * STEPS, res["folds_%d" % deg]
     assert res["skipped"]
 
 
