@@ -2,6 +2,7 @@
 densification / logging / GUI -- lr schedule, render, losses, backward, [grad all-reduce], NaN guard, Adam."""
 from __future__ import annotations
 
+import functools
 import os
 from types import SimpleNamespace
 from typing import List, Optional
@@ -146,16 +147,6 @@ def _generic_densify_stats(gaussians, pkg, pipe):
         vis = pkg["visibility_filter"]
         gaussians.update_max_radii(pkg["radii"], vis)
         gaussians.add_densification_stats(pkg["viewspace_points"], vis)
-
-
-def training_step(gaussians, cams: List, background, opt, iteration: int, *args, **kwargs):
-    # (this wrapper only makes sure the optimizer's view slots never outlive the step)
-    try:
-        return _training_step(gaussians, cams, background, opt, iteration, *args, **kwargs)
-    finally:
-        o = getattr(gaussians, "optimizer", None)
-        if hasattr(o, "end_factored_views"):
-            o.end_factored_views()
 
 
 def _training_step(gaussians, cams: List, background, opt, iteration: int, bucket: Optional[FlatGradBucket] = None,
@@ -342,7 +333,18 @@ def _training_step(gaussians, cams: List, background, opt, iteration: int, bucke
     return total
 
 
-training_step.__doc__ = _training_step.__doc__  # (the arguments are documented there)
+@functools.wraps(_training_step)
+def training_step(gaussians, cams: List, background, opt, iteration: int, *args, **kwargs):
+    # (this wrapper only makes sure the optimizer's view slots never outlive the step)
+    try:
+        return _training_step(gaussians, cams, background, opt, iteration, *args, **kwargs)
+    finally:
+        o = getattr(gaussians, "optimizer", None)
+        if hasattr(o, "end_factored_views"):
+            o.end_factored_views()
+
+
+training_step.__name__ = training_step.__qualname__ = "training_step"
 
 
 @torch.no_grad()
