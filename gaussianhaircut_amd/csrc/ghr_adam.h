@@ -212,4 +212,51 @@ __global__ void k_adam_finish(int* state, unsigned skip_mask, int n_groups)
     }
 }
 
+// ---- one re-lay of the flat parameter / moment buffers for a densification event (round 6) ---------------------------------
+// The reference's densify_and_prune (src/scene/gaussian_model.py:596-741) clones, splits and prunes by re-creating every
+// nn.Parameter and every Adam state tensor several times (cat_tensors_to_optimizer / _prune_optimizer: boolean-mask gathers).
+// scene/densification.py decides the event on per-row scalars and describes the surviving rows as (source row, fresh?, child?);
+// this kernel then writes the NEW flat buffers in one pass: for every group g (rows of w_g floats, group-major in both
+// layouts) and every new row r
+//   p_out[g][r] = override_g ? override_g[child[r]] (child[r] >= 0) : p_in[g][take[r]]
+//   m_out[g][r] = fresh[r] ? 0 : m_in[g][take[r]]            (clones and split children start with zero moments)
+//   v_out[g][r] likewise
+// ~80 PyTorch launches (index_select / where per group and buffer, then the copies of FusedAdam._rebuild) become one.
+struct RelayArgs {
+    long long P_old, P_new;
+    int n_groups;
+    int width[GHR_ADAM_MAX_GROUPS];           // floats per row of each group
+    long long end_new[GHR_ADAM_MAX_GROUPS];   // exclusive end of each group in the NEW flat layout
+    long long off_old[GHR_ADAM_MAX_GROUPS];   // start of each group in the OLD flat layout
+    const float* override_[GHR_ADAM_MAX_GROUPS];  // optional per group: [n_children, width] rows for child[r] >= 0
+    const long long* take;    // [P_new] source row
+    const unsigned char* fresh;  // [P_new]
+    const long long* child;   // [P_new] or NULL
+    const float* p_in; const float* m_in; const float* v_in;
+    float* p_out; float* m_out; float* v_out;
+};
+
+__global__ void __launch_bounds__(256) k_relay_rows(RelayArgs a)
+{
+    const long long n = a.end_new[a.n_groups - 1];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        int g = 0;
+        while (i >= a.end_new[g]) g++;
+        const long long beg = g == 0 ? 0 : a.end_new[g - 1];
+        const int w = a.width[g];
+        const long long r = (i - beg) / w;
+        const int c = (int)((i - beg) - r * w);
+        const long long src = a.off_old[g] + a.take[r] * w + c;
+        float pv = a.p_in[src];
+        if (a.override_[g] != nullptr && a.child != nullptr) {
+            const long long ch = a.child[r];
+            if (ch >= 0) pv = a.override_[g][ch * w + c];
+        }
+        const bool fr = a.fresh[r] != 0;
+        a.p_out[i] = pv;
+        a.m_out[i] = fr ? 0.f : a.m_in[src];
+        a.v_out[i] = fr ? 0.f : a.v_in[src];
+    }
+}
+
 }  // namespace ghr

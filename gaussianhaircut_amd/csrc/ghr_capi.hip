@@ -906,6 +906,38 @@ int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* 
                                eps, nan_guard, zero_grad, 1, skip_mask);
 }
 
+int ghr_adam_relay_rows(void* stream, int32_t n_groups, const int32_t* width_host, int64_t P_old, int64_t P_new,
+                        const int64_t* take, const uint8_t* fresh, const int64_t* child, const float* const* override_host,
+                        const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out)
+{
+    if (n_groups <= 0 || n_groups > GHR_ADAM_MAX_GROUPS || !width_host || P_old < 0 || P_new < 0)
+        return fail(GHR_E_INVALID, "ghr_adam_relay_rows: bad sizes");
+    if (P_new == 0) return GHR_OK;
+    if (!take || !fresh || !p_in || !m_in || !v_in || !p_out || !m_out || !v_out)
+        return fail(GHR_E_INVALID, "ghr_adam_relay_rows: NULL buffer");
+    ghr::RelayArgs a;
+    a.P_old = P_old; a.P_new = P_new; a.n_groups = n_groups;
+    long long off_old = 0, end_new = 0;
+    for (int g = 0; g < n_groups; g++) {
+        if (width_host[g] <= 0) return fail(GHR_E_INVALID, "ghr_adam_relay_rows: a group without columns");
+        a.width[g] = width_host[g];
+        a.off_old[g] = off_old;
+        off_old += (long long)width_host[g] * P_old;
+        end_new += (long long)width_host[g] * P_new;
+        a.end_new[g] = end_new;
+        a.override_[g] = override_host ? override_host[g] : nullptr;
+        if (a.override_[g] && !child) return fail(GHR_E_INVALID, "ghr_adam_relay_rows: override rows without child indices");
+    }
+    for (int g = n_groups; g < GHR_ADAM_MAX_GROUPS; g++) { a.width[g] = 1; a.off_old[g] = 0; a.end_new[g] = end_new; a.override_[g] = nullptr; }
+    a.take = (const long long*)take; a.fresh = fresh; a.child = (const long long*)child;
+    a.p_in = p_in; a.m_in = m_in; a.v_in = v_in; a.p_out = p_out; a.m_out = m_out; a.v_out = v_out;
+    hipStream_t s = (hipStream_t)stream;
+    const long long blocks_ll = (end_new + 255) / 256;
+    const int blocks = (int)(blocks_ll < 16384 ? blocks_ll : 16384);
+    hipLaunchKernelGGL(ghr::k_relay_rows, dim3(blocks), dim3(256), 0, s, a);
+    return finish(s, 0);
+}
+
 int ghr_adam_nan_scan(void* stream, const float* g, int64_t count, int32_t* state)
 {
     if (count < 0 || !state || (count > 0 && !g)) return fail(GHR_E_INVALID, "ghr_adam_nan_scan: bad args");

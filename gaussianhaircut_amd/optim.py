@@ -220,6 +220,63 @@ class FusedAdam:
         self._skip_next = (1 << len(self.param_groups)) - 1  # every parameter is new: the coming step is a no-op
         return out
 
+    def relay_rows(self, take: torch.Tensor, fresh: torch.Tensor, child: torch.Tensor = None, overrides: Dict = None):
+        """One re-lay of the flat buffers for a densification event (``ghr_adam_relay_rows``): new row r of every group is old
+        row ``take[r]`` -- or row ``child[r]`` of ``overrides[group name]`` where ``child[r] >= 0`` -- with zeroed moments
+        where ``fresh[r]``.  Every group must hold one parameter of shape [P, ...].  Returns {group name: new nn.Parameter}
+        like ``_rebuild`` (whose ~80 index_select / where / copy launches this replaces)."""
+        self.sync_moments()
+        dev = self.flat_param.device
+        P_old = int(self.param_groups[0]["params"][0].shape[0])
+        P_new = int(take.numel())
+        widths, shapes = [], []
+        for g in self.param_groups:
+            p = g["params"][0]
+            assert len(g["params"]) == 1 and p.shape[0] == P_old, "relay_rows: one [P, ...] parameter per group"
+            widths.append(int(p.numel() // max(P_old, 1)) if P_old else int(torch.Size(p.shape[1:]).numel()))
+            shapes.append(tuple(p.shape[1:]))
+        n = sum(widths) * P_new
+        flat_p = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_m = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_v = torch.empty(n, dtype=torch.float32, device=dev)
+        take = take.to(torch.int64).contiguous()
+        fresh = fresh.to(torch.uint8).contiguous()
+        child = None if child is None else child.to(torch.int64).contiguous()
+        keep = []
+        ovr = (ctypes.c_void_p * len(widths))()
+        for i, g in enumerate(self.param_groups):
+            t = (overrides or {}).get(g["name"])
+            if t is not None:
+                t = t.detach().to(torch.float32).contiguous()
+                assert t.numel() == 0 or t.numel() // t.shape[0] == widths[i]
+                keep.append(t)
+                ovr[i] = t.data_ptr() if t.numel() else None
+        w_arr = (ctypes.c_int32 * len(widths))(*widths)
+        with _on_device(dev):
+            _lib.check(_lib.lib().ghr_adam_relay_rows(
+                _stream(), len(widths), w_arr, P_old, P_new, _ptr(take), _ptr(fresh), None if child is None else _ptr(child),
+                ctypes.cast(ovr, ctypes.c_void_p) if keep else None, _ptr(self.flat_param), _ptr(self.exp_avg),
+                _ptr(self.exp_avg_sq), _ptr(flat_p), _ptr(flat_m), _ptr(flat_v)))
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off, ends, out, params = 0, [], {}, []
+        for g, w, shp in zip(self.param_groups, widths, shapes):
+            k = w * P_new
+            p = torch.nn.Parameter(flat_p[off:off + k].view((P_new,) + shp), requires_grad=True)
+            p.grad = self.flat_grad[off:off + k].view((P_new,) + shp)
+            g["params"] = [p]
+            out[g["name"]] = p
+            params.append(p)
+            off += k
+            ends.append(off)
+        self.flat_param, self.exp_avg, self.exp_avg_sq = flat_p, flat_m, flat_v
+        self._fuse = None
+        self._ends = (ctypes.c_int64 * len(ends))(*ends)
+        self.params = params
+        self._mark_zero()
+        self._direct_backwards = 0
+        self._skip_next = (1 << len(self.param_groups)) - 1  # every parameter is new: the coming step is a no-op
+        return out
+
     def _group_views(self):
         self.sync_moments()  # (sharded optimizer: the moments of the other ranks' slices are stale here)
         off = 0

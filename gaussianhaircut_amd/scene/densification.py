@@ -9,11 +9,15 @@ once per operation).  ``densify_and_split`` draws its samples from an optional `
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch import nn
 
 from ..utils.general_utils import build_rotation, inverse_sigmoid
 
+
+RELAY_KERNEL = os.environ.get("GHR_DENSIFY_RELAY_KERNEL", "1") != "0"  # the event's re-lay as one HIP pass
 
 class DensificationMixin:
     # ------------------------------------------------------------------ optimizer surgery
@@ -197,6 +201,17 @@ class DensificationMixin:
         child = rows - (P0 + n_c)                # >= 0 for the children: their place in child_xyz / child_scaling
         is_child = child >= 0
         o = self.optimizer
+        if RELAY_KERNEL and hasattr(o, "relay_rows"):
+            # one HIP pass writes the new flat buffers (optim.FusedAdam.relay_rows / ghr_adam_relay_rows)
+            t = o.relay_rows(take, fresh, child if n_s else None,
+                             {"xyz": child_xyz, "scaling": child_scaling} if n_s else None)
+            self._assign(t)
+            self._orient_conf = t["orient_conf"] if "orient_conf" in t else torch.zeros_like(self._label)
+            P = self.get_xyz.shape[0]
+            self.xyz_gradient_accum = torch.zeros((P, 1), device=dev)
+            self.denom = torch.zeros((P, 1), device=dev)
+            self.max_radii2D = torch.zeros((P,), device=dev)
+            return P
         o.sync_moments()
         ps, ms, vs = [], [], []
         off = 0

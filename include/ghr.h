@@ -395,6 +395,16 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* a, const float* maps, c
  * nan_guard == 1 scans the gradients first, nan_guard == 2 trusts state[1] as maintained by the gradient producer
  * (ghr_model_backward's nan_flag).
  * zero_grad != 0: the gradient buffer is zeroed for the next step. */
+/* ABI 19.  One re-lay of the flat parameter / moment buffers for a densification event (src/scene/gaussian_model.py:596-741:
+ * densify_and_clone, densify_and_split, prune_points with their cat_tensors_to_optimizer / _prune_optimizer re-creations of
+ * every parameter and Adam state tensor).  The buffers are group-major: group g holds P rows of width[g] floats.  For every
+ * group and every NEW row r (P_new of them):  p_out[g][r] = override[g] != NULL && child[r] >= 0 ? override[g][child[r]] :
+ * p_in[g][take[r]];  m_out / v_out[g][r] = fresh[r] ? 0 : m_in / v_in[g][take[r]]  (clones and split children start with zero
+ * moments, gaussian_model.py:634-654).  take, child (nullable; int64) and fresh (uint8) are DEVICE arrays of P_new entries;
+ * width_host and override_host (nullable; n_groups device pointers, each NULL or [n_children, width[g]]) are HOST arrays. */
+int ghr_adam_relay_rows(void* stream, int32_t n_groups, const int32_t* width_host, int64_t P_old, int64_t P_new,
+                        const int64_t* take, const uint8_t* fresh, const int64_t* child, const float* const* override_host,
+                        const float* p_in, const float* m_in, const float* v_in, float* p_out, float* m_out, float* v_out);
 /* ABI 18.  state[1] |= any(isnan(g[0 .. count))): the scan of nan_guard == 1 over a part of the gradients, for a step whose other
  * gradients came from a producer that keeps the flag itself (the strand stage, src/train_strands.py:151-155: the SH features'
  * gradients are assigned by the fused render_hair backward, those of the strand directions arrive through autograd); follow
