@@ -44,14 +44,18 @@ def main():
         cam.original_orient_conf = torch.ones_like(p["orient_conf"]).detach()
         hair._dirs.mul_(1.02)
     hair.training_setup(opt)
+    losses = []
     for i in range(4):
-        strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=pipe)
+        losses.append(strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=pipe))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(K):
-        strand_training_step(head, hair, [cam], bg, opt, 5 + i, pipe=pipe)
+        losses.append(strand_training_step(head, hair, [cam], bg, opt, 5 + i, pipe=pipe))
     t1 = time.perf_counter()
     torch.cuda.synchronize()
+    print("STRAND loss %.5f -> %.5f over %d iterations (%d strand Gaussians), optimizer step %d, skipped-step flag %d" % (
+        float(losses[0]), float(losses[-1]), len(losses), S * n_seg, int(hair.optimizer.state_dev[0]),
+        int(hair.optimizer.state_dev[1])))
     print("STRAND %.3f ms per iteration (host issue %.3f)" % (1e3 * (time.perf_counter() - t0) / K, 1e3 * (t1 - t0) / K))
 
 
