@@ -141,7 +141,7 @@ EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binnin
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
            "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_sh_grad_from_views", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
-           "ghr_adam_step_range", "ghr_adam_nan_scan", "ghr_adam_relay_rows"]
+           "ghr_adam_step_range", "ghr_adam_nan_scan", "ghr_adam_relay_rows", "ghr_adam_fused_finish"]
 
 _lib = None
 
@@ -196,6 +196,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_sh_grad_from_views.argtypes = [vp, i32, i32, i32, vp, i32, vp, ctypes.c_int64, vp, ctypes.c_int64, vp, vp, i32, vp,
                                          ctypes.c_int64]
     L.ghr_adam_relay_rows.argtypes = [vp, i32, vp, ctypes.c_int64, ctypes.c_int64] + [vp] * 10
+    L.ghr_adam_fused_finish.argtypes = [vp, vp]
     L.ghr_adam_nan_scan.argtypes = [vp, vp, ctypes.c_int64, vp]
     L.ghr_strand_build.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp, vp]
     L.ghr_strand_build_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]

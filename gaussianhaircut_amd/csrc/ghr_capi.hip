@@ -531,9 +531,12 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     if (!radii || !geom_ws)
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
     const bool factored_sh = m->d_rgb != nullptr;  // ABI 19: the SH gradients leave as d_rgb, their own buffers may be NULL
-    if (!cam_only && (!d_means2D || !d_xyz || !d_log_scales || !d_rotations || (!factored_sh && !d_features_dc) ||
+    // (the SH gradient buffers may be NULL when nothing is stored there: the factored form, or the update carried by this
+    // call -- ghr_adam_fuse -- without earlier views' gradients to add)
+    const bool sh_unstored = factored_sh || (m->adam_fuse != nullptr && !accumulate);
+    if (!cam_only && (!d_means2D || !d_xyz || !d_log_scales || !d_rotations || (!sh_unstored && !d_features_dc) ||
         (need_act && (!d_opacity_logit || !d_label_logit || !d_orient_conf_log)) ||
-        (!factored_sh && a.sh_coeffs > 1 && !d_features_rest)))
+        (!sh_unstored && a.sh_coeffs > 1 && !d_features_rest)))
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: NULL buffer");
     if (factored_sh && (cam_only || m->adam_fuse))
         return fail(GHR_E_INVALID, "ghr_model_backward_segment: d_rgb with cam_only / adam_fuse");
@@ -568,14 +571,18 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     mg.adam.on = 0;
     const ghr_adam_fuse* af = m->adam_fuse;
     if (af) {
-        if (a.mode != 0 || cam_only) return fail(GHR_E_INVALID, "ghr_adam_fuse: only with mode 0 segments that store gradients");
+        if (cam_only) return fail(GHR_E_INVALID, "ghr_adam_fuse: not with a cam_only segment");
+        if (a.mode == 1 && accumulate) return fail(GHR_E_INVALID, "ghr_adam_fuse: a strand segment carries the update only as the step's single view");
         if (af->n <= 0 || !af->p_in || !af->m_in || !af->v_in || !af->p_out || !af->m_out || !af->v_out || !af->state || !af->flag ||
             !af->flag_next || af->n_groups <= 0 || af->n_groups > GHR_ADAM_MAX_GROUPS || !af->group_end_host || !af->lr_host)
             return fail(GHR_E_INVALID, "ghr_adam_fuse: NULL buffer / bad group table");
         if (nan_flag != af->flag) return fail(GHR_E_INVALID, "ghr_adam_fuse: nan_flag of the backward call must be adam_fuse->flag");
         const float* arrays[GHR_ADAM_FUSE_ARRAYS] = {a.xyz, a.log_scales, a.rotations, a.opacity_logit, a.label_logit,
                                                      a.orient_conf_log, a.features_dc, a.features_rest};
-        const long long width[GHR_ADAM_FUSE_ARRAYS] = {3, 3, 4, 1, 1, 1, 3, 3LL * (a.sh_coeffs - 1)};
+        // (mode 1, a strand segment: only the SH features are raw parameters of the optimizer; the other groups of its flat
+        // buffer -- strand directions, confidence -- get their gradients through autograd and are stepped by the caller)
+        const long long w6 = a.mode == 1 ? 0 : 1;
+        const long long width[GHR_ADAM_FUSE_ARRAYS] = {3 * w6, 3 * w6, 4 * w6, w6, w6, w6, 3, 3LL * (a.sh_coeffs - 1)};
         long long covered = 0;
         for (int k = 0; k < GHR_ADAM_FUSE_ARRAYS; k++) {
             const long long len = width[k] * a.P;
@@ -591,7 +598,8 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
             mg.adam.lr[k] = af->lr_host[gi];
             covered += len;
         }
-        if (covered != af->n) return fail(GHR_E_INVALID, "ghr_adam_fuse: the eight raw-parameter arrays must tile p_in (n floats)");
+        if (a.mode == 0 && covered != af->n)
+            return fail(GHR_E_INVALID, "ghr_adam_fuse: the eight raw-parameter arrays must tile p_in (n floats)");
         mg.adam.p_base = af->p_in; mg.adam.m_in = af->m_in; mg.adam.v_in = af->v_in;
         mg.adam.p_out = af->p_out; mg.adam.m_out = af->m_out; mg.adam.v_out = af->v_out;
         mg.adam.state = af->state; mg.adam.beta1 = af->beta1; mg.adam.beta2 = af->beta2; mg.adam.eps = af->eps;
@@ -607,11 +615,25 @@ int ghr_model_backward_segment(void* stream, const ghr_model_args* m, int32_t ro
     if (af) {
         if (mg.cam_partial) hipLaunchKernelGGL((ghr::k_project_bwd<true, true>), grid, block, 0, s, a, mg);
         else hipLaunchKernelGGL((ghr::k_project_bwd<false, true>), grid, block, 0, s, a, mg);
-        hipLaunchKernelGGL(ghr::k_adam_fused_finish, dim3(1024), dim3(256), 0, s, (long long)af->n, af->p_in, af->m_in, af->v_in,
-                           af->p_out, af->m_out, af->v_out, af->state, (const int*)af->flag, af->flag_next);
+        // (a strand segment leaves the finish to the caller -- ghr_adam_fused_finish -- who first steps the groups whose
+        // gradients are still on their way through autograd and adds their non-finite mark to the step's flag)
+        if (a.mode == 0)
+            hipLaunchKernelGGL(ghr::k_adam_fused_finish, dim3(1024), dim3(256), 0, s, (long long)af->n, af->p_in, af->m_in,
+                               af->v_in, af->p_out, af->m_out, af->v_out, af->state, (const int*)af->flag, af->flag_next);
     } else if (mg.cam_partial) hipLaunchKernelGGL((ghr::k_project_bwd<true, false>), grid, block, 0, s, a, mg);
     else hipLaunchKernelGGL((ghr::k_project_bwd<false, false>), grid, block, 0, s, a, mg);
     return finish(s, m->debug);
+}
+
+int ghr_adam_fused_finish(void* stream, const ghr_adam_fuse* af)
+{
+    if (!af || af->n < 0 || !af->p_in || !af->m_in || !af->v_in || !af->p_out || !af->m_out || !af->v_out || !af->state ||
+        !af->flag || !af->flag_next)
+        return fail(GHR_E_INVALID, "ghr_adam_fused_finish: bad ghr_adam_fuse");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ghr::k_adam_fused_finish, dim3(1024), dim3(256), 0, s, (long long)af->n, af->p_in, af->m_in, af->v_in,
+                       af->p_out, af->m_out, af->v_out, af->state, (const int*)af->flag, af->flag_next);
+    return finish(s, 0);
 }
 
 int32_t ghr_camera_slots(int32_t P) { return P > 0 ? (P + GHR_PBW_BLOCK - 1) / GHR_PBW_BLOCK : 0; }

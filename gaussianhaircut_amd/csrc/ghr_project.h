@@ -785,6 +785,32 @@ GHR_HD bool project_bwd_store(const ModelArgs& a, const ModelGrads& g, int idx, 
         for (int i = 0; i < n; i++) v[i] += old[i];
     }
     bool bad = false;
+    if (in != nullptr && g.adam.on && a.mode == 1) {
+        // ---- strand segment (round 6): of this Gaussian's raw values only the SH features are parameters of the optimizer --
+        // position, scale, rotation, direction, confidence are functions of the strand polylines, their gradients go on
+        // through autograd (ghr_strand_build_backward) and are stored as usual.  The DC colour is updated here, the higher
+        // bands by slab_out_adam.
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            if (p[i]) {
+                *p[i] = v[i];
+                bad |= nonfinite(v[i]);
+            }
+        const AdamFuse& f = g.adam;
+        const float w1 = (float)(1.0 - f.beta1), w2 = (float)(1.0 - f.beta2), bt2 = (float)f.beta2;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const ptrdiff_t off = (a.features_dc + 3 * (size_t)idx + i) - f.p_base;
+            float pp = in->dc[i], mm = f.m_in[off], vv = f.v_in[off];
+            const float gv = v[16 + i];
+            bad |= nonfinite(gv);
+            adam_update(pp, gv, mm, vv, ss[6], w1, bt2, w2, f.eps, b2[6]);
+            f.p_out[off] = pp;
+            f.m_out[off] = mm;
+            f.v_out[off] = vv;
+        }
+        return bad;
+    }
     if (in != nullptr && g.adam.on) {
         // ---- the optimizer update instead of the gradient stores (mode 0: sixteen values in six arrays + the DC colour).  The
         // gradient is what the store below would have left in the flat buffer; the parameter is the raw value this thread loaded

@@ -235,7 +235,8 @@ def render_hair(viewpoint_camera, pc, pc_hair, pipe, bg_color: torch.Tensor, sca
     if _use_fused_hair(pc, pc_hair, pipe, viewpoint_camera):
         from .fused import render_hair_fused
         renders, radii, screenspace_points = render_hair_fused(viewpoint_camera, pc, pc_hair, bg_color,
-                                                               scaling_modifier, getattr(pipe, "debug", False))
+                                                               scaling_modifier, getattr(pipe, "debug", False),
+                                                               fuse_adam=bool(getattr(pipe, "fuse_adam", False)))
         return _package(renders, screenspace_points, radii)
     head = pc.mask_precomp
     conic = torch.cat([pc.get_conic(viewpoint_camera, scaling_modifier)[head],

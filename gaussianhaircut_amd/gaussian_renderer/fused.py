@@ -415,11 +415,21 @@ class _RenderHairFused(torch.autograd.Function):
                 # (a buffer left undefined by step(zero_grad="defer") is only made whole by a backward that assigns EVERY
                 # group; this one assigns two of four: the others would be accumulated into garbage)
                 sink.resolve_deferred()
-            direct = (sink is not None and n_hair > 0 and all(
+            leaves_ok = (sink is not None and n_hair > 0 and all(
+                isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous() and
+                t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.sh_leaves))
+            # The optimizer update of the SH features inside this backward (round 6: trainer.strand_training_step opened a fused
+            # step, FusedAdam.begin_fused_step): the kernel reads their moments and writes parameters + moments of the other
+            # buffer set instead of 192 B of gradient per Gaussian for a separate Adam pass to read back; the caller finishes the
+            # step once autograd has delivered the strand directions' gradients (finish_fused_step_with_late_groups)
+            fuse = bool(leaves_ok and cfg.get("fuse_adam") and getattr(sink, "_fuse_step", None) is not None)
+            direct = (not fuse and sink is not None and n_hair > 0 and all(
                 isinstance(t, torch.nn.Parameter) and t.requires_grad and t.grad is not None and t.grad.is_contiguous() and
                 t.grad.dtype == torch.float32 and t.grad.shape == t.shape for t in ctx.sh_leaves) and sink.take_known_zero())
             if direct:
                 d_fdc, d_frest = ctx.sh_leaves[0].grad, ctx.sh_leaves[1].grad
+            elif fuse:
+                d_fdc = d_frest = None
             else:
                 d_fdc, d_frest = torch.empty((n_hair, 1, 3), **f32), torch.empty((n_hair, K - 1, 3), **f32)
             scratch = getattr(ctx, "scratch", None)  # made (and zeroed) by the forward pass when it knew of a backward
@@ -431,6 +441,12 @@ class _RenderHairFused(torch.autograd.Function):
             hair = dict(xyz=xyz, scaling=scaling, rotation=rotation, dir=dirs, conf=conf, fdc=fdc, frest=frest)
             cam_t = [view, proj, campos, bg, ctx.fov]
             m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, cam_t, cfg, cfg["eps_hair"], (1.0, 1.0, 0.0))
+            if fuse:
+                # (the kernel finds the parameters' moments through the offsets of the RAW parameter arrays inside the flat
+                # buffer: the saved copies are the leaves' own storage -- .detach().float().contiguous() of a contiguous fp32
+                # parameter is a view)
+                m_hair.features_dc, m_hair.features_rest = _ptr(ctx.sh_leaves[0].data), _ptr(ctx.sh_leaves[1].data)
+                m_hair.adam_fuse = ctypes.addressof(sink._fuse_step["args"])
             want_cam = any(ctx.needs_input_grad[8:13])
             cam_partial = None
             if want_cam and rows > 0:
@@ -450,11 +466,16 @@ class _RenderHairFused(torch.autograd.Function):
             if n_hair > 0:
                 _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
                                                         _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
-                                                        _ptr(d_rot), None, None, _ptr(d_conf), _ptr(d_fdc), _ptr(d_frest),
-                                                        _ptr(d_dir), 0, sink.nan_flag_ptr() if direct else None,
+                                                        _ptr(d_rot), None, None, _ptr(d_conf),
+                                                        None if fuse else _ptr(d_fdc), None if fuse else _ptr(d_frest),
+                                                        _ptr(d_dir), 0, sink.nan_flag_ptr() if (direct or fuse) else None,
                                                         scratch.shape[0], _ptr(binb), ctx.cap))
             d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
             d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:13], dev, ctx.fov) if want_cam else (None,) * 5
+        if fuse:
+            sink.note_direct_backward()
+            sink.note_fused_update()
+            return (d_xyz, d_sc, d_rot, d_dir, d_conf, None, None, d_m2d) + d_cam + (None, None)
         if direct:
             sink.note_direct_backward()
             return (d_xyz, d_sc, d_rot, d_dir, d_conf, None, None, d_m2d) + d_cam + (None, None)
@@ -478,7 +499,7 @@ def head_segment(pc):
     return cache[1]
 
 
-def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
+def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug, fuse_adam=False):
     """Returns (renders[10,H,W], radii[n_head + n_hair], screenspace_points leaf)."""
     import math
     head = head_segment(pc)
@@ -494,6 +515,7 @@ def render_hair_fused(cam, pc, pc_hair, bg_color, scaling_modifier, debug):
     opt = getattr(pc_hair, "optimizer", None)
     if isinstance(opt, FusedAdam) and opt.direct_grads and torch.is_grad_enabled():
         cfg["grad_sink"] = opt
+        cfg["fuse_adam"] = bool(fuse_adam)
     renders, radii = _RenderHairFused.apply(xyz, pc_hair.get_scaling, pc_hair._rotation, pc_hair._dir,
                                             pc_hair.get_orient_conf, pc_hair._features_dc, pc_hair._features_rest,
                                             screenspace_points, view, proj, campos, fovx, fovy, head, cfg)

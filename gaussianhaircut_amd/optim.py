@@ -494,9 +494,42 @@ class FusedAdam:
         """The step's last backward has launched the update (gaussian_renderer.fused)."""
         self._fuse_step["done"] = True
 
-    def end_fused_step(self) -> bool:
+    def finish_fused_step_with_late_groups(self, late_groups):
+        """A step whose update was carried by a STRAND segment's backward (``ghr_adam_fuse`` with mode 1: only the SH features are
+        updated by the kernel): the groups in ``late_groups`` got their gradients through autograd, after the kernel.  Their
+        NaN mark joins the step's flag, their ranges of the ``out`` set are brought up to date (copy + ``ghr_adam_step_range`` on
+        the ``out`` buffers, guarded by the flag, gradients zeroed), then ``k_adam_fused_finish`` decides for everything."""
+        st, f = self._fuse_step, self._fuse
+        a = st["args"]
+        lib = _lib.lib()
+        n = self.flat_param.numel()
+        ranges, off = [], 0
+        for g in self.param_groups:
+            k = sum(p.numel() for p in g["params"])
+            if g["name"] in late_groups and k:
+                ranges.append((off, k))
+            off += k
+        par = f["parity"]
+        with _on_device(self.flat_param.device):
+            for o, k in ranges:  # (ghr_adam_nan_scan raises state[1]: the step's flag word is passed as state + 1)
+                _lib.check(lib.ghr_adam_nan_scan(_stream(), ctypes.c_void_p(self.flat_grad.data_ptr() + 4 * o), k,
+                                                 ctypes.c_void_p(int(a.flag) - 4)))
+            self.state_dev[1:2].copy_(f["flags"][par:par + 1])
+            for o, k in ranges:
+                f["p"][o:o + k].copy_(self.flat_param[o:o + k])
+                f["m"][o:o + k].copy_(self.exp_avg[o:o + k])
+                f["v"][o:o + k].copy_(self.exp_avg_sq[o:o + k])
+                _lib.check(lib.ghr_adam_step_range(_stream(), n, o, k, _ptr(f["p"]), _ptr(self.flat_grad), _ptr(f["m"]),
+                                                   _ptr(f["v"]), _ptr(self.state_dev), len(self.param_groups), self._ends,
+                                                   st["lrs"], self.betas[0], self.betas[1], self.eps, 2, 1, 0, 0))
+            self.state_dev[1:2].zero_()
+            _lib.check(lib.ghr_adam_fused_finish(_stream(), ctypes.byref(a)))
+
+    def end_fused_step(self, grads_zero: bool = False) -> bool:
         """After the views: True when the update was carried by the last backward -- the two buffer sets then swap roles and
-        the parameters are re-pointed (host work only); False: nothing happened, the caller steps the usual way."""
+        the parameters are re-pointed (host work only); False: nothing happened, the caller steps the usual way.
+        ``grads_zero``: the gradient buffer holds zeros afterwards (the strand-stage form: the SH ranges were never written,
+        the late groups' were zeroed by their update) instead of being undefined."""
         st, self._fuse_step = self._fuse_step, None
         f = self._fuse
         if st is None or not st["done"]:
@@ -523,7 +556,10 @@ class FusedAdam:
         self._direct_backwards = 0
         self._acc_event = None
         self._skip_next = 0
-        self._after_step(False, True)  # the gradient buffer was neither zeroed nor written: undefined until the next backward
+        if grads_zero:
+            self._after_step(True, False)
+        else:
+            self._after_step(False, True)  # the gradient buffer was neither zeroed nor written: undefined until the next backward
         self.fused_steps += 1
         return True
 

@@ -30,6 +30,7 @@ def _one_like(loss):
 
 OVERLAP_ALL_REDUCE_WITH_ADAM = os.environ.get("GHR_OVERLAP_AR_ADAM", "1") != "0"
 # One rank, fused path: the step's LAST projection backward applies the optimizer update itself (optim.FusedAdam.begin_fused_step)
+FUSE_STRAND_ADAM = os.environ.get("GHR_FUSE_STRAND_ADAM", "1") != "0"  # strand stage: the SH features' update in the backward
 FUSE_ADAM_INTO_BACKWARD = os.environ.get("GHR_FUSE_ADAM", "1") != "0"
 DEFER_GRAD_ZEROING = os.environ.get("GHR_DEFER_GRAD_ZEROING", "1") != "0"
 CACHE_GT_SSIM_STATS = True  # keep the SSIM window moments of every camera's ground truth (2*3*H*W floats per camera)
@@ -407,19 +408,42 @@ def strand_view_loss(render_pkg, cam, opt, fused=None, scale: float = 1.0):
 def strand_training_step(gaussians, gaussians_hair, cams: List, background, opt, iteration: int, pipe=PIPE):
     """One iteration of the strand stage (src/train_strands.py:98-160): rebuild the strand Gaussians from the strand
     parameters, render head + hair, loss, backward, NaN guard on the strand parameters, Adam."""
-    from .gaussian_renderer import render_hair
+    from .gaussian_renderer import _use_fused_hair, render_hair
+    from .optim import FusedAdam
     gaussians_hair.initialize_gaussians_hair()
     gaussians_hair.update_learning_rate(iteration)
     V = len(cams)
     losses = []
-    for cam in cams:
-        pkg = render_hair(cam, gaussians, gaussians_hair, pipe, background)
-        loss = strand_view_loss(pkg, cam, opt, scale=1.0 / V)
-        loss.backward(gradient=_one_like(loss))
-        losses.append(loss.detach())
-        if cam is not cams[-1]:
-            gaussians_hair.initialize_gaussians_hair()  # a fresh graph for the next view
-    from .optim import FusedAdam
+    # One view, FusedAdam, the fused render_hair path: the optimizer update of the SH features (48 of the 52 floats per strand
+    # Gaussian) rides in the projection backward (ghr_adam_fuse, strand segment): no 192 B of gradient per Gaussian written
+    # for an Adam pass to read back.  The strand directions' and the confidence's gradients arrive through autograd after
+    # that kernel; they are stepped -- and their NaN mark is added to the step's flag -- before the step is finished on the
+    # device (FusedAdam.finish_fused_step_with_late_groups), which undoes everything when the flag is up.
+    o = gaussians_hair.optimizer if isinstance(getattr(gaussians_hair, "optimizer", None), FusedAdam) else None
+    fuse = bool(FUSE_STRAND_ADAM and o is not None and V == 1 and o.direct_grads and o.can_fuse_step() and
+                not getattr(pipe, "debug", False) and _use_fused_hair(gaussians, gaussians_hair, pipe, cams[0]) and
+                all(g["name"] in ("xyz", "f_dc", "f_rest", "orient_conf") for g in o.param_groups))
+    run_pipe = pipe
+    if fuse:
+        o.resolve_deferred()
+        o.begin_fused_step()
+        run_pipe = SimpleNamespace(**{**vars(pipe), "fuse_adam": True})
+    fused_done = False
+    try:
+        for cam in cams:
+            pkg = render_hair(cam, gaussians, gaussians_hair, run_pipe, background)
+            loss = strand_view_loss(pkg, cam, opt, scale=1.0 / V)
+            loss.backward(gradient=_one_like(loss))
+            losses.append(loss.detach())
+            if cam is not cams[-1]:
+                gaussians_hair.initialize_gaussians_hair()  # a fresh graph for the next view
+        if fuse and o._fuse_step["done"]:
+            o.finish_fused_step_with_late_groups([g["name"] for g in o.param_groups if g["name"] not in ("f_dc", "f_rest")])
+    finally:
+        if fuse:
+            fused_done = o.end_fused_step(grads_zero=True)
+    if fused_done:
+        return losses[0]
     if isinstance(gaussians_hair.optimizer, FusedAdam):
         o = gaussians_hair.optimizer
         if o._direct_backwards == V and V > 0:

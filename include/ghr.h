@@ -258,6 +258,15 @@ typedef struct ghr_adam_fuse {
     double beta1, beta2;
     float eps;
 } ghr_adam_fuse;
+/* ABI 19: a strand segment (mode 1, render_hair(): src/train_strands.py:98-160) may carry the update too, as the step's single
+ * view (accumulate == 0).  Of its raw values only features_dc / features_rest are parameters of the optimizer's flat buffer
+ * (the other groups there -- strand directions, confidence: gaussian_model_strands.py:578-589 -- receive their gradients through
+ * autograd, after this call): the kernel updates those two arrays into the `out` set, stores every other gradient as usual
+ * (d_features_dc / d_features_rest may be NULL) and launches NO finish kernel.  The caller then (1) adds the non-finite mark
+ * of the late gradients to *flag (ghr_adam_nan_scan with state = flag - 1), (2) brings the remaining ranges of the `out` set up
+ * to date (copy in -> out, ghr_adam_step_range on the `out` buffers with nan_guard = 2 and state[1] = *flag), (3) calls
+ * ghr_adam_fused_finish: the same k_adam_fused_finish as above (out := in for everything when the flag is up, step counter). */
+int ghr_adam_fused_finish(void* stream, const ghr_adam_fuse* adam_fuse);
 
 /* Stage 1 of the fused path: replaces ghr_forward_stage1 (then call ghr_forward_stage2 with a ghr_view_args that
  * carries P, W, H, C and background; every other field may be NULL).  means2D_out [P,3] (NDC) may be NULL. */

@@ -497,11 +497,18 @@ def test_strand_training_step_learns_on_gpu():
 
 
 def test_strand_stage_direct_sh_gradients_match_autograd_accumulation():
-    """Round 6: the fused render_hair backward ASSIGNS the SH-feature gradients of a strand model whose optimizer is a
-    FusedAdam straight into its (known-zero) gradient buffer and raises the optimizer's non-finite flag itself;
-    strand_training_step then steps without the scan over every parameter.  Same parameters after three iterations as with
-    autograd's accumulation (direct_grads off), a second view of the same step accumulates the classic way, and a NaN that
-    reaches the strand directions only through autograd still skips the update."""
+    """Round 6, three forms of the strand-stage iteration (src/train_strands.py:98-160) with FusedAdam, the same parameters bit
+    for bit after every one of five iterations:
+      fused    -- the SH features' update rides in the render_hair backward (ghr_adam_fuse, strand segment); directions and
+                  confidence are stepped when autograd has delivered their gradients; the step is finished on the device;
+      direct   -- the backward ASSIGNS the SH-feature gradients into the optimizer's (known-zero) buffer and raises its flag;
+                  the step scans only the autograd-fed groups;
+      autograd -- the gradients are returned and accumulated by autograd; the step scans everything.
+    A two-view step takes the classic road in all three; a NaN that only autograd carries (into the strand directions) skips
+    the update in all three and the next iteration goes through again."""
+    import copy
+    from gaussianhaircut_amd import _lib as ghr_lib
+    from gaussianhaircut_amd import trainer
     from gaussianhaircut_amd.gaussian_renderer import render_hair
     from gaussianhaircut_amd.scene.gaussian_model import OptimizationParams
     from gaussianhaircut_amd.trainer import strand_training_step
@@ -510,12 +517,13 @@ def test_strand_stage_direct_sh_gradients_match_autograd_accumulation():
     opt = OptimizationParams()
     opt.lambda_dorient, opt.lambda_dmask = 0.1, 0.1
     bg = syn.background(dev)
-    from gaussianhaircut_amd import _lib as ghr_lib
     lib = ghr_lib.lib()
     lib.ghr_set_deterministic(1)
+    saved = trainer.FUSE_STRAND_ADAM
     try:
         res = {}
-        for direct in (True, False):
+        for mode in ("fused", "direct", "autograd"):
+            trainer.FUSE_STRAND_ADAM = mode == "fused"
             spec, head, hair, cam = _hair_scene(dev)
             _, _, gt_hair, _ = _hair_scene(dev)
             with torch.no_grad():
@@ -529,31 +537,42 @@ def test_strand_stage_direct_sh_gradients_match_autograd_accumulation():
                 cam.original_orient_conf = torch.ones_like(pkg["orient_conf"]).detach()
             hair.training_setup(opt, fused=True)
             o = hair.optimizer
-            o.direct_grads = direct
+            o.direct_grads = mode != "autograd"
             seen = []
             step0 = o.step
             o.step = lambda *a, **k: (seen.append(k.get("nan_scan", True)), step0(*a, **k))[1]
+            params = lambda: [p.detach().clone() for p in (hair._dirs, hair._features_dc, hair._features_rest, hair._orient_conf)]
+            trace = []
             for i in range(3):
                 strand_training_step(head, hair, [cam], bg, opt, i + 1, pipe=FUSED)
-            import copy
+                trace.append(params())
             strand_training_step(head, hair, [cam, copy.copy(cam)], bg, opt, 4, pipe=FUSED)  # the second view accumulates
-            assert seen == ([False] * 3 + [True] if direct else [True] * 4), seen
-            res[direct] = [p.detach().clone() for p in (hair._dirs, hair._features_dc, hair._features_rest, hair._orient_conf)]
-            if direct:
-                # a NaN that only autograd carries (into the strand directions): flag raised by the small check, update skipped
-                before = [t.clone() for t in res[direct]]
-                h = hair._dirs.register_hook(lambda g: torch.full_like(g, float("nan")))
-                strand_training_step(head, hair, [cam], bg, opt, 5, pipe=FUSED)
-                h.remove()
-                assert seen[-1] is False
-                for a, b in zip(before, (hair._dirs, hair._features_dc, hair._features_rest, hair._orient_conf)):
-                    assert torch.equal(a, b.detach())
-                assert float(o.flat_grad.abs().max()) == 0.0
-                strand_training_step(head, hair, [cam], bg, opt, 6, pipe=FUSED)  # and the next one goes through again
-                assert not torch.equal(before[1], hair._features_dc.detach())
-        for a, b in zip(res[True], res[False]):
-            assert torch.equal(a, b)
+            trace.append(params())
+            # a NaN that only autograd carries (into the strand directions): the update is skipped, nothing moves
+            h = hair._dirs.register_hook(lambda g: torch.full_like(g, float("nan")))
+            strand_training_step(head, hair, [cam], bg, opt, 5, pipe=FUSED)
+            h.remove()
+            torch.cuda.synchronize()
+            for x, y in zip(trace[-1], params()):
+                assert torch.equal(x, y), mode
+            assert int(o.state_dev[0]) == 4 and int(o.state_dev[1]) == 0 and float(o.flat_grad.abs().max()) == 0.0, mode
+            strand_training_step(head, hair, [cam], bg, opt, 6, pipe=FUSED)  # and the next one goes through again
+            trace.append(params())
+            assert not torch.equal(trace[-2][1], trace[-1][1]) and int(o.state_dev[0]) == 5, mode
+            if mode == "fused":
+                assert seen == [True] and o.fused_steps == 5, (seen, o.fused_steps)   # only the two-view step called step()
+                assert hair._dirs.data_ptr() == o.flat_param.data_ptr()                # the parameters alias the CURRENT set
+            elif mode == "direct":
+                assert seen == [False, False, False, True, False, False] and o.fused_steps == 0, seen
+            else:
+                assert seen == [True] * 6, seen
+            res[mode] = trace
+        for mode in ("direct", "autograd"):
+            for it, (ta, tb) in enumerate(zip(res["fused"], res[mode])):
+                for x, y in zip(ta, tb):
+                    assert torch.equal(x, y), (mode, it, float((x - y).abs().max()))
     finally:
+        trainer.FUSE_STRAND_ADAM = saved
         lib.ghr_set_deterministic(0)
 
 
