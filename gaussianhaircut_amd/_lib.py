@@ -26,7 +26,7 @@ CAM_PARTIALS = 32  # GHR_CAM_PARTIALS: rows of the camera-gradient partial table
 CAM_GRADS = 37     # GHR_CAM_GRADS: d view[16] | d proj[16] | d camera_center[3] | d tanfov[2]
 STRAND_MAX_SEG = 2048  # GHR_STRAND_MAX_SEG: longest strand ghr_strand_build takes
 ADAM_STATE = 18  # GHR_ADAM_STATE
-ABI_VERSION = 19  # GHR_ABI_VERSION of include/ghr.h this binding was written for
+ABI_VERSION = 20  # GHR_ABI_VERSION of include/ghr.h this binding was written for
 
 GHR_OK, GHR_E_INVALID, GHR_E_NOCOLORS, GHR_E_HIP = 0, -1, -2, -3
 
@@ -141,7 +141,7 @@ EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binnin
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
            "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_sh_grad_from_views", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
-           "ghr_adam_step_range", "ghr_adam_nan_scan", "ghr_adam_relay_rows", "ghr_adam_fused_finish"]
+           "ghr_adam_step_range", "ghr_adam_step_range_to", "ghr_adam_nan_scan", "ghr_adam_relay_rows", "ghr_adam_fused_finish"]
 
 _lib = None
 
@@ -186,6 +186,8 @@ def lib() -> ctypes.CDLL:
     L.ghr_adam_step_range.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, vp, vp, vp, i32,
                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double,
                                       ctypes.c_double, f32, i32, i32, i32, u32]
+    L.ghr_adam_step_range_to.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64] + [vp] * 9 + [
+        i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, u32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp, i32]
     L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]

@@ -34,6 +34,13 @@ struct AdamArgs {
     double beta1, beta2;  // double like torch's Python-side scalars: 1 - beta^step cancels badly in fp32
     float eps;
     int zero_grad;
+    // ABI 20 (ghr_adam_step_range_to): out-of-place form.  p_in != NULL: p, m, v are READ from p_in / m_in / v_in and written to
+    // p / m / v (same offsets; an element that takes no update is copied).  flag != NULL: the skip-the-step word is *flag
+    // instead of state[1] (a fused step's own flag word, ghr_adam_fuse).
+    const float* p_in;
+    const float* m_in;
+    const float* v_in;
+    const int* flag;
 };
 
 // state[1] |= any(isnan(g)).  grid-stride.
@@ -62,7 +69,11 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
     // per group: step size lr / (1 - beta1^t) and sqrt(1 - beta2^t) with t = the group's own step number (torch keeps a
     // step counter per parameter: a group that sat out a step -- skip_mask -- lags the others from then on)
     __shared__ float s_ss[GHR_ADAM_MAX_GROUPS], s_b2[GHR_ADAM_MAX_GROUPS];
-    const int skip = a.state[1];
+    const int skip = a.flag ? *a.flag : a.state[1];
+    const bool oop = a.p_in != nullptr;
+    const float* pi = oop ? a.p_in : a.p;
+    const float* mi = oop ? a.m_in : a.m;
+    const float* vi = oop ? a.v_in : a.v;
     if ((int)threadIdx.x < a.n_groups) {
         const int step = a.state[0] + 1 - a.state[2 + threadIdx.x];  // this update's step number for the group
         const double bias1 = 1.0 - pow(a.beta1, (double)step);
@@ -72,14 +83,16 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
     __syncthreads();
     const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
     for (long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
+        bool upd = false;
+        int gi = 0;
         if (!skip) {
-            int gi = 0;
             while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;
-            if (!((a.skip_mask >> gi) & 1u)) {
-                float p = a.p[i], m = a.m[i], v = a.v[i];
-                adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
-                a.p[i] = p; a.m[i] = m; a.v[i] = v;
-            }
+            upd = !((a.skip_mask >> gi) & 1u);
+        }
+        if (upd || oop) {
+            float p = pi[i], m = mi[i], v = vi[i];
+            if (upd) adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+            a.p[i] = p; a.m[i] = m; a.v[i] = v;
         }
         if (a.zero_grad) a.g[i] = 0.f;
     }
@@ -93,7 +106,11 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
 __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
 {
     __shared__ float s_ss[GHR_ADAM_MAX_GROUPS], s_b2[GHR_ADAM_MAX_GROUPS];
-    const int skip = a.state[1];
+    const int skip = a.flag ? *a.flag : a.state[1];
+    const bool oop = a.p_in != nullptr;
+    const float* pi = oop ? a.p_in : a.p;
+    const float* mi = oop ? a.m_in : a.m;
+    const float* vi = oop ? a.v_in : a.v;
     if ((int)threadIdx.x < a.n_groups) {
         const int step = a.state[0] + 1 - a.state[2 + threadIdx.x];
         const double bias1 = 1.0 - pow(a.beta1, (double)step);
@@ -106,16 +123,20 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
         const long long i = a.begin + 4 * q;
+        int g0 = 0, g3 = 0;
+        bool any = false;
         if (!skip) {
-            int g0 = 0, g3 = 0;
             while (g0 < a.n_groups - 1 && i >= a.end[g0]) g0++;
             g3 = g0;
             while (g3 < a.n_groups - 1 && i + 3 >= a.end[g3]) g3++;
-            const bool any = g0 != g3 || !((a.skip_mask >> g0) & 1u);
+            any = g0 != g3 || !((a.skip_mask >> g0) & 1u);
+        }
+        if (any || oop) {
+            const f4 P = __builtin_nontemporal_load(reinterpret_cast<const f4*>(pi + i)), M = __builtin_nontemporal_load(reinterpret_cast<const f4*>(mi + i)),
+                     V = __builtin_nontemporal_load(reinterpret_cast<const f4*>(vi + i));
+            float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
             if (any) {
-                const f4 P = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.p + i)), M = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.m + i)),
-                         V = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.v + i)), G = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g + i));
-                float pp[4] = {P.x, P.y, P.z, P.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
+                const f4 G = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g + i));
                 const float gg[4] = {G.x, G.y, G.z, G.w};
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -123,10 +144,10 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
                     if (g0 != g3) while (gi < a.n_groups - 1 && i + e >= a.end[gi]) gi++;
                     if (!((a.skip_mask >> gi) & 1u)) adam_update(pp[e], gg[e], mm[e], vv[e], s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
                 }
-                __builtin_nontemporal_store(f4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f4*>(a.p + i));
-                __builtin_nontemporal_store(f4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f4*>(a.m + i));
-                __builtin_nontemporal_store(f4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f4*>(a.v + i));
             }
+            __builtin_nontemporal_store(f4{pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<f4*>(a.p + i));
+            __builtin_nontemporal_store(f4{mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<f4*>(a.m + i));
+            __builtin_nontemporal_store(f4{vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<f4*>(a.v + i));
         }
         if (a.zero_grad) __builtin_nontemporal_store(zero, reinterpret_cast<f4*>(a.g + i));
     }
@@ -134,14 +155,16 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
     if (blockIdx.x == 0 && threadIdx.x < 4) {
         const long long i = a.begin + 4 * n4 + threadIdx.x;
         if (i < a.n) {
+            bool upd = false;
+            int gi = 0;
             if (!skip) {
-                int gi = 0;
                 while (gi < a.n_groups - 1 && i >= a.end[gi]) gi++;
-                if (!((a.skip_mask >> gi) & 1u)) {
-                    float p = a.p[i], m = a.m[i], v = a.v[i];
-                    adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
-                    a.p[i] = p; a.m[i] = m; a.v[i] = v;
-                }
+                upd = !((a.skip_mask >> gi) & 1u);
+            }
+            if (upd || oop) {
+                float p = pi[i], m = mi[i], v = vi[i];
+                if (upd) adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+                a.p[i] = p; a.m[i] = m; a.v[i] = v;
             }
             if (a.zero_grad) a.g[i] = 0.f;
         }

@@ -21,6 +21,9 @@ namespace ghr {
 #define GHR_SORT_BIG_CAP 8192   // keys per LDS block of k_tile_sort_big (64 KiB)
 #define GHR_SORT_BIG_BLOCK 1024
 #define GHR_SORT_BIG_MIN_AVG 256  // k_tile_sort_big is launched when the lists average at least this many instances
+#define GHR_SORT_MID_CAP 4096   // k_tile_sort_mid (round 6): lists of GHR_SORT_CAP + 1 .. this many keys (34.8 KiB of LDS)
+#define GHR_SORT_MID_BLOCK 512
+#define GHR_SORT_WALK_MAX 64    // tiles one workgroup of the dense-tile kernels may have to look at (grid >= T / this)
 #define GHR_SORT_DONE 0xffffffffu  // tile_cursor value k_tile_sort_big leaves for k_tile_sort: "this tile is sorted"
 #define GHR_SORT_BLOCK 128  // two waves per tile (round 5; 256 threads and a barrier per step before)
 #define GHR_SORT_SOLO 256u  // lists up to this long are sorted by wave 0 alone
@@ -774,19 +777,70 @@ GHR_HD void bitonic_disperse_from(KeyPtr k, uint32_t n, uint32_t count, uint32_t
     GHR_SYNC();
 }
 
-__global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T, const uint32_t* __restrict__ tile_start,
+#if defined(__HIP_DEVICE_COMPILE__)
+// The tiles blockIdx.x, blockIdx.x + gridDim.x, ... whose list length lies in (lo, hi], found in ONE round trip (thread t looks
+// at the t-th of them) and listed in LDS; returns their number.  (Round 6: the dense-tile kernels walked their tiles one
+// dependent pair of loads at a time -- 16 of them, ~1 us each, in front of the first key at 1080p.)  Needs T <= gridDim.x *
+// GHR_SORT_WALK_MAX (the host sizes the grid).
+__device__ __forceinline__ uint32_t dense_tiles_of_workgroup(uint32_t T, const uint32_t* __restrict__ tile_start, uint32_t cap,
+                                                             uint32_t lo, uint32_t hi, uint32_t* s_list, uint32_t* s_cnt)
+{
+    if (threadIdx.x == 0) *s_cnt = 0u;
+    __syncthreads();
+    const uint32_t tile = blockIdx.x + threadIdx.x * gridDim.x;
+    if (threadIdx.x < GHR_SORT_WALK_MAX && tile < T) {
+        const uint32_t s = min(tile_start[tile], cap);
+        const uint32_t n = min(tile_start[tile + 1], cap) - s;
+        if (n > lo && n <= hi) s_list[atomicAdd(s_cnt, 1u)] = tile;
+    }
+    __syncthreads();
+    return *s_cnt;
+}
+#endif
+
+// Lists of GHR_SORT_CAP + 1 .. GHR_SORT_MID_CAP keys (round 6).  k_tile_sort_big gives such a tile 1024 threads, 64 KiB of LDS
+// and one barrier per compare-exchange step -- two workgroups per CU, most of their threads without a pair to exchange; at
+// 2 M strand Gaussians (BASELINE configs[4]) and in the strand stage most dense tiles are of this size and the kernel took
+// 207 / 269 us per view.  Here: 512 threads, the register-blocked network of k_tile_sort (8 keys per thread between two LDS
+// trips: 26 passes for 2048 keys where the per-step form takes 66 steps), 34.8 KiB of LDS: three workgroups per CU.
+__global__ void __launch_bounds__(GHR_SORT_MID_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) k_tile_sort_mid(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                                    uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                                    uint32_t* tile_cursor, const rect4* __restrict__ rects,
                                                                    uint32_t* inst_line, int gx)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ uint64_t s_keys[GHR_SORT_BIG_CAP];
-    const int tid = threadIdx.x;
-    constexpr uint32_t B = GHR_SORT_BIG_CAP;
-    for (uint32_t tile = blockIdx.x; tile < T; tile += gridDim.x) {
+    static_assert((GHR_SORT_MID_BLOCK << 3) == GHR_SORT_MID_CAP, "8 keys per thread");
+    __shared__ uint64_t s_keys[GHR_SORT_MID_CAP + GHR_SORT_MID_CAP / 16 + 1];
+    __shared__ uint32_t s_list[GHR_SORT_WALK_MAX], s_cnt;
+    const uint32_t cnt = dense_tiles_of_workgroup(T, tile_start, cap, GHR_SORT_CAP, GHR_SORT_MID_CAP, s_list, &s_cnt);
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t tile = s_list[k];
         const uint32_t s = min(tile_start[tile], cap);
         const uint32_t n = min(tile_start[tile + 1], cap) - s;
-        if (n <= GHR_SORT_CAP) continue;  // workgroup-uniform
+        __syncthreads();  // (the previous tile's keys have left LDS)
+        tile_sort_group<3, GHR_SORT_MID_BLOCK>(keys + s, n, s, s_keys, point_list, inst_line, rects, (int)(tile % (uint32_t)gx),
+                                               (int)(tile / (uint32_t)gx), cap, (int)threadIdx.x);
+        if (threadIdx.x == 0) tile_cursor[T + tile] = GHR_SORT_DONE;
+    }
+#endif
+}
+
+// `min_n`: lists up to this long are somebody else's (GHR_SORT_CAP, or GHR_SORT_MID_CAP behind k_tile_sort_mid)
+__global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T, const uint32_t* __restrict__ tile_start,
+                                                                   uint64_t* keys, uint32_t* point_list, uint32_t cap,
+                                                                   uint32_t* tile_cursor, const rect4* __restrict__ rects,
+                                                                   uint32_t* inst_line, int gx, uint32_t min_n)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ uint64_t s_keys[GHR_SORT_BIG_CAP];
+    __shared__ uint32_t s_list[GHR_SORT_WALK_MAX], s_cnt;
+    const int tid = threadIdx.x;
+    constexpr uint32_t B = GHR_SORT_BIG_CAP;
+    const uint32_t n_dense = dense_tiles_of_workgroup(T, tile_start, cap, min_n, 0xffffffffu, s_list, &s_cnt);
+    for (uint32_t kk = 0; kk < n_dense; kk++) {
+        const uint32_t tile = s_list[kk];
+        const uint32_t s = min(tile_start[tile], cap);
+        const uint32_t n = min(tile_start[tile + 1], cap) - s;
         uint64_t* g = keys + s;
         const uint32_t nb = (n + B - 1) / B;
         // every block on its own: the network's steps up to size B

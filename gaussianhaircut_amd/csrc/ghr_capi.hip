@@ -305,9 +305,19 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         // then passes those by.  R is the capacity here, an upper bound of the count: a guess that is too high only
         // costs an idle 3-us launch.
         const bool dense = (size_t)R >= (size_t)GHR_SORT_BIG_MIN_AVG * (size_t)T;
-        if (dense)
-            hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(512), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
-                               im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
+        if (dense) {
+            // (round 6) lists of 1025 .. 4096 keys by 512-thread workgroups with the register-blocked network, longer ones
+            // by the 1024-thread kernel; a workgroup looks at up to GHR_SORT_WALK_MAX tiles
+            const unsigned walk = (unsigned)((T + GHR_SORT_WALK_MAX - 1) / GHR_SORT_WALK_MAX);
+            uint32_t big_min = GHR_SORT_CAP;
+            if (std::getenv("GHR_NO_SORT_MID") == nullptr) {
+                hipLaunchKernelGGL(ghr::k_tile_sort_mid, dim3(std::max(768u, walk)), dim3(GHR_SORT_MID_BLOCK), 0, s, (uint32_t)T,
+                                   im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
+                big_min = GHR_SORT_MID_CAP;
+            }
+            hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(std::max(512u, walk)), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
+                               im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, big_min);
+        }
         hipLaunchKernelGGL(ghr::k_tile_sort<1024>, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
                            im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx,
                            order_ptr(im.tile_order, 0));
@@ -885,10 +895,40 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
     return finish(s, 0);
 }
 
+namespace {
+int adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
+                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, const int32_t* flag,
+                    int32_t n_groups, const int64_t* group_end_host, const float* lr_host, double beta1, double beta2,
+                    float eps, int32_t nan_guard, int32_t zero_grad, int32_t last, uint32_t skip_mask);
+}
+
 int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, float* p, float* g, float* m, float* v,
                         int32_t* state, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
                         double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last,
                         uint32_t skip_mask)
+{
+    return adam_step_range(stream, n, begin, count, nullptr, nullptr, nullptr, p, g, m, v, state, nullptr, n_groups,
+                           group_end_host, lr_host, beta1, beta2, eps, nan_guard, zero_grad, last, skip_mask);
+}
+
+int ghr_adam_step_range_to(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
+                           const float* v_in, float* p_out, float* g, float* m_out, float* v_out, int32_t* state,
+                           const int32_t* flag, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
+                           double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask)
+{
+    if (!p_in || !m_in || !v_in) return fail(GHR_E_INVALID, "ghr_adam_step_range_to: NULL input buffer");
+    if (p_in == p_out || m_in == m_out || v_in == v_out)
+        return fail(GHR_E_INVALID, "ghr_adam_step_range_to: in and out buffers must differ (ghr_adam_step_range updates in place)");
+    // (nan_guard 2: whoever produced the gradients keeps the flag; last 0: the caller's own finish advances the counter)
+    return adam_step_range(stream, n, begin, count, p_in, m_in, v_in, p_out, g, m_out, v_out, state, flag, n_groups,
+                           group_end_host, lr_host, beta1, beta2, eps, 2, zero_grad, 0, skip_mask);
+}
+
+namespace {
+int adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
+                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, const int32_t* flag,
+                    int32_t n_groups, const int64_t* group_end_host, const float* lr_host, double beta1, double beta2,
+                    float eps, int32_t nan_guard, int32_t zero_grad, int32_t last, uint32_t skip_mask)
 {
     if (n < 0 || begin < 0 || count < 0 || begin + count > n || !p || !g || !m || !v || !state || n_groups <= 0 ||
         n_groups > GHR_ADAM_MAX_GROUPS || !group_end_host || !lr_host)
@@ -901,11 +941,13 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
         a.begin = begin; a.n = begin + count; a.p = p; a.g = g; a.m = m; a.v = v; a.state = state; a.n_groups = n_groups;
         for (int i = 0; i < n_groups; i++) { a.end[i] = group_end_host[i]; a.lr[i] = lr_host[i]; }
         a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad; a.skip_mask = skip_mask;
+        a.p_in = p_in; a.m_in = m_in; a.v_in = v_in; a.flag = flag;
         const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
         if (nan_guard == 1)
             hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);
         // four elements per thread where the range and the buffers allow 16-B accesses (GHR_ADAM_SCALAR: the scalar kernel)
-        const bool v4 = (begin & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15u) == 0 &&
+        const bool v4 = (begin & 3) == 0 && ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) |
+                                              ((uintptr_t)p_in) | ((uintptr_t)m_in) | ((uintptr_t)v_in)) & 15u) == 0 &&
                         std::getenv("GHR_ADAM_SCALAR") == nullptr;
         if (v4) {
             const long long n4 = (count + 3) / 4;
@@ -919,6 +961,7 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
     if (last && n > 0) hipLaunchKernelGGL(ghr::k_adam_finish, dim3(1), dim3(64), 0, s, state, skip_mask, n_groups);
     return finish(s, 0);
 }
+}  // namespace
 
 int ghr_adam_step(void* stream, int64_t n, float* p, float* g, float* m, float* v, int32_t* state, int32_t n_groups,
                   const int64_t* group_end_host, const float* lr_host, double beta1, double beta2, float eps,

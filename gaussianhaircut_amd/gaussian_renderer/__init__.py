@@ -219,14 +219,25 @@ def render(viewpoint_camera, pc, pipe, bg_color: torch.Tensor, scaling_modifier=
     return _package(renders, screenspace_points, radii)
 
 
+def _has(obj, name: str) -> bool:
+    """``hasattr`` that does not EVALUATE a property: ``hasattr(pc_hair, "get_orient_conf")`` runs the property -- an exp kernel
+    over every strand Gaussian plus its autograd node, twice per strand-stage iteration (round 6: tools/strand_torch_profile.py)."""
+    if name in getattr(obj, "__dict__", ()):
+        return True
+    cls = type(obj)
+    if hasattr(cls, name):
+        return True
+    return hasattr(cls, "__getattr__") and hasattr(obj, name)  # (classes that answer attributes dynamically, e.g. nn.Module)
+
+
 def _use_fused_hair(pc, pc_hair, pipe, cam=None) -> bool:
     """Fused strand-stage path: a free-Gaussian head with its ``*_precomp`` attributes (``src/train_strands.py:65-73``) and a
     strand model exposing the explicit per-Gaussian quantities of ``src/scene/gaussian_model_strands.py:230-452`` (``_dir``,
     ``get_scaling``, ``_rotation``, ``get_orient_conf``, SH features) on a ROCm device; constant or trainable camera."""
-    hair_ok = all(hasattr(pc_hair, n) for n in ("_dir", "_rotation", "_features_dc", "_features_rest", "get_scaling",
-                                                  "get_orient_conf", "get_xyz", "active_sh_degree"))
-    head_ok = is_free_gaussian_model(pc) and all(hasattr(pc, n) for n in ("xyz_precomp", "opacity_precomp", "scaling_precomp",
-                                                                           "rotation_precomp", "mask_precomp", "shs_view"))
+    hair_ok = all(_has(pc_hair, n) for n in ("_dir", "_rotation", "_features_dc", "_features_rest", "get_scaling",
+                                               "get_orient_conf", "get_xyz", "active_sh_degree"))
+    head_ok = is_free_gaussian_model(pc) and all(_has(pc, n) for n in ("xyz_precomp", "opacity_precomp", "scaling_precomp",
+                                                                        "rotation_precomp", "mask_precomp", "shs_view"))
     return bool(getattr(pipe, "fused_projection", True) and hair_ok and head_ok and pc_hair.get_xyz.is_cuda)
 
 

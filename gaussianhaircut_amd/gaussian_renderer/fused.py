@@ -295,6 +295,14 @@ def camera_inputs(cam):
     return view, proj, campos, None, None, _tan_half(fx), _tan_half(fy)
 
 
+def _ptr_rows(t, rows: int, row_bytes: int):
+    """Base pointer of a per-row array displaced by `rows` rows (may point in front of the allocation: the library only touches
+    the rows of the segment it is called for, which lie inside; include/ghr.h, segmented form)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + rows * row_bytes)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # Strand stage: render_hair() = frozen head Gaussians + strand Gaussians (reference gaussian_renderer/__init__.py:116-214)
 # as TWO segments of one rasterizer state, both projected by the fused kernel in its explicit mode (include/ghr.h,
@@ -342,8 +350,16 @@ class _RenderHairFused(torch.autograd.Function):
         cam_t.append((fovx.detach().float().contiguous(), fovy.detach().float().contiguous()) if fovx is not None else None)
         with _on_device(dev):
             color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+            # The reference's per-Gaussian outputs are indexed [head rows, strand rows] WITHOUT the alignment padding between the
+            # two segments.  The library indexes radii / means2D_out / d_means2D by workspace row (row0 + i), so the strand
+            # segment is handed base pointers displaced by the padding (include/ghr.h allows it): the kernels then write the
+            # compact arrays themselves -- three torch.cat, a copy and a 37-MB zero-fill per iteration before (round 6).
+            # (radii keeps `rows` entries: the head segment zero-fills its padding rows there, the strand kernel overwrites them)
+            pad = row0 - n_head
             radii_ws = torch.empty((rows,), dtype=torch.int32, device=dev)
-            m2d_ws = torch.empty((rows, 3), dtype=torch.float32, device=dev)
+            m2d = screenspace_points.detach()
+            if not (m2d.is_contiguous() and m2d.dtype == torch.float32 and tuple(m2d.shape) == (n_head + n_hair, 3)):
+                raise RuntimeError("render_hair: screenspace_points must be a contiguous fp32 [n_head + n_hair, 3] tensor")
             gbytes, ibytes = _lib.forward_sizes(rows, W, H, False)
             geom = torch.empty((gbytes,), dtype=torch.uint8, device=dev)
             img = torch.empty((ibytes,), dtype=torch.uint8, device=dev)
@@ -351,9 +367,9 @@ class _RenderHairFused(torch.autograd.Function):
             m_hair = _seg_args(n_hair, row0, W, H, cfg["sh_degree"], K, hair, cam_t, cfg, cfg["eps_hair"], (1.0, 1.0, 0.0))
             pinned = _pinned(dev)
             _lib.check(L.ghr_model_forward_segment(_stream(), ctypes.byref(m_head), rows, 1, _ptr(geom), _ptr(img),
-                                                   _ptr(radii_ws), _ptr(m2d_ws)))
+                                                   _ptr(radii_ws), _ptr(m2d)))
             _lib.check(L.ghr_model_forward_segment(_stream(), ctypes.byref(m_hair), rows, 0, _ptr(geom), _ptr(img),
-                                                   _ptr(radii_ws), _ptr(m2d_ws)))
+                                                   _ptr_rows(radii_ws, -pad, 4), _ptr_rows(m2d, -pad, 12)))
             _lib.check(L.ghr_model_forward_finish(_stream(), rows, W, H, int(bool(cfg["debug"])), _ptr(geom), _ptr(img),
                                                   ctypes.c_void_p(pinned.data_ptr())))
             va = _lib.ViewArgs()
@@ -373,9 +389,7 @@ class _RenderHairFused(torch.autograd.Function):
                 return b, sc
 
             R, cap, (binb, ctx.scratch) = run_stage2(dev, rows, pinned, launch)
-            # the reference's outputs are indexed by [head rows, strand rows] without the alignment padding
-            radii = torch.cat([radii_ws[:n_head], radii_ws[row0:]])
-            screenspace_points.detach().copy_(torch.cat([m2d_ws[:n_head], m2d_ws[row0:]]))
+            radii = radii_ws[:n_head + n_hair]
         LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(rows)
         ctx.cfg, ctx.R, ctx.K, ctx.cap, ctx.dims = cfg, R, K, cap, (n_head, n_hair, row0, rows)
         ctx.scratch_clean = ctx.scratch is not None
@@ -402,7 +416,10 @@ class _RenderHairFused(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros((NUM_CHANNELS, H, W), **f32)
         with _on_device(dev):
-            d_m2d_ws = torch.zeros((rows, 3), **f32)   # head rows keep 0: the head is frozen
+            pad = row0 - n_head
+            d_m2d = torch.empty((n_head + n_hair, 3), **f32)  # compact [head rows, strand rows]; see forward
+            if n_head > 0:
+                d_m2d[:n_head].zero_()  # the head is frozen
             d_xyz, d_sc = torch.empty((n_hair, 3), **f32), torch.empty((n_hair, 3), **f32)
             d_rot, d_dir = torch.empty((n_hair, 4), **f32), torch.empty((n_hair, 3), **f32)
             d_conf = torch.empty((n_hair, 1), **f32)
@@ -464,13 +481,12 @@ class _RenderHairFused(torch.autograd.Function):
                                                         _ptr(scratch), None, None, None, None, None, None, None, None, None,
                                                         None, 0, None, scratch.shape[0], _ptr(binb), ctx.cap))
             if n_hair > 0:
-                _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr(radii_ws), _ptr(geom),
-                                                        _ptr(scratch), _ptr(d_m2d_ws), _ptr(d_xyz), _ptr(d_sc),
+                _lib.check(L.ghr_model_backward_segment(_stream(), ctypes.byref(m_hair), rows, _ptr_rows(radii_ws, -pad, 4),
+                                                        _ptr(geom), _ptr(scratch), _ptr_rows(d_m2d, -pad, 12), _ptr(d_xyz), _ptr(d_sc),
                                                         _ptr(d_rot), None, None, _ptr(d_conf),
                                                         None if fuse else _ptr(d_fdc), None if fuse else _ptr(d_frest),
                                                         _ptr(d_dir), 0, sink.nan_flag_ptr() if (direct or fuse) else None,
                                                         scratch.shape[0], _ptr(binb), ctx.cap))
-            d_m2d = torch.cat([d_m2d_ws[:n_head], d_m2d_ws[row0:]])
             d_cam = _camera_grads(cam_partial, ctx.cam_meta, ctx.needs_input_grad[8:13], dev, ctx.fov) if want_cam else (None,) * 5
         if fuse:
             sink.note_direct_backward()

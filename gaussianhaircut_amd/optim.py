@@ -497,8 +497,8 @@ class FusedAdam:
     def finish_fused_step_with_late_groups(self, late_groups):
         """A step whose update was carried by a STRAND segment's backward (``ghr_adam_fuse`` with mode 1: only the SH features are
         updated by the kernel): the groups in ``late_groups`` got their gradients through autograd, after the kernel.  Their
-        NaN mark joins the step's flag, their ranges of the ``out`` set are brought up to date (copy + ``ghr_adam_step_range`` on
-        the ``out`` buffers, guarded by the flag, gradients zeroed), then ``k_adam_fused_finish`` decides for everything."""
+        NaN mark joins the step's flag, their ranges of the ``out`` set are written by ``ghr_adam_step_range_to`` (in set -> out set,
+        guarded by the flag, gradients zeroed), then ``k_adam_fused_finish`` decides for everything."""
         st, f = self._fuse_step, self._fuse
         a = st["args"]
         lib = _lib.lib()
@@ -514,15 +514,15 @@ class FusedAdam:
             for o, k in ranges:  # (ghr_adam_nan_scan raises state[1]: the step's flag word is passed as state + 1)
                 _lib.check(lib.ghr_adam_nan_scan(_stream(), ctypes.c_void_p(self.flat_grad.data_ptr() + 4 * o), k,
                                                  ctypes.c_void_p(int(a.flag) - 4)))
-            self.state_dev[1:2].copy_(f["flags"][par:par + 1])
+            # (ABI 20: one out-of-place pass per range -- in set -> out set, skipped under the step's own flag word -- where
+            # rounds up to 6 copied p, m, v across, stepped in place and moved the flag through state[1]: six 12-36 MB copies
+            # and three one-word kernels per iteration at the reference's 30 000 strands)
             for o, k in ranges:
-                f["p"][o:o + k].copy_(self.flat_param[o:o + k])
-                f["m"][o:o + k].copy_(self.exp_avg[o:o + k])
-                f["v"][o:o + k].copy_(self.exp_avg_sq[o:o + k])
-                _lib.check(lib.ghr_adam_step_range(_stream(), n, o, k, _ptr(f["p"]), _ptr(self.flat_grad), _ptr(f["m"]),
-                                                   _ptr(f["v"]), _ptr(self.state_dev), len(self.param_groups), self._ends,
-                                                   st["lrs"], self.betas[0], self.betas[1], self.eps, 2, 1, 0, 0))
-            self.state_dev[1:2].zero_()
+                _lib.check(lib.ghr_adam_step_range_to(_stream(), n, o, k, _ptr(self.flat_param), _ptr(self.exp_avg),
+                                                      _ptr(self.exp_avg_sq), _ptr(f["p"]), _ptr(self.flat_grad), _ptr(f["m"]),
+                                                      _ptr(f["v"]), _ptr(self.state_dev), ctypes.c_void_p(int(a.flag)),
+                                                      len(self.param_groups), self._ends, st["lrs"], self.betas[0],
+                                                      self.betas[1], self.eps, 1, 0))
             _lib.check(lib.ghr_adam_fused_finish(_stream(), ctypes.byref(a)))
 
     def end_fused_step(self, grads_zero: bool = False) -> bool:

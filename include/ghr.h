@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define GHR_ABI_VERSION 19
+#define GHR_ABI_VERSION 20
 #define GHR_NUM_CHANNELS 10 /* R:cuda_rasterizer/config.h:15 */
 #define GHR_TILE 16         /* R:cuda_rasterizer/config.h:16-17 (BLOCK_X, BLOCK_Y) */
 #define GHR_ADAM_STATE 18  /* ints of the fused Adam's device state */
@@ -264,7 +264,8 @@ typedef struct ghr_adam_fuse {
  * autograd, after this call): the kernel updates those two arrays into the `out` set, stores every other gradient as usual
  * (d_features_dc / d_features_rest may be NULL) and launches NO finish kernel.  The caller then (1) adds the non-finite mark
  * of the late gradients to *flag (ghr_adam_nan_scan with state = flag - 1), (2) brings the remaining ranges of the `out` set up
- * to date (copy in -> out, ghr_adam_step_range on the `out` buffers with nan_guard = 2 and state[1] = *flag), (3) calls
+ * to date (ghr_adam_step_range_to with flag, ABI 20; or: copy in -> out, ghr_adam_step_range on the `out` buffers with
+ * nan_guard = 2 and state[1] = *flag), (3) calls
  * ghr_adam_fused_finish: the same k_adam_fused_finish as above (out := in for everything when the flag is up, step counter). */
 int ghr_adam_fused_finish(void* stream, const ghr_adam_fuse* adam_fuse);
 
@@ -283,7 +284,12 @@ int ghr_model_forward_stage1(void* stream, const ghr_model_args* m, void* geom_w
  * rasterizer state of rows_total rows (workspaces sized with ghr_forward_sizes(rows_total, ...); radii / means2D_out
  * [rows_total(,3)]).  Call ghr_model_forward_segment for every segment (first != 0 on the first), then
  * ghr_model_forward_finish (tile scan + *R_host), then ghr_forward_stage2 with P = rows_total as usual.  Rows between
- * the end of a segment and the next multiple of 256 are culled padding. */
+ * the end of a segment and the next multiple of 256 are culled padding.
+ * radii / means2D_out (and d_means2D below) are the caller's per-row arrays and are indexed by workspace row, row0 + i: a call
+ * touches the rows of ITS segment only (plus, in radii, the zero-fill of the padding rows behind it), so a caller that wants
+ * its outputs without the padding -- the reference's [head rows, strand rows] indexing -- may hand a later segment base
+ * pointers displaced by the padding in front of it (round 6: the Python side does; the three arrays are then written compact,
+ * earlier segments first).  The same displaced `radii` must be passed to that segment's ghr_model_backward_segment. */
 int ghr_model_forward_segment(void* stream, const ghr_model_args* m, int32_t rows_total, int32_t first, void* geom_ws,
                               void* img_ws, int32_t* radii, float* means2D_out);
 int ghr_model_forward_finish(void* stream, int32_t rows_total, int32_t W, int32_t H, int32_t debug, void* geom_ws,
@@ -430,6 +436,17 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
                         int32_t* state, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
                         double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last,
                         uint32_t skip_mask);
+
+/* ABI 20.  ghr_adam_step_range OUT OF PLACE: p, m, v of [begin, begin + count) are read from the *_in buffers and written to
+ * the *_out buffers (same offsets; an element that takes no update -- flag up, or its group in skip_mask -- is copied), the
+ * gradients zeroed when zero_grad != 0.  flag != NULL: the skip-the-step word is *flag instead of state[1].  The step counter is
+ * not advanced.  For the late groups of a fused step (ghr_adam_fuse, strand segment: the strand directions' and the
+ * confidence's gradients arrive through autograd after the kernel that carried the SH features' update): their ranges of the
+ * `out` set are produced by ONE pass each instead of three copies and an in-place pass (src/train_strands.py:151-160). */
+int ghr_adam_step_range_to(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
+                           const float* v_in, float* p_out, float* g, float* m_out, float* v_out, int32_t* state,
+                           const int32_t* flag, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
+                           double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask);
 
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     L = _lib.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.ghr_abi_version() == _lib.ABI_VERSION == 19
+    assert L.ghr_abi_version() == _lib.ABI_VERSION == 20
 
 
 def test_workspace_sizes_and_error_codes():

@@ -101,11 +101,14 @@ def test_render_hair_fused_vs_oracle_chain_at_strand_stage_size(oracle_mod, cam)
     ins = inspect_fused(pg.renders_packed, rows, W, H, R)
 
     # ---- K1 state of both segments; padding rows culled
+    # (round 6: the per-row arrays the caller sees -- radii, NDC means -- are written WITHOUT the padding between the segments,
+    # through displaced base pointers, include/ghr.h; the workspace rows themselves keep it: the padding rects are culled)
     radii_ws = ins["radii"]
-    assert (radii_ws[n_head:row0] == 0).all() and (ins["rects"][n_head:row0, :2] == 0).all(), "padding rows not culled"
+    assert radii_ws.shape[0] == rows and (ins["rects"][n_head:row0, :2] == 0).all(), "padding rows not culled"
     P = n_head + n_hair
-    radii_g = np.concatenate([radii_ws[:n_head], radii_ws[row0:]])
+    radii_g = radii_ws[:P]
     assert np.array_equal(radii_g, pg["radii"].cpu().numpy())
+    assert (radii_g[n_head:] > 0).mean() > 0.3, "strand radii missing from the compact array"
     radii_c = pc["radii"].numpy()
     rect_c = np.zeros((P, 4), np.int64)
     rect_c[idx] = _rects(st.xy.astype(np.float32), st.radii.astype(np.int64), W, H)

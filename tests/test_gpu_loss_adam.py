@@ -141,6 +141,67 @@ def test_chunked_adam_equals_whole_buffer_adam_bit_for_bit(chunks):
     assert int(whole.state_dev[0]) == 3 and int(whole.state_dev[1]) == 0   # three applied steps, one skipped
 
 
+@pytest.mark.parametrize("begin,count", [(0, 9003), (9003, 9003), (9004, 3000), (63021, 12004), (9003 + 1, 45015 + 3)])
+def test_out_of_place_adam_range_equals_copy_plus_in_place_range_bit_for_bit(begin, count, monkeypatch):
+    """ghr_adam_step_range_to (ABI 20: p, m, v read from one buffer set, written to another; the late groups of a fused strand
+    step) against what it replaces -- three copies in -> out and ghr_adam_step_range on the out buffers: the same bits in the
+    range, nothing touched outside it, gradients zeroed alike; with the step's own flag word up (and with a group in
+    skip_mask) the range is copied, not updated.  Vector and scalar kernels, aligned and unaligned ranges."""
+    import ctypes
+    from gaussianhaircut_amd import _lib
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    L = _lib.lib()
+    sizes = [9003, 9003, 45015, 3001, 12004]
+    n = sum(sizes)
+    ends = (ctypes.c_int64 * len(sizes))(*[sum(sizes[:i + 1]) for i in range(len(sizes))])
+    lrs = (ctypes.c_float * len(sizes))(1.6e-4, 2.5e-3, 1.25e-4, 0.05, 1e-3)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("GHR_ADAM_SCALAR", "1")
+        for flag_up, skip_mask in ((0, 0), (1, 0), (0, 0b00101)):
+            p_in = torch.randn(n, generator=g).to(dev)
+            m_in, v_in = (torch.randn(n, generator=g) * 0.01).to(dev), (torch.rand(n, generator=g) * 1e-3).to(dev)
+            grad = torch.randn(n, generator=g).to(dev)
+            state = torch.zeros(_lib.ADAM_STATE, dtype=torch.int32, device=dev)
+            state[0] = 6
+            flag = torch.tensor([flag_up], dtype=torch.int32, device=dev)
+            junk = [torch.full((n,), 7.0, device=dev) for _ in range(6)]
+            # reference: copy + in-place range (the skip word moved through state[1])
+            po, mo, vo = junk[0], junk[1], junk[2]
+            po[begin:begin + count].copy_(p_in[begin:begin + count])
+            mo[begin:begin + count].copy_(m_in[begin:begin + count])
+            vo[begin:begin + count].copy_(v_in[begin:begin + count])
+            g_ref, st_ref = grad.clone(), state.clone()
+            st_ref[1] = flag_up
+            _lib.check(L.ghr_adam_step_range(stream, n, begin, count, ptr(po), ptr(g_ref), ptr(mo), ptr(vo), ptr(st_ref), len(sizes),
+                                             ends, lrs, 0.9, 0.999, 1e-15, 2, 1, 0, skip_mask))
+            # out of place
+            pt, mt, vt = junk[3], junk[4], junk[5]
+            g_new, st_new = grad.clone(), state.clone()
+            _lib.check(L.ghr_adam_step_range_to(stream, n, begin, count, ptr(p_in), ptr(m_in), ptr(v_in), ptr(pt), ptr(g_new),
+                                                ptr(mt), ptr(vt), ptr(st_new), ptr(flag), len(sizes), ends, lrs, 0.9, 0.999, 1e-15,
+                                                1, skip_mask))
+            torch.cuda.synchronize()
+            for a, b, src in ((po, pt, p_in), (mo, mt, m_in), (vo, vt, v_in)):
+                assert torch.equal(a, b), (scalar, flag_up, skip_mask)
+                if flag_up:
+                    assert torch.equal(b[begin:begin + count], src[begin:begin + count])
+                elif skip_mask == 0:
+                    assert not torch.equal(b[begin:begin + count], src[begin:begin + count])
+                assert float((b[:begin] - 7.0).abs().sum()) == 0.0 and float((b[begin + count:] - 7.0).abs().sum()) == 0.0
+            assert torch.equal(g_ref, g_new) and float(g_new[begin:begin + count].abs().sum()) == 0.0
+            assert torch.equal(st_new, state)   # neither the counter nor state[1] is touched
+    # in == out is refused (that is ghr_adam_step_range)
+    t = torch.zeros(8, device=dev)
+    st = torch.zeros(18, dtype=torch.int32, device=dev)
+    rc = L.ghr_adam_step_range_to(stream, 8, 0, 8, ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(st), None, 1,
+                                  (ctypes.c_int64 * 1)(8), (ctypes.c_float * 1)(0.1), 0.9, 0.999, 1e-15, 1, 0)
+    assert rc != 0 and b"must differ" in L.ghr_last_error()
+
+
 def _torch_stage1(renders, gt_image, gt_mask, gt_angle, gt_oconf, w):
     """The reference's loss code path on the packed output (gaussian_renderer/__init__.py:100-105 +
     train_gaussians.py:126-140), PyTorch autograd."""
