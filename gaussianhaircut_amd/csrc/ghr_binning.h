@@ -782,13 +782,26 @@ GHR_HD void bitonic_disperse_from(KeyPtr k, uint32_t n, uint32_t count, uint32_t
 // at the t-th of them) and listed in LDS; returns their number.  (Round 6: the dense-tile kernels walked their tiles one
 // dependent pair of loads at a time -- 16 of them, ~1 us each, in front of the first key at 1080p.)  Needs T <= gridDim.x *
 // GHR_SORT_WALK_MAX (the host sizes the grid).
+// `tile_order` (k_tile_scan's heaviest-first order per XCD, may be NULL; `order_len` entries): the workgroup takes every
+// (gridDim.x / 8)-th entry of its XCD's list instead -- every list of 1008 keys and more sits at the front of those lists (one
+// weight class), so the dense tiles are dealt out evenly, where the strided walk over the raster order hands a workgroup
+// anything between none and six of them (they cluster in the image: the hair).  Then gridDim.x must be a multiple of 8.
 __device__ __forceinline__ uint32_t dense_tiles_of_workgroup(uint32_t T, const uint32_t* __restrict__ tile_start, uint32_t cap,
-                                                             uint32_t lo, uint32_t hi, uint32_t* s_list, uint32_t* s_cnt)
+                                                             uint32_t lo, uint32_t hi, const uint32_t* __restrict__ tile_order,
+                                                             uint32_t order_len, uint32_t* s_list, uint32_t* s_cnt)
 {
     if (threadIdx.x == 0) *s_cnt = 0u;
     __syncthreads();
-    const uint32_t tile = blockIdx.x + threadIdx.x * gridDim.x;
-    if (threadIdx.x < GHR_SORT_WALK_MAX && tile < T) {
+    uint32_t tile = 0xffffffffu;
+    if (threadIdx.x < GHR_SORT_WALK_MAX) {
+        if (tile_order) {
+            const uint32_t i = 8u * ((blockIdx.x >> 3) + threadIdx.x * (gridDim.x >> 3)) + (blockIdx.x & 7u);
+            if (i < order_len) tile = tile_order[i];
+        } else {
+            tile = blockIdx.x + threadIdx.x * gridDim.x;
+        }
+    }
+    if (tile < T) {
         const uint32_t s = min(tile_start[tile], cap);
         const uint32_t n = min(tile_start[tile + 1], cap) - s;
         if (n > lo && n <= hi) s_list[atomicAdd(s_cnt, 1u)] = tile;
@@ -806,13 +819,15 @@ __device__ __forceinline__ uint32_t dense_tiles_of_workgroup(uint32_t T, const u
 __global__ void __launch_bounds__(GHR_SORT_MID_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) k_tile_sort_mid(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                                    uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                                    uint32_t* tile_cursor, const rect4* __restrict__ rects,
-                                                                   uint32_t* inst_line, int gx)
+                                                                   uint32_t* inst_line, int gx,
+                                                                   const uint32_t* __restrict__ tile_order, uint32_t order_len)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert((GHR_SORT_MID_BLOCK << 3) == GHR_SORT_MID_CAP, "8 keys per thread");
     __shared__ uint64_t s_keys[GHR_SORT_MID_CAP + GHR_SORT_MID_CAP / 16 + 1];
     __shared__ uint32_t s_list[GHR_SORT_WALK_MAX], s_cnt;
-    const uint32_t cnt = dense_tiles_of_workgroup(T, tile_start, cap, GHR_SORT_CAP, GHR_SORT_MID_CAP, s_list, &s_cnt);
+    const uint32_t cnt = dense_tiles_of_workgroup(T, tile_start, cap, GHR_SORT_CAP, GHR_SORT_MID_CAP, tile_order, order_len,
+                                                  s_list, &s_cnt);
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t tile = s_list[k];
         const uint32_t s = min(tile_start[tile], cap);
@@ -829,14 +844,15 @@ __global__ void __launch_bounds__(GHR_SORT_MID_BLOCK) __attribute__((amdgpu_wave
 __global__ void __launch_bounds__(GHR_SORT_BIG_BLOCK) k_tile_sort_big(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                                    uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                                    uint32_t* tile_cursor, const rect4* __restrict__ rects,
-                                                                   uint32_t* inst_line, int gx, uint32_t min_n)
+                                                                   uint32_t* inst_line, int gx, uint32_t min_n,
+                                                                   const uint32_t* __restrict__ tile_order, uint32_t order_len)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ uint64_t s_keys[GHR_SORT_BIG_CAP];
     __shared__ uint32_t s_list[GHR_SORT_WALK_MAX], s_cnt;
     const int tid = threadIdx.x;
     constexpr uint32_t B = GHR_SORT_BIG_CAP;
-    const uint32_t n_dense = dense_tiles_of_workgroup(T, tile_start, cap, min_n, 0xffffffffu, s_list, &s_cnt);
+    const uint32_t n_dense = dense_tiles_of_workgroup(T, tile_start, cap, min_n, 0xffffffffu, tile_order, order_len, s_list, &s_cnt);
     for (uint32_t kk = 0; kk < n_dense; kk++) {
         const uint32_t tile = s_list[kk];
         const uint32_t s = min(tile_start[tile], cap);

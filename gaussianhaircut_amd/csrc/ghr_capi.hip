@@ -308,15 +308,20 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
         if (dense) {
             // (round 6) lists of 1025 .. 4096 keys by 512-thread workgroups with the register-blocked network, longer ones
             // by the 1024-thread kernel; a workgroup looks at up to GHR_SORT_WALK_MAX tiles
-            const unsigned walk = (unsigned)((T + GHR_SORT_WALK_MAX - 1) / GHR_SORT_WALK_MAX);
+            // by up to GHR_SORT_WALK_MAX entries of k_tile_scan's heaviest-first order (the dense tiles sit at its front: dealt
+            // out evenly) or, without the order, of the raster order
+            const uint32_t* order = order_ptr(im.tile_order, 0);
+            const uint32_t order_len = ghr::xcd_grid((uint32_t)T);
+            const unsigned walk = ((unsigned)(((order ? order_len : (uint32_t)T) + GHR_SORT_WALK_MAX - 1) / GHR_SORT_WALK_MAX) + 7u) & ~7u;
             uint32_t big_min = GHR_SORT_CAP;
             if (std::getenv("GHR_NO_SORT_MID") == nullptr) {
                 hipLaunchKernelGGL(ghr::k_tile_sort_mid, dim3(std::max(768u, walk)), dim3(GHR_SORT_MID_BLOCK), 0, s, (uint32_t)T,
-                                   im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx);
+                                   im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, order, order_len);
                 big_min = GHR_SORT_MID_CAP;
             }
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(std::max(512u, walk)), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
-                               im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, big_min);
+                               im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, big_min, order,
+                               order_len);
         }
         hipLaunchKernelGGL(ghr::k_tile_sort<1024>, dim3(ghr::xcd_grid((uint32_t)T)), dim3(GHR_SORT_BLOCK), 0, s, (uint32_t)T,
                            im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx,

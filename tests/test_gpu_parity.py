@@ -206,11 +206,12 @@ def test_edge_borders_huge_and_ragged_image(oracle_mod, dev):
     assert run.R > 0
 
 
-@pytest.mark.parametrize("P", [5000, 20000, 40000])
+@pytest.mark.parametrize("P", [1100, 1300, 2100, 3300, 4090, 5000, 20000, 40000])
 def test_edge_depth_ties_and_long_tile_list(oracle_mod, dev, P):
-    """> 4096 instances in ONE tile (LDS sort capacity) with many exactly equal depths: exercises the dense-tile sort
-    (k_tile_sort_big: one LDS block at 5000, three / five blocks with global flip and disperse steps at 20000 / 40000)
-    and the tie-break by ascending Gaussian index; also the > 1024-instance path of the backward render kernel."""
+    """> 1024 / > 4096 instances in ONE tile with many exactly equal depths: exercises the dense-tile sorts (k_tile_sort_mid,
+    round 6: lists of 1025 .. 4096 keys, 512 threads on the register-blocked network; k_tile_sort_big: one LDS block at 5000,
+    three / five blocks with global flip and disperse steps at 20000 / 40000) and the tie-break by ascending Gaussian index;
+    also the > 1024-instance path of the backward render kernel."""
     g = torch.Generator().manual_seed(3)
     xyz = torch.zeros(P, 3)
     xyz[:, :2] = (torch.rand(P, 2, generator=g) - 0.5) * 0.05
@@ -219,6 +220,9 @@ def test_edge_depth_ties_and_long_tile_list(oracle_mod, dev, P):
     run, st = _run_manual(oracle_mod, dev, ri)
     counts = np.diff(run.inspect()["tile_start"].astype(np.int64))
     assert counts.max() > 4096 * (P // 5000)
+    assert counts.max() > 1024 and counts.sum() >= 256 * counts.size, "not a dense scene: the dense-tile kernels were not launched"
+    if P < 4096:
+        assert counts.max() <= 4096
 
 
 def test_analytic_single_gaussian(dev):
