@@ -140,7 +140,7 @@ class WsView(ctypes.Structure):
 EXPORTS = ["ghr_last_error", "ghr_abi_version", "ghr_forward_sizes", "ghr_binning_size", "ghr_forward_stage1",
            "ghr_forward_stage2", "ghr_backward", "ghr_backward_ex", "ghr_mark_visible", "ghr_ws_inspect", "ghr_set_profile_events", "ghr_set_deterministic", "ghr_selftest_wave", "ghr_selftest_math", "ghr_model_forward_stage1",
            "ghr_model_backward", "ghr_model_forward_segment", "ghr_model_forward_finish", "ghr_render_backward",
-           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_sh_grad_from_views", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
+           "ghr_model_backward_segment", "ghr_camera_slots", "ghr_camera_grad_fold", "ghr_strand_build", "ghr_strand_build_backward", "ghr_strand_build_backward_ex", "ghr_sh_grad_from_views", "ghr_loss_sums_floats", "ghr_loss_forward", "ghr_loss_gt_stats", "ghr_loss_backward", "ghr_adam_step",
            "ghr_adam_step_range", "ghr_adam_step_range_to", "ghr_adam_nan_scan", "ghr_adam_relay_rows", "ghr_adam_fused_finish"]
 
 _lib = None
@@ -187,7 +187,7 @@ def lib() -> ctypes.CDLL:
                                       ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double,
                                       ctypes.c_double, f32, i32, i32, i32, u32]
     L.ghr_adam_step_range_to.argtypes = [vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64] + [vp] * 9 + [
-        i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, u32]
+        i32, i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_float), ctypes.c_double, ctypes.c_double, f32, i32, u32]
     L.ghr_model_backward.argtypes = [vp, ctypes.POINTER(ModelArgs), u32] + [vp] * 15 + [i32, vp, i32]
     L.ghr_model_forward_segment.argtypes = [vp, ctypes.POINTER(ModelArgs), i32, i32, vp, vp, vp, vp]
     L.ghr_model_forward_finish.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp]
@@ -202,6 +202,7 @@ def lib() -> ctypes.CDLL:
     L.ghr_adam_nan_scan.argtypes = [vp, vp, ctypes.c_int64, vp]
     L.ghr_strand_build.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp, vp]
     L.ghr_strand_build_backward.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    L.ghr_strand_build_backward_ex.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp]
     L.ghr_ws_inspect.argtypes = [i32, i32, i32, i32, u32, vp, vp, vp, ctypes.POINTER(WsView)]
     for name in EXPORTS:
         fn = getattr(L, name)

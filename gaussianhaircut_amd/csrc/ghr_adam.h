@@ -41,6 +41,9 @@ struct AdamArgs {
     const float* m_in;
     const float* v_in;
     const int* flag;
+    int* nan_mark;   // != NULL (out-of-place form only): the pass itself ORs 1 into *nan_mark when a gradient it reads is NaN -- the
+                     // `in` set stays intact, so whoever finishes the step can still undo everything (k_adam_fused_finish): no
+                     // separate scan of the range in front of the update
 };
 
 // state[1] |= any(isnan(g)).  grid-stride.
@@ -82,6 +85,7 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
     }
     __syncthreads();
     const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
+    bool bad = false;
     for (long long i = a.begin + (long long)blockIdx.x * 256 + threadIdx.x; i < a.n; i += (long long)gridDim.x * 256) {
         bool upd = false;
         int gi = 0;
@@ -91,11 +95,16 @@ __global__ void __launch_bounds__(256) k_adam(AdamArgs a)
         }
         if (upd || oop) {
             float p = pi[i], m = mi[i], v = vi[i];
-            if (upd) adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+            if (upd) {
+                const float gv = a.g[i];
+                bad |= gv != gv;
+                adam_update(p, gv, m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+            }
             a.p[i] = p; a.m[i] = m; a.v[i] = v;
         }
         if (a.zero_grad) a.g[i] = 0.f;
     }
+    if (a.nan_mark != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.nan_mark, 1);
 }
 
 // k_adam, four consecutive elements per thread as 16-B NON-TEMPORAL accesses (range start a multiple of 4, 16-B aligned
@@ -121,6 +130,7 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
     const float w1 = (float)(1.0 - a.beta1), w2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2;
     const long long n4 = (a.n - a.begin) >> 2;
     const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    bool bad = false;
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
         const long long i = a.begin + 4 * q;
         int g0 = 0, g3 = 0;
@@ -138,6 +148,7 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
             if (any) {
                 const f4 G = __builtin_nontemporal_load(reinterpret_cast<const f4*>(a.g + i));
                 const float gg[4] = {G.x, G.y, G.z, G.w};
+                bad |= (G.x != G.x) | (G.y != G.y) | (G.z != G.z) | (G.w != G.w);
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     int gi = g0;
@@ -163,13 +174,19 @@ __global__ void __launch_bounds__(256) k_adam_v4(AdamArgs a)
             }
             if (upd || oop) {
                 float p = pi[i], m = mi[i], v = vi[i];
-                if (upd) adam_update(p, a.g[i], m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+                if (upd) {
+                    const float gv = a.g[i];
+                    bad |= gv != gv;
+                    adam_update(p, gv, m, v, s_ss[gi], w1, b2, w2, a.eps, s_b2[gi]);
+                }
                 a.p[i] = p; a.m[i] = m; a.v[i] = v;
             }
             if (a.zero_grad) a.g[i] = 0.f;
         }
     }
+    if (a.nan_mark != nullptr && __builtin_amdgcn_ballot_w64(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(a.nan_mark, 1);
 }
+
 
 // ---- Adam fused into the projection backward (round 6; ghr_project.h k_project_bwd<.., ADAM>) ---------------------------------
 // The LAST view's projection backward of a single-rank step holds every parameter gradient of the step in registers (its own

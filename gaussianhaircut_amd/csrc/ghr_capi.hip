@@ -712,6 +712,12 @@ int ghr_strand_build(void* stream, int32_t S, int32_t n_seg, const float* origin
 int ghr_strand_build_backward(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
                               const float* d_rotation, const float* d_scaling, float* d_dirs)
 {
+    return ghr_strand_build_backward_ex(stream, S, n_seg, dirs, d_xyz, d_rotation, d_scaling, nullptr, d_dirs);
+}
+
+int ghr_strand_build_backward_ex(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
+                                 const float* d_rotation, const float* d_scaling, const float* d_dir_rows, float* d_dirs)
+{
     if (S < 0 || n_seg < 0 || n_seg > GHR_STRAND_MAX_SEG) return fail(GHR_E_INVALID, "ghr_strand_build_backward: bad strand shape");
     if (S == 0 || n_seg == 0) return GHR_OK;
     if ((int64_t)S * n_seg > (int64_t)INT32_MAX / 4) return fail(GHR_E_INVALID, "ghr_strand_build_backward: too many segments");
@@ -719,7 +725,7 @@ int ghr_strand_build_backward(void* stream, int32_t S, int32_t n_seg, const floa
     hipStream_t s = (hipStream_t)stream;
     ghr::StrandBwdArgs a;
     a.S = S; a.n_seg = n_seg; a.spb = ghr::strands_per_block(n_seg);
-    a.dirs = dirs; a.d_xyz = d_xyz; a.d_rot = d_rotation; a.d_scaling = d_scaling; a.d_dirs = d_dirs;
+    a.dirs = dirs; a.d_xyz = d_xyz; a.d_rot = d_rotation; a.d_scaling = d_scaling; a.d_dir_rows = d_dir_rows; a.d_dirs = d_dirs;
     const size_t lds = (size_t)2 * a.spb * n_seg * 3 * sizeof(float);
     hipLaunchKernelGGL(ghr::k_strand_build_bwd, dim3((S + a.spb - 1) / a.spb), dim3(GHR_STRAND_BLOCK), lds, s, a);
     return finish(s, 0);
@@ -902,7 +908,7 @@ int ghr_loss_backward(void* stream, const ghr_loss_args* l, const float* maps, c
 
 namespace {
 int adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
-                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, const int32_t* flag,
+                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, int32_t* flag, int32_t nan_mark,
                     int32_t n_groups, const int64_t* group_end_host, const float* lr_host, double beta1, double beta2,
                     float eps, int32_t nan_guard, int32_t zero_grad, int32_t last, uint32_t skip_mask);
 }
@@ -912,26 +918,27 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
                         double beta1, double beta2, float eps, int32_t nan_guard, int32_t zero_grad, int32_t last,
                         uint32_t skip_mask)
 {
-    return adam_step_range(stream, n, begin, count, nullptr, nullptr, nullptr, p, g, m, v, state, nullptr, n_groups,
+    return adam_step_range(stream, n, begin, count, nullptr, nullptr, nullptr, p, g, m, v, state, nullptr, 0, n_groups,
                            group_end_host, lr_host, beta1, beta2, eps, nan_guard, zero_grad, last, skip_mask);
 }
 
 int ghr_adam_step_range_to(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
                            const float* v_in, float* p_out, float* g, float* m_out, float* v_out, int32_t* state,
-                           const int32_t* flag, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
-                           double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask)
+                           int32_t* flag, int32_t nan_mark, int32_t n_groups, const int64_t* group_end_host,
+                           const float* lr_host, double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask)
 {
     if (!p_in || !m_in || !v_in) return fail(GHR_E_INVALID, "ghr_adam_step_range_to: NULL input buffer");
+    if (nan_mark && !flag) return fail(GHR_E_INVALID, "ghr_adam_step_range_to: nan_mark needs the flag word");
     if (p_in == p_out || m_in == m_out || v_in == v_out)
         return fail(GHR_E_INVALID, "ghr_adam_step_range_to: in and out buffers must differ (ghr_adam_step_range updates in place)");
     // (nan_guard 2: whoever produced the gradients keeps the flag; last 0: the caller's own finish advances the counter)
-    return adam_step_range(stream, n, begin, count, p_in, m_in, v_in, p_out, g, m_out, v_out, state, flag, n_groups,
+    return adam_step_range(stream, n, begin, count, p_in, m_in, v_in, p_out, g, m_out, v_out, state, flag, nan_mark, n_groups,
                            group_end_host, lr_host, beta1, beta2, eps, 2, zero_grad, 0, skip_mask);
 }
 
 namespace {
 int adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
-                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, const int32_t* flag,
+                    const float* v_in, float* p, float* g, float* m, float* v, int32_t* state, int32_t* flag, int32_t nan_mark,
                     int32_t n_groups, const int64_t* group_end_host, const float* lr_host, double beta1, double beta2,
                     float eps, int32_t nan_guard, int32_t zero_grad, int32_t last, uint32_t skip_mask)
 {
@@ -946,7 +953,7 @@ int adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, const
         a.begin = begin; a.n = begin + count; a.p = p; a.g = g; a.m = m; a.v = v; a.state = state; a.n_groups = n_groups;
         for (int i = 0; i < n_groups; i++) { a.end[i] = group_end_host[i]; a.lr[i] = lr_host[i]; }
         a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.zero_grad = zero_grad; a.skip_mask = skip_mask;
-        a.p_in = p_in; a.m_in = m_in; a.v_in = v_in; a.flag = flag;
+        a.p_in = p_in; a.m_in = m_in; a.v_in = v_in; a.flag = flag; a.nan_mark = nan_mark ? flag : nullptr;
         const int blocks = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
         if (nan_guard == 1)
             hipLaunchKernelGGL(ghr::k_adam_nan_flag, dim3(blocks), dim3(256), 0, s, g, (long long)n, state);

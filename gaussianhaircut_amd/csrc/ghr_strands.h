@@ -137,6 +137,8 @@ struct StrandBwdArgs {
     const float* d_xyz;      // [S n_seg, 3] or NULL
     const float* d_rot;      // [S n_seg, 4] or NULL
     const float* d_scaling;  // [S n_seg, 3] or NULL (only column 0 depends on the directions)
+    const float* d_dir_rows; // [S n_seg, 3] or NULL: cotangent of the direction rows themselves (self._dir, a view of dirs),
+                             // added LAST: (row + suffix sums) + d_dir_rows, the order autograd sums the two paths in
     float* d_dirs;           // [S, n_seg, 3], assigned
 };
 
@@ -172,6 +174,10 @@ __global__ void __launch_bounds__(GHR_STRAND_BLOCK) k_strand_build_bwd(StrandBwd
         float o[3];
         strand_row_bwd(dp[0], dp[1], dp[2], a.d_rot != nullptr ? q : nullptr, ds0, o);
         if (a.d_xyz != nullptr) { o[0] += acc[3 * i]; o[1] += acc[3 * i + 1]; o[2] += acc[3 * i + 2]; }
+        if (a.d_dir_rows != nullptr) {
+            const float* e = a.d_dir_rows + base + 3 * i;
+            o[0] += e[0]; o[1] += e[1]; o[2] += e[2];
+        }
         float* out = a.d_dirs + base + 3 * i;
         out[0] = o[0]; out[1] = o[1]; out[2] = o[2];
     }

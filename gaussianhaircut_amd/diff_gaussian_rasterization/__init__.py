@@ -161,7 +161,8 @@ class _ImgLease:
 RECYCLE_IMG_WS = os.environ.get("GHR_RECYCLE_IMG_WS", "1") != "0"  # the rasterizer op's own use of _ImgLease
 
 
-_R_HINT = {}    # device index -> binning capacity guess: 1.25 x the largest instance count of the last 64 frames
+CAPACITY_GRID = os.environ.get("GHR_CAPACITY_GRID", "1") != "0"  # (0: the exact 1.25 x + 4096 of rounds 1-5, for A/B runs)
+_R_HINT = {}    # device index -> binning capacity guess: 1.25 x the largest instance count of the last 64 frames, on a grid
 _R_RECENT = {}  # device index -> those counts (cameras of a training set differ; a guess from the last frame alone would
                 # overflow every time a wide view follows a narrow one)
 
@@ -179,7 +180,15 @@ def _note_count(dev_index, R, P):
     recent = _R_RECENT.setdefault(dev_index, collections.deque(maxlen=64))
     recent.append(int(R))
     m = max(recent)
-    _R_HINT[dev_index] = m + m // 4 + 4096
+    # ... rounded UP to a coarse grid (1/32 .. 1/16 of itself, at least 64k instances): the binning workspace and the gradient
+    # lines (76 B per instance: 0.5 GB at 2 M Gaussians) are allocated per view with this capacity, and a guess that creeps up
+    # with every new maximum -- the instance count drifts as the model trains -- asks the caching allocator for a slightly
+    # larger block every few steps: a hipMalloc of several milliseconds inside the step each time (round 6: bench.py's
+    # config5_2M block read 2.0 ms per step, or 2.8 / 3.0 when it hit two of those in its ten steps) and one more cached block
+    # nobody can reuse.  On the grid the sizes repeat.
+    g = m + m // 4 + 4096
+    q = 1 << max(16, g.bit_length() - 5) if CAPACITY_GRID else 1
+    _R_HINT[dev_index] = (g + q - 1) // q * q
     LAST_STATS["num_rendered"], LAST_STATS["P"] = R, int(P)
 
 

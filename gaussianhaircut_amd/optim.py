@@ -511,16 +511,14 @@ class FusedAdam:
             off += k
         par = f["parity"]
         with _on_device(self.flat_param.device):
-            for o, k in ranges:  # (ghr_adam_nan_scan raises state[1]: the step's flag word is passed as state + 1)
-                _lib.check(lib.ghr_adam_nan_scan(_stream(), ctypes.c_void_p(self.flat_grad.data_ptr() + 4 * o), k,
-                                                 ctypes.c_void_p(int(a.flag) - 4)))
-            # (ABI 20: one out-of-place pass per range -- in set -> out set, skipped under the step's own flag word -- where
+            # (ABI 20: one out-of-place pass per range -- in set -> out set, skipped under the step's own flag word, which the
+            # pass raises itself for a NaN among the range's gradients: the `in` set is intact, the finish kernel undoes -- where
             # rounds up to 6 copied p, m, v across, stepped in place and moved the flag through state[1]: six 12-36 MB copies
             # and three one-word kernels per iteration at the reference's 30 000 strands)
             for o, k in ranges:
                 _lib.check(lib.ghr_adam_step_range_to(_stream(), n, o, k, _ptr(self.flat_param), _ptr(self.exp_avg),
                                                       _ptr(self.exp_avg_sq), _ptr(f["p"]), _ptr(self.flat_grad), _ptr(f["m"]),
-                                                      _ptr(f["v"]), _ptr(self.state_dev), ctypes.c_void_p(int(a.flag)),
+                                                      _ptr(f["v"]), _ptr(self.state_dev), ctypes.c_void_p(int(a.flag)), 1,
                                                       len(self.param_groups), self._ends, st["lrs"], self.betas[0],
                                                       self.betas[1], self.eps, 1, 0))
             _lib.check(lib.ghr_adam_fused_finish(_stream(), ctypes.byref(a)))

@@ -27,7 +27,9 @@ def _strand_build_applies(origins, dirs) -> bool:
 
 
 class _StrandBuild(torch.autograd.Function):
-    """(origins [S,1,3], dirs [S,n_seg,3]) -> xyz [P,3], rotation [P,4], scaling [P,3] of the P = S n_seg segment Gaussians."""
+    """(origins [S,1,3], dirs [S,n_seg,3]) -> xyz [P,3], rotation [P,4], scaling [P,3] of the P = S n_seg segment Gaussians, and
+    the direction rows [P,3] (a view of dirs): as an output of THIS node their cotangent -- the rasterizer's d_dir3d -- arrives
+    in its backward and is added by the kernel, instead of autograd summing two paths into ``_dirs`` with a pass of its own."""
 
     @staticmethod
     def forward(ctx, origins, dirs, scale):
@@ -42,21 +44,21 @@ class _StrandBuild(torch.autograd.Function):
                                                    _ptr(rot), _ptr(scaling)))
         ctx.save_for_backward(dirs)
         ctx.set_materialize_grads(False)  # an output nobody differentiated arrives as None (the kernel takes NULL), not as zeros
-        return xyz, rot, scaling
+        return xyz, rot, scaling, dirs.view(-1, 3)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, d_xyz, d_rot, d_scaling):
+    def backward(ctx, d_xyz, d_rot, d_scaling, d_dir_rows):
         from ..diff_gaussian_rasterization import _on_device, _ptr, _stream
         (dirs,) = ctx.saved_tensors
-        if not ctx.needs_input_grad[1] or (d_xyz is None and d_rot is None and d_scaling is None):
+        if not ctx.needs_input_grad[1] or (d_xyz is None and d_rot is None and d_scaling is None and d_dir_rows is None):
             return None, None, None
         S, n_seg = int(dirs.shape[0]), int(dirs.shape[1])
-        cots = [None if g is None else g.contiguous().float() for g in (d_xyz, d_rot, d_scaling)]
+        cots = [None if g is None else g.contiguous().float() for g in (d_xyz, d_rot, d_scaling, d_dir_rows)]
         d_dirs = torch.empty_like(dirs)
         with _on_device(dirs.device):
-            _lib.check(_lib.lib().ghr_strand_build_backward(_stream(), S, n_seg, _ptr(dirs), *[None if g is None else _ptr(g)
-                                                                                               for g in cots], _ptr(d_dirs)))
+            _lib.check(_lib.lib().ghr_strand_build_backward_ex(_stream(), S, n_seg, _ptr(dirs),
+                                                               *[None if g is None else _ptr(g) for g in cots], _ptr(d_dirs)))
         return None, d_dirs, None
 
 
@@ -87,7 +89,8 @@ class GaussianModelStrands(GaussianModel):
         self._dir = self._dirs.reshape(-1, 3)
         if FUSED_STRAND_BUILD and _strand_build_applies(self.pts_origins, self._dirs):
             self.__dict__.pop("_pts_value", None)
-            self._xyz, self._rotation, self._scaling = _StrandBuild.apply(self.pts_origins, self._dirs, float(self.scale))
+            self._xyz, self._rotation, self._scaling, self._dir = _StrandBuild.apply(self.pts_origins, self._dirs,
+                                                                                      float(self.scale))
             return
         self._initialize_gaussians_hair_torch()
 

@@ -352,6 +352,11 @@ int ghr_strand_build(void* stream, int32_t S, int32_t n_seg, const float* origin
  * [S,n_seg,3], ASSIGNED.  d xyz_k / d dirs_j = 1 for j < k and 1/2 for j == k (a suffix sum along the strand). */
 int ghr_strand_build_backward(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
                               const float* d_rotation, const float* d_scaling, float* d_dirs);
+/* ABI 20: the same with the cotangent of the direction ROWS (self._dir = dirs.reshape(-1, 3): what render_hair() hands the
+ * rasterizer as dir3d, and what ghr_model_backward_segment returns as d_dir3d) as a fourth input, [S n_seg,3] or NULL, added to
+ * the result last -- one kernel where autograd otherwise sums the two paths into `_dirs` with a pass of its own. */
+int ghr_strand_build_backward_ex(void* stream, int32_t S, int32_t n_seg, const float* dirs, const float* d_xyz,
+                                 const float* d_rotation, const float* d_scaling, const float* d_dir_rows, float* d_dirs);
 
 int ghr_model_backward(void* stream, const ghr_model_args* m, uint32_t R, const int32_t* radii, const void* geom_ws,
                        const void* img_ws, const void* bin_ws, const float* dL_dpix, float* grad_scratch,
@@ -439,14 +444,17 @@ int ghr_adam_step_range(void* stream, int64_t n, int64_t begin, int64_t count, f
 
 /* ABI 20.  ghr_adam_step_range OUT OF PLACE: p, m, v of [begin, begin + count) are read from the *_in buffers and written to
  * the *_out buffers (same offsets; an element that takes no update -- flag up, or its group in skip_mask -- is copied), the
- * gradients zeroed when zero_grad != 0.  flag != NULL: the skip-the-step word is *flag instead of state[1].  The step counter is
- * not advanced.  For the late groups of a fused step (ghr_adam_fuse, strand segment: the strand directions' and the
+ * gradients zeroed when zero_grad != 0.  flag != NULL: the skip-the-step word is *flag instead of state[1].  nan_mark != 0 (needs
+ * flag): the pass ORs 1 into *flag itself when a gradient of the range is NaN (the check of src/train_strands.py:151-155) -- some
+ * of its elements may then have been updated already, which is harmless here and ONLY here: the `in` set is intact and the
+ * caller's finish (ghr_adam_fused_finish) copies it over the `out` set when the flag is up.  No separate ghr_adam_nan_scan of the
+ * range is needed in front of the call.  The step counter is not advanced.  For the late groups of a fused step (ghr_adam_fuse, strand segment: the strand directions' and the
  * confidence's gradients arrive through autograd after the kernel that carried the SH features' update): their ranges of the
  * `out` set are produced by ONE pass each instead of three copies and an in-place pass (src/train_strands.py:151-160). */
 int ghr_adam_step_range_to(void* stream, int64_t n, int64_t begin, int64_t count, const float* p_in, const float* m_in,
                            const float* v_in, float* p_out, float* g, float* m_out, float* v_out, int32_t* state,
-                           const int32_t* flag, int32_t n_groups, const int64_t* group_end_host, const float* lr_host,
-                           double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask);
+                           int32_t* flag, int32_t nan_mark, int32_t n_groups, const int64_t* group_end_host,
+                           const float* lr_host, double beta1, double beta2, float eps, int32_t zero_grad, uint32_t skip_mask);
 
 /* present[i] = view-space z > 0.2 (rasterizer_impl.cu:54-66). */
 int ghr_mark_visible(void* stream, int32_t P, const float* means3D, const float* viewmatrix,

@@ -236,22 +236,37 @@ def test_tan_half_fov_is_cached_per_tensor_version():
 
 
 def test_capacity_guess_follows_the_largest_recent_count():
-    """The speculative binning capacity is 1.25 x the largest instance count of the last 64 frames (+4096): a narrow
-    view after a wide one must not shrink it, and it must forget counts that left the window."""
+    """The speculative binning capacity is 1.25 x the largest instance count of the last 64 frames (+4096), rounded up to a
+    coarse grid (so that the per-view workspaces keep their size while the count drifts: no allocator growth inside a step):
+    a narrow view after a wide one must not shrink it, and it must forget counts that left the window."""
     import gaussianhaircut_amd.diff_gaussian_rasterization as dgr
+
+    def want(m):
+        g = m + m // 4 + 4096
+        q = 1 << max(16, g.bit_length() - 5)
+        return (g + q - 1) // q * q
+
     saved = (dict(dgr._R_HINT), dict(dgr._R_RECENT), dict(dgr.LAST_STATS))
     try:
         dgr._R_HINT.pop(7, None)
         dgr._R_RECENT.pop(7, None)
-        dgr._note_count(7, 1000, 10)
-        assert dgr._R_HINT[7] == 1000 + 250 + 4096 and dgr.LAST_STATS["num_rendered"] == 1000
-        dgr._note_count(7, 100, 10)                      # narrow view: the guess keeps covering the wide one
-        assert dgr._R_HINT[7] == 1000 + 250 + 4096 and dgr.LAST_STATS["num_rendered"] == 100
-        dgr._note_count(7, 4000, 10)
-        assert dgr._R_HINT[7] == 4000 + 1000 + 4096
+        dgr._note_count(7, 1_000_000, 10)
+        assert dgr._R_HINT[7] == want(1_000_000) and dgr.LAST_STATS["num_rendered"] == 1_000_000
+        assert 1_254_096 <= dgr._R_HINT[7] < 1_254_096 * 1.07
+        dgr._note_count(7, 100_000, 10)                  # narrow view: the guess keeps covering the wide one
+        assert dgr._R_HINT[7] == want(1_000_000) and dgr.LAST_STATS["num_rendered"] == 100_000
+        for k in range(1, 20):                           # a count that creeps up keeps its capacity (same allocation sizes)
+            dgr._note_count(7, 1_000_000 + 500 * k, 10)
+        assert dgr._R_HINT[7] == want(1_000_000)
+        dgr._note_count(7, 4_000_000, 10)
+        assert dgr._R_HINT[7] == want(4_000_000) >= 5_004_096
         for _ in range(64):                              # the wide views leave the window
-            dgr._note_count(7, 200, 10)
-        assert dgr._R_HINT[7] == 200 + 50 + 4096
+            dgr._note_count(7, 200_000, 10)
+        assert dgr._R_HINT[7] == want(200_000)
+        dgr._note_count(7, 1000, 10)
+        for _ in range(64):
+            dgr._note_count(7, 1000, 10)
+        assert dgr._R_HINT[7] == 65536                   # (the grid's floor)
     finally:
         dgr._R_HINT.clear(); dgr._R_HINT.update(saved[0])
         dgr._R_RECENT.clear(); dgr._R_RECENT.update(saved[1])

@@ -426,7 +426,8 @@ def test_speculative_stage2_capacity_guess_never_changes_the_result(pipe):
         full = torch.cat([pkg["render"], pkg["mask"], pkg["orient_conf"]], dim=0)
         (full * w).sum().backward()
         R = dgr.LAST_STATS["num_rendered"]
-        assert 64 < R < 10_000_000 and dgr._R_HINT[dev.index] == R + R // 4 + 4096
+        g_ = R + R // 4 + 4096   # (on a grid of 1/32 .. 1/16 of itself, at least 64k instances: round 6)
+        assert 64 < R < 10_000_000 and g_ <= dgr._R_HINT[dev.index] < g_ + max(65536, g_ // 16)
         outs.append((full.detach().clone(), pkg["radii"].clone(), model._xyz.grad.clone(), model._features_dc.grad.clone()))
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])

@@ -182,8 +182,8 @@ def test_out_of_place_adam_range_equals_copy_plus_in_place_range_bit_for_bit(beg
             pt, mt, vt = junk[3], junk[4], junk[5]
             g_new, st_new = grad.clone(), state.clone()
             _lib.check(L.ghr_adam_step_range_to(stream, n, begin, count, ptr(p_in), ptr(m_in), ptr(v_in), ptr(pt), ptr(g_new),
-                                                ptr(mt), ptr(vt), ptr(st_new), ptr(flag), len(sizes), ends, lrs, 0.9, 0.999, 1e-15,
-                                                1, skip_mask))
+                                                ptr(mt), ptr(vt), ptr(st_new), ptr(flag), 1, len(sizes), ends, lrs, 0.9, 0.999,
+                                                1e-15, 1, skip_mask))
             torch.cuda.synchronize()
             for a, b, src in ((po, pt, p_in), (mo, mt, m_in), (vo, vt, v_in)):
                 assert torch.equal(a, b), (scalar, flag_up, skip_mask)
@@ -194,10 +194,24 @@ def test_out_of_place_adam_range_equals_copy_plus_in_place_range_bit_for_bit(beg
                 assert float((b[:begin] - 7.0).abs().sum()) == 0.0 and float((b[begin + count:] - 7.0).abs().sum()) == 0.0
             assert torch.equal(g_ref, g_new) and float(g_new[begin:begin + count].abs().sum()) == 0.0
             assert torch.equal(st_new, state)   # neither the counter nor state[1] is touched
+            assert int(flag) == flag_up         # finite gradients: nan_mark leaves the word alone
+            # nan_mark: a NaN among the range's gradients raises the word (the scan ghr_adam_nan_scan did in front of the update);
+            # one outside the range does not
+            for where, want in ((begin + count // 2, 1), ((begin + count) % n if count < n else None, 0)):
+                if where is None or (want == 0 and begin <= where < begin + count):
+                    continue
+                g_nan = grad.clone()
+                g_nan[where] = float("nan")
+                fl = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(L.ghr_adam_step_range_to(stream, n, begin, count, ptr(p_in), ptr(m_in), ptr(v_in), ptr(pt), ptr(g_nan),
+                                                    ptr(mt), ptr(vt), ptr(st_new), ptr(fl), 1, len(sizes), ends, lrs, 0.9, 0.999,
+                                                    1e-15, 0, 0))
+                torch.cuda.synchronize()
+                assert int(fl) == want, (scalar, where, want)
     # in == out is refused (that is ghr_adam_step_range)
     t = torch.zeros(8, device=dev)
     st = torch.zeros(18, dtype=torch.int32, device=dev)
-    rc = L.ghr_adam_step_range_to(stream, 8, 0, 8, ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(st), None, 1,
+    rc = L.ghr_adam_step_range_to(stream, 8, 0, 8, ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(t), ptr(st), None, 0, 1,
                                   (ctypes.c_int64 * 1)(8), (ctypes.c_float * 1)(0.1), 0.9, 0.999, 1e-15, 1, 0)
     assert rc != 0 and b"must differ" in L.ghr_last_error()
 

@@ -111,8 +111,9 @@ def test_gpu_strand_build_matches_the_torch_form(S, n_seg):
     _, gd64 = _torch_form(origins, dirs, 1e-3, cots, double=True)
     d = torch.nn.Parameter(dirs.clone())
     assert gms._strand_build_applies(origins, d)
-    xyz, rot, sc = gms._StrandBuild.apply(origins, d, 1e-3)
+    xyz, rot, sc, rows = gms._StrandBuild.apply(origins, d, 1e-3)
     assert torch.equal(xyz, xyz_t)
+    assert rows.shape == (P, 3) and rows.data_ptr() == d.data_ptr() and type(rows.grad_fn).__name__.startswith("_StrandBuild")
     assert torch.allclose(rot, rot_t, rtol=0, atol=3e-7) and float(rot.detach()[:, 1].abs().max()) == 0.0
     assert torch.allclose(sc, sc_t, rtol=3e-7, atol=0)
     (sum((o * c).sum() for o, c in zip((xyz, rot, sc), cots))).backward()
@@ -126,10 +127,22 @@ def test_gpu_strand_build_matches_the_torch_form(S, n_seg):
     assert err_k <= max(2e-5 * scale, 2.0 * err_t), (err_k, err_t, scale)
     # partial cotangents (an output nobody differentiated)
     d2 = torch.nn.Parameter(dirs.clone())
-    xyz2, _, _ = gms._StrandBuild.apply(origins, d2, 1e-3)
+    xyz2, _, _, _ = gms._StrandBuild.apply(origins, d2, 1e-3)
     (xyz2 * cots[0]).sum().backward()
     _, gx64 = _torch_form(origins, dirs, 1e-3, [cots[0], torch.zeros_like(cots[1]), torch.zeros_like(cots[2])], double=True)
     assert float((d2.grad.double() - gx64).abs().max()) <= 2e-5 * float(gx64.abs().max())
+    # the direction rows as a fourth output (round 6): their cotangent is added by the kernel, last -- the bits of autograd
+    # summing the node's gradient and the rows' own (what the graph did while `_dir` was a plain view of `_dirs`)
+    c_rows = torch.randn(P, 3, generator=g).to(dev)
+    d3, d4 = torch.nn.Parameter(dirs.clone()), torch.nn.Parameter(dirs.clone())
+    o3 = gms._StrandBuild.apply(origins, d3, 1e-3)
+    (sum((o * c).sum() for o, c in zip(o3[:3], cots)) + (o3[3] * c_rows).sum()).backward()
+    o4 = gms._StrandBuild.apply(origins, d4, 1e-3)
+    (sum((o * c).sum() for o, c in zip(o4[:3], cots)) + (d4.reshape(-1, 3) * c_rows).sum()).backward()
+    assert torch.equal(d3.grad, d4.grad)
+    d5 = torch.nn.Parameter(dirs.clone())
+    (gms._StrandBuild.apply(origins, d5, 1e-3)[3] * c_rows).sum().backward()   # the rows alone
+    assert torch.equal(d5.grad.reshape(-1, 3)[ok.reshape(-1)], c_rows[ok.reshape(-1)])
 
 
 @pytest.mark.gpu

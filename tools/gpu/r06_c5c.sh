@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 6: capacity guess on a grid against the exact guess, alternating processes on one box (headline / 4-view shard / 2M block)
+cd ${GRAFT_REPO_ROOT:-/root/repo}
+R=$PWD; O=$PWD/gpurun_out/r06c5c; mkdir -p $O; export TMPDIR=/tmp PYTHONUNBUFFERED=1
+timeout 600 python -m pytest tests/test_gpu_fused.py -m gpu -x -q 2>&1 | tail -3 | tee $O/pytest.log
+rm -f $O/c5.log
+B="python $R/bench.py --no-cpu-baseline --no-op-only --no-camera-block --no-strand-block"
+for rep in 1 2 3 4; do
+for grid in 0 1; do
+GHR_CAPACITY_GRID=$grid $B 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('[grid $grid] headline', d['ms_per_step'], 'fixed', d['fixed_camera_step']['ms_per_step'], 'config5_2M', d['config5_2M']['ms_per_step'], 'shard', d['config4_shard']['ms_per_step'])" | tee -a $O/c5.log
+done; done
