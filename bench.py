@@ -18,7 +18,11 @@ scaling: one view per GPU per step at every N (a global step covers N views).
   roofline            : k_render_bwd_cells = K8 (the dominant kernel): SURVEY 8(d) algorithmic bytes / HIP-event duration on the
                         launch stream over solo passes cycling over the same cameras, against 8 TB/s HBM; `traffic` from the
                         committed rocprofv3 FETCH_SIZE / WRITE_SIZE passes (profiles/).
-Further blocks of the same line (N = 1 unless noted), each named for what it measures:
+  repeat_ms_per_step  : the same K steps once more, straight behind the timed ones -- a diagnostic, never used for `value`
+Further blocks of the same line (N = 1 unless noted), each named for what it measures.  Blocks timed over steps run TWO timed
+passes and report the faster one (`ms_per_step_passes` lists both): they exist to be compared with the headline, a pass lasts
+7-40 ms, and the boxes of this pool stall a process for a few milliseconds now and then (`host_gc`: it is not Python's
+collector):
   fixed_camera_step   : the headline step on camera 0 only (what rounds 1-5 timed)
   config4_shard       : BASELINE configs[3]'s per-GPU shard -- 4 views per GPU per step, same model (every N)
   config5_2M          : BASELINE configs[4]'s model (2M strand Gaussians), one view per step: step time, K8 time and fraction
@@ -211,6 +215,16 @@ def main():
         gc_log["timed"] = False
         return max_over_ranks(dt_timed), [views(n_warm + i) for i in range(n_steps)]
 
+    def timed_steps_2(model_, pool_, v, n_warm, n_steps, it0=0, **kw):
+        """For the SIDE blocks: two timed passes of n_steps, the faster one returned, both listed (ms per step).  A pass of ten or
+        twenty steps lasts 7-40 ms and the boxes of this pool stall a process for 3-4 ms every now and then (not this process'
+        doing: DESIGN.md 7a); a side block exists to be compared with the headline, and a stalled pass compares the box with
+        itself.  The headline is timed ONCE, K steps, as the contract says (its repeat is printed beside it, never used)."""
+        a, ua = timed_steps(model_, pool_, v, n_warm, n_steps, it0=it0, **kw)
+        b, ub = timed_steps(model_, pool_, v, 0, n_steps, it0=it0 + n_warm + n_steps, **kw)
+        passes = [round(1e3 * a / n_steps, 4), round(1e3 * b / n_steps, 4)]
+        return (a, ua, passes) if a <= b else (b, ub, passes)
+
     def visible(model_, cams_):
         with torch.no_grad():
             return [int((_render(c, model_, _tr.PIPE, bg)["radii"] > 0).sum().item()) for c in cams_]
@@ -255,6 +269,10 @@ def main():
     timed_steps(model, pool, V, n_settle, 0)
     elapsed, used = timed_steps(model, pool, V, Wm, K, it0=n_settle)
     ms_per_step = 1e3 * elapsed / K
+    # (a diagnostic only, printed as `repeat_ms_per_step`: the same K steps once more, straight behind the timed ones.  `value`
+    # and `ms_per_step` are the FIRST K steps whatever this says; two numbers far apart mean the box stalled the process in one
+    # of the two 14-ms windows)
+    elapsed_rep, _ = timed_steps(model, pool, V, 0, K, it0=n_settle + Wm + K)
 
     N_pix = spec.W * spec.H
     T_tiles = ((spec.W + 15) // 16) * ((spec.H + 15) // 16)
@@ -352,6 +370,7 @@ def main():
                        "k_render_fwd_hbm_frac": round(bytes_fwd_kernel / (fwd_avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
                        if fwd_avg > 0 else None},
         "roofline": roofline,
+        "repeat_ms_per_step": round(1e3 * elapsed_rep / K, 4),
     }
     if replicas_identical is not None:
         out["replicas_identical"] = replicas_identical
@@ -359,8 +378,8 @@ def main():
     # ---- the same step on ONE camera (what rounds 1-5 timed): the per-camera caches -- ground-truth SSIM moments, the
     # capacity guess, the image-workspace lease -- all hit every step there; the headline above proves them across cameras
     if len(pool) > 1:
-        e1, _ = timed_steps(model, pool[:1], V, 3, K, it0=Wm + K)
-        out["fixed_camera_step"] = {"ms_per_step": round(1e3 * e1 / K, 4), "steps": K,
+        e1, _, p1 = timed_steps_2(model, pool[:1], V, 3, K, it0=Wm + K)
+        out["fixed_camera_step"] = {"ms_per_step": round(1e3 * e1 / K, 4), "ms_per_step_passes": p1, "steps": K,
                                     "headline_over_fixed": round(ms_per_step / (1e3 * e1 / K), 4)}
 
     # ---- ... and with the stage-1 loop's per-iteration densification statistics (train_gaussians.py:161-165: every iteration
@@ -375,8 +394,10 @@ def main():
                               global_views=V * world, streams=args.streams, densify_stats=True)
             sync_all()
             return time.perf_counter() - t_
-        e2 = stats_steps(3, K, Wm + 2 * K + 3)
-        out["densify_stats_step"] = {"ms_per_step": round(1e3 * e2 / K, 4), "steps": K,
+        e2a, e2b = stats_steps(3, K, Wm + 3 * K + 6), stats_steps(0, K, Wm + 4 * K + 9)
+        e2 = min(e2a, e2b)
+        out["densify_stats_step"] = {"ms_per_step": round(1e3 * e2 / K, 4),
+                                     "ms_per_step_passes": [round(1e3 * e2a / K, 4), round(1e3 * e2b / K, 4)], "steps": K,
                                      "over_headline_us": round(1e3 * (1e3 * e2 / K - ms_per_step), 2),
                                      "seen_fraction": round(float((model.denom > 0).float().mean().item()), 4)}
 
@@ -385,11 +406,7 @@ def main():
         K4 = max(5, K // 2)
         # (two timed passes, the faster one reported and both listed: a side block of ten steps lasts 25 ms, and one run in five
         # a disturbance of the box -- not of this process: `host_gc` -- lands in one of them; the HEADLINE above is K steps, once)
-        dt4, used4 = timed_steps(model, pool, VS, 5, K4, it0=Wm + 2 * K + 3)
-        dt4b, used4b = timed_steps(model, pool, VS, 0, K4, it0=Wm + 2 * K + 3 + 5 + K4)
-        passes4 = [round(1e3 * dt4 / K4, 4), round(1e3 * dt4b / K4, 4)]
-        if dt4b < dt4:
-            dt4, used4 = dt4b, used4b
+        dt4, used4, passes4 = timed_steps_2(model, pool, VS, 5, K4, it0=Wm + 5 * K + 12)
         dt4 /= K4
         pv4 = torch.tensor([float(sum(P_vis[c] for vs in used4 for c in vs)) / K4], dtype=torch.float64, device=dev)
         if world > 1:
@@ -515,10 +532,7 @@ def main():
         spec5 = syn.CONFIGS["cfg5"]
         m5, pool5 = build_scene(spec5, 1)
         K5 = 10
-        e5, _ = timed_steps(m5, pool5, 1, 8, K5)
-        e5b, _ = timed_steps(m5, pool5, 1, 0, K5, it0=8 + K5)   # (two passes, the faster one reported: see config4_shard)
-        passes5 = [round(1e3 * e5 / K5, 4), round(1e3 * e5b / K5, 4)]
-        e5 = min(e5, e5b)
+        e5, _, passes5 = timed_steps_2(m5, pool5, 1, 8, K5)
         solo5 = solo_kernel_times(m5, pool5, 10, 1)
         b5 = sum(s_[1] for s_ in solo5) / len(solo5)
         f5 = sum(s_[0] for s_ in solo5) / len(solo5)
@@ -554,8 +568,9 @@ def main():
             for c in cams_:
                 for n in ("world_view_transform", "full_proj_transform", "camera_center", "FoVx", "FoVy"):
                     getattr(c, n).grad = None
-        ea, _ = timed_steps(model, leaf_pool, V, 3, K, it0=10_000, after_step=drop_cam_grads)
-        blk["leaf_camera_tensors"] = {"ms_per_step": round(1e3 * ea / K, 4), "over_headline": round(1e3 * ea / K / ms_per_step, 4)}
+        ea, _, pa = timed_steps_2(model, leaf_pool, V, 3, K, it0=10_000, after_step=drop_cam_grads)
+        blk["leaf_camera_tensors"] = {"ms_per_step": round(1e3 * ea / K, 4), "ms_per_step_passes": pa,
+                                      "over_headline": round(1e3 * ea / K / ms_per_step, 4)}
         # (b) pose / FoV residuals as parameters (scene.cameras.TrainableCamera: the reference's ortho-6D + translation + FoV
         # residuals, cameras.py:85-117), composed with PyTorch ops under autograd, stepped by an Adam of their own after the
         # Gaussians' (train_gaussians.py:45-60,183-196: three groups, eps 1e-15)
@@ -567,8 +582,9 @@ def main():
         def cam_step(_cams):
             cam_opt.step()
             cam_opt.zero_grad(set_to_none=True)
-        eb, _ = timed_steps(mC, poolC, V, 3, K, after_step=cam_step)
-        blk["residual_parameters"] = {"ms_per_step": round(1e3 * eb / K, 4), "over_headline": round(1e3 * eb / K / ms_per_step, 4),
+        eb, _, pb = timed_steps_2(mC, poolC, V, 3, K, after_step=cam_step)
+        blk["residual_parameters"] = {"ms_per_step": round(1e3 * eb / K, 4), "ms_per_step_passes": pb,
+                                      "over_headline": round(1e3 * eb / K / ms_per_step, 4),
                                       "camera_moved": bool(poolC[0]._translation_res.detach().abs().max().item() > 0),
                                       "note": "camera matrices composed from the residuals by ~40 small PyTorch kernels per view "
                                               "(forward + autograd) and a torch.optim.Adam over the camera parameters: camera-"
