@@ -22,7 +22,16 @@ namespace ghr {
 #define GHR_SORT_BIG_BLOCK 1024
 #define GHR_SORT_BIG_MIN_AVG 256  // k_tile_sort_big is launched when the lists average at least this many instances
 #define GHR_SORT_MID_CAP 4096   // k_tile_sort_mid (round 6): lists of GHR_SORT_CAP + 1 .. this many keys (34.8 KiB of LDS)
-#define GHR_SORT_MID_BLOCK 512
+#ifndef GHR_SORT_MID_WAVES
+#define GHR_SORT_MID_WAVES 8    // per SIMD the register allocation of k_tile_sort_mid aims at (64 VGPRs, one spilled; 6: 66 VGPRs)
+#endif
+#ifndef GHR_SORT_MID_EMIT
+#define GHR_SORT_MID_EMIT 2     // entries whose rect gathers are in flight together when the list is written out (4 in k_tile_sort)
+#endif
+#ifndef GHR_SORT_MID_SPLIT
+#define GHR_SORT_MID_SPLIT 0    // 1: 256 threads for lists up to 2048 keys, 512 for the rest (two launches whose critical paths add:
+                                // strand stage 162 + 51 us against 169, cfg5 71 + 35 against 101: profiles/r06q); 0: 512 threads for all
+#endif
 #define GHR_SORT_WALK_MAX 64    // tiles one workgroup of the dense-tile kernels may have to look at (grid >= T / this)
 #define GHR_SORT_DONE 0xffffffffu  // tile_cursor value k_tile_sort_big leaves for k_tile_sort: "this tile is sorted"
 #define GHR_SORT_BLOCK 128  // two waves per tile (round 5; 256 threads and a barrier per step before)
@@ -571,7 +580,7 @@ GHR_HD void sort_emit(uint32_t* point_list, uint32_t* inst_line, const rect4* re
 // NT threads (one wave: NT = 64, separated by wave-level fences; or NT / 64 cooperating waves, separated by barriers) sort a
 // list of up to NT << r keys in LDS and write it out (k_tile_sort).  Every phase keeps a thread's (up to) 2^r memory
 // operations in flight together: loads never sit under a branch (positions past n read the last key and drop it).
-template <int r, int NT>
+template <int r, int NT, int EMIT = 4>
 __device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_t s, uint64_t* s_keys, uint32_t* point_list,
                                                 uint32_t* inst_line, const rect4* __restrict__ rects, int tx, int ty,
                                                 uint32_t cap, int t_)
@@ -592,7 +601,7 @@ __device__ __forceinline__ void tile_sort_group(uint64_t* g, uint32_t n, uint32_
     if (WAVE) GHR_SYNC_WAVE(); else GHR_SYNC();
     if (n > 1) bitonic_blocked<r, WAVE, true, true>(s_keys, n, t_, NT);
     // (four entries at a time: the rect gather of more would set the kernel's register count)
-    constexpr int E = L < 4 ? L : 4;
+    constexpr int E = L < EMIT ? L : EMIT;
 #pragma unroll
     for (int h = 0; h < L; h += E) {
         uint64_t kq[E];
@@ -814,27 +823,35 @@ __device__ __forceinline__ uint32_t dense_tiles_of_workgroup(uint32_t T, const u
 // Lists of GHR_SORT_CAP + 1 .. GHR_SORT_MID_CAP keys (round 6).  k_tile_sort_big gives such a tile 1024 threads, 64 KiB of LDS
 // and one barrier per compare-exchange step -- two workgroups per CU, most of their threads without a pair to exchange; at
 // 2 M strand Gaussians (BASELINE configs[4]) and in the strand stage most dense tiles are of this size and the kernel took
-// 207 / 269 us per view.  Here: 512 threads, the register-blocked network of k_tile_sort (8 keys per thread between two LDS
-// trips: 26 passes for 2048 keys where the per-step form takes 66 steps), 34.8 KiB of LDS: three workgroups per CU.
-__global__ void __launch_bounds__(GHR_SORT_MID_BLOCK) __attribute__((amdgpu_waves_per_eu(6, 8))) k_tile_sort_mid(uint32_t T, const uint32_t* __restrict__ tile_start,
+// 207 / 269 us per view.  Here: NT threads sort lists of (lo, 8 NT] keys on the register-blocked network of k_tile_sort (8 keys
+// per thread between two LDS trips: 26 passes for 2048 keys where the per-step form takes 66 steps) in 8.5 NT bytes of LDS --
+// 512 threads for up to 4096 keys (34.8 KiB of LDS, four workgroups per CU); the 256-thread instantiation for up to 2048 keys
+// in front of it (GHR_SORT_MID_SPLIT) measured slower -- two launches whose critical paths add.
+// The kernel is bound by a list's chain of passes (VALU 37 % busy, LDS 26 %: profiles/r06q): what pays is more lists in flight
+// per CU -- 64 VGPRs for eight waves per SIMD (the list is written out two rect gathers at a time instead of four: no spill),
+// and the grid sized so that every workgroup is resident: 181 -> 169 us (strand stage), 117 -> 101 us (cfg5) against three
+// workgroups per CU at 66 VGPRs.
+template <int NT>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(GHR_SORT_MID_WAVES, 8))) k_tile_sort_mid(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                                    uint64_t* keys, uint32_t* point_list, uint32_t cap,
                                                                    uint32_t* tile_cursor, const rect4* __restrict__ rects,
                                                                    uint32_t* inst_line, int gx,
-                                                                   const uint32_t* __restrict__ tile_order, uint32_t order_len)
+                                                                   const uint32_t* __restrict__ tile_order, uint32_t order_len,
+                                                                   uint32_t lo)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert((GHR_SORT_MID_BLOCK << 3) == GHR_SORT_MID_CAP, "8 keys per thread");
-    __shared__ uint64_t s_keys[GHR_SORT_MID_CAP + GHR_SORT_MID_CAP / 16 + 1];
+    constexpr uint32_t CAPM = (uint32_t)NT << 3;  // 8 keys per thread
+    static_assert(CAPM <= GHR_SORT_MID_CAP && NT >= GHR_SORT_WALK_MAX, "k_tile_sort_mid: list length / tile walk");
+    __shared__ uint64_t s_keys[CAPM + CAPM / 16 + 1];
     __shared__ uint32_t s_list[GHR_SORT_WALK_MAX], s_cnt;
-    const uint32_t cnt = dense_tiles_of_workgroup(T, tile_start, cap, GHR_SORT_CAP, GHR_SORT_MID_CAP, tile_order, order_len,
-                                                  s_list, &s_cnt);
+    const uint32_t cnt = dense_tiles_of_workgroup(T, tile_start, cap, lo, CAPM, tile_order, order_len, s_list, &s_cnt);
     for (uint32_t k = 0; k < cnt; k++) {
         const uint32_t tile = s_list[k];
         const uint32_t s = min(tile_start[tile], cap);
         const uint32_t n = min(tile_start[tile + 1], cap) - s;
         __syncthreads();  // (the previous tile's keys have left LDS)
-        tile_sort_group<3, GHR_SORT_MID_BLOCK>(keys + s, n, s, s_keys, point_list, inst_line, rects, (int)(tile % (uint32_t)gx),
-                                               (int)(tile / (uint32_t)gx), cap, (int)threadIdx.x);
+        tile_sort_group<3, NT, GHR_SORT_MID_EMIT>(keys + s, n, s, s_keys, point_list, inst_line, rects, (int)(tile % (uint32_t)gx),
+                               (int)(tile / (uint32_t)gx), cap, (int)threadIdx.x);
         if (threadIdx.x == 0) tile_cursor[T + tile] = GHR_SORT_DONE;
     }
 #endif

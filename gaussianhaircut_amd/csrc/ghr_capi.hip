@@ -315,8 +315,17 @@ int ghr_forward_stage2(void* stream, const ghr_view_args* a, uint32_t R, void* g
             const unsigned walk = ((unsigned)(((order ? order_len : (uint32_t)T) + GHR_SORT_WALK_MAX - 1) / GHR_SORT_WALK_MAX) + 7u) & ~7u;
             uint32_t big_min = GHR_SORT_CAP;
             if (std::getenv("GHR_NO_SORT_MID") == nullptr) {
-                hipLaunchKernelGGL(ghr::k_tile_sort_mid, dim3(std::max(768u, walk)), dim3(GHR_SORT_MID_BLOCK), 0, s, (uint32_t)T,
-                                   im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, order, order_len);
+                // (every workgroup resident: 256 CUs x 8 resp. 4 workgroups)
+                uint32_t lo = GHR_SORT_CAP;
+                if (GHR_SORT_MID_SPLIT) {
+                    hipLaunchKernelGGL(ghr::k_tile_sort_mid<256>, dim3(std::max(2048u, walk)), dim3(256), 0, s, (uint32_t)T,
+                                       im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, order,
+                                       order_len, lo);
+                    lo = 2048u;
+                }
+                hipLaunchKernelGGL(ghr::k_tile_sort_mid<512>, dim3(std::max(1024u, walk)), dim3(512), 0, s, (uint32_t)T,
+                                   im.tile_start, b.keys, b.point_list, R, im.tile_count, g.rects, b.inst_line, gx, order,
+                                   order_len, lo);
                 big_min = GHR_SORT_MID_CAP;
             }
             hipLaunchKernelGGL(ghr::k_tile_sort_big, dim3(std::max(512u, walk)), dim3(GHR_SORT_BIG_BLOCK), 0, s, (uint32_t)T,
