@@ -358,3 +358,32 @@ def test_strand_model_modules_export_the_reference_class_names():
     assert GaussianModelCurves is GaussianModelStrands and issubclass(GaussianModelHair, GaussianModelStrands)
     assert scene.GaussianModelCurves is GaussianModelCurves and scene.GaussianModelHair is GaussianModelHair
     assert scene.GaussianModel.__name__ == "GaussianModel"
+
+
+def test_fused_hair_check_does_not_evaluate_properties():
+    """``_use_fused_hair`` asks whether the strand model HAS ``get_orient_conf`` / ``get_scaling`` / ``get_xyz``: with ``hasattr``
+    that ran the properties -- an exp kernel over every strand Gaussian and its autograd node, twice per iteration (round 6)."""
+    from gaussianhaircut_amd.gaussian_renderer import _has
+    calls = []
+
+    class M:
+        attr_on_class = 1
+
+        def __init__(self):
+            self._dir = 0
+
+        @property
+        def get_orient_conf(self):
+            calls.append("evaluated")
+            return 1
+
+    class Dyn:
+        def __getattr__(self, name):
+            if name == "answered":
+                return 1
+            raise AttributeError(name)
+
+    m = M()
+    assert _has(m, "get_orient_conf") and _has(m, "_dir") and _has(m, "attr_on_class") and not _has(m, "missing")
+    assert calls == []
+    assert _has(Dyn(), "answered") and not _has(Dyn(), "missing")
