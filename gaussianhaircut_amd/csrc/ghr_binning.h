@@ -716,7 +716,12 @@ __device__ __forceinline__ void tile_sort_wave_long(uint64_t* g, uint32_t n, uin
 // barrier at all (wave 1 leaves at once); longer ones by both waves (a wave per tile throughout was measured too: the
 // longest lists then set the kernel's duration, profiles/r05u).  LDS holds CAP = 1024 keys
 // (8.5 KiB); longer lists: tile_sort_wave_long.
+#ifndef GHR_SORT_WAVES
 #define GHR_SORT_WAVES 6  // per SIMD: 80 VGPRs, no spills: 26.1 us (8: 64 VGPRs + 8 spilled dwords 26.8; 5: 27.4; profiles/r05u)
+#endif
+#ifndef GHR_SORT_EMIT
+#define GHR_SORT_EMIT 4   // entries whose rect gathers are in flight together when a list is written out
+#endif
 template <int CAP>
 __global__ void __launch_bounds__(GHR_SORT_BLOCK) __attribute__((amdgpu_waves_per_eu(GHR_SORT_WAVES, 8))) k_tile_sort(uint32_t T, const uint32_t* __restrict__ tile_start,
                                                          uint64_t* keys, uint32_t* point_list, uint32_t cap,
@@ -745,12 +750,12 @@ __global__ void __launch_bounds__(GHR_SORT_BLOCK) __attribute__((amdgpu_waves_pe
     const int tx = tile % gx, ty = tile / gx;
     if (n <= GHR_SORT_SOLO) {
         if (wave == 1) return;
-        if (n <= 128u) tile_sort_group<1, 64>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
-        else tile_sort_group<2, 64>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
+        if (n <= 128u) tile_sort_group<1, 64, GHR_SORT_EMIT>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
+        else tile_sort_group<2, 64, GHR_SORT_EMIT>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, lane);
         return;
     }
-    if (n <= 512u) tile_sort_group<2, 128>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
-    else if (n <= 1024u) tile_sort_group<3, 128>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    if (n <= 512u) tile_sort_group<2, 128, GHR_SORT_EMIT>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
+    else if (n <= 1024u) tile_sort_group<3, 128, GHR_SORT_EMIT>(g, n, s, s_keys, point_list, inst_line, rects, tx, ty, cap, tid);
     else {
         // Rare: a single tile with more instances than fit in LDS (and no k_tile_sort_big launch: sparse scene on average)
         if (wave == 1) return;
